@@ -1,0 +1,215 @@
+/*
+ * vislam_hip.h -- C ABI of the MI355X-native visual front-end (libvislam_hip.so).
+ *
+ * This is the drop-in boundary for the Camera/Matcher/RANSAC hot path of
+ * MecatronicaUSB/vi-slam.  The reference has no FFI of its own: its "GPU path" is
+ * three C++ classes that call OpenCV's CUDA module.  Every entry point below
+ * replaces one of those OpenCV(-CUDA) call sites; the reference file:line it
+ * replaces is cited next to it.  The C++ adapter classes in vi-slam_amd/host/ keep
+ * the reference's CameraGPU / MatcherGPU / VISystemGPU surface on top of this ABI.
+ *
+ * Conventions
+ *   - plain C, no torch / OpenCV types; pointers + sizes only.
+ *   - return value: VIS_OK (0) or a negative VIS_E_* code; never throws, never exits
+ *     (reference convention is cout+exit / cv::Exception; adapters decide).
+ *   - a vis_ctx is bound to ONE device and is NOT thread-safe (the reference is
+ *     single-threaded, one frame in flight: src/main_vi_slamGPU.cpp:118-123).
+ *   - "host" pointers are ordinary CPU memory; "dev" pointers are HIP device
+ *     memory on the context's device (e.g. torch tensor .data_ptr()).
+ *   - all functions are synchronous w.r.t. their host outputs unless they say
+ *     "async": those enqueue on the context stream (vis_set_stream) and return.
+ */
+#ifndef VISLAM_HIP_H_
+#define VISLAM_HIP_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIS_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------- */
+enum {
+    VIS_OK = 0,
+    VIS_E_INVALID = -1,     /* bad argument / shape                            */
+    VIS_E_NODEVICE = -2,    /* no HIP device (reference: main_vi_slamGPU.cpp:44-48 returns -1) */
+    VIS_E_HIP = -3,         /* a HIP runtime call failed (see vis_last_error)  */
+    VIS_E_CAPACITY = -4,    /* caller buffer too small / internal cap exceeded */
+    VIS_E_STATE = -5,       /* call order wrong (e.g. slot empty, no plan)     */
+    VIS_E_NOMEM = -6
+};
+
+/* ---- POD layouts crossing the ABI --------------------------------------- */
+/* same field order and size (28 B) as cv::KeyPoint (Frame::keypoints, include/Camera.hpp:50) */
+typedef struct vis_keypoint {
+    float x, y;          /* level-0 pixel coordinates                            */
+    float size;          /* 31 * scale(octave)                                   */
+    float angle;         /* degrees [0,360)                                      */
+    float response;      /* Harris response                                      */
+    int32_t octave;      /* pyramid level                                        */
+    int32_t class_id;    /* -1                                                   */
+} vis_keypoint;
+
+/* same field order and size (16 B) as cv::DMatch (Matcher::matches, include/Matcher.hpp:52) */
+typedef struct vis_dmatch {
+    int32_t queryIdx, trainIdx, imgIdx;
+    float distance;      /* Hamming distance as float, like BFMatcher           */
+} vis_dmatch;
+
+enum { VIS_SYM_REFERENCE_EFFECTIVE = 0,  /* mutual best + ratio on direction 1 only:
+                                            what src/Matcher.cpp:96-144 effectively does */
+       VIS_SYM_INTENDED = 1 };           /* ratio on both directions + mutual best      */
+
+enum { VIS_DESC_BYTES = 32, VIS_MAX_LEVELS = 16, VIS_MAX_GRID_ROOT = 32 };
+
+/* One POD with every knob of the path.  Defaults (vis_default_params) are the
+ * reference's hard-coded constants; see SURVEY.md section 5 "Config / flags". */
+typedef struct vis_params {
+    /* ORB -- cv::ORB::create(nfeatures) defaults; src/Camera.cpp:127 (200), src/CameraGPU.cpp:99 (1000) */
+    int32_t nfeatures;        /* 1000 */
+    int32_t nlevels;          /* 8    */
+    float   scale_factor;     /* 1.2f */
+    int32_t edge_threshold;   /* 31   */
+    int32_t patch_size;       /* 31   */
+    int32_t fast_threshold;   /* 20   */
+    /* matcher post-filters -- src/Matcher.cpp:103 (0.8f), calibration/calibrationEUROC.xml:54 (49) */
+    float   ratio;            /* 0.8f */
+    int32_t n_cells;          /* 49   */
+    int32_t w_size, h_size;   /* Matcher::setImageDimensions, src/Matcher.cpp:30-34 */
+    int32_t sym_mode;         /* VIS_SYM_* */
+    /* essential RANSAC -- src/VISystem.cpp:1680 (prob 0.999, thr 1.0); OpenCV 3.2 maxIters = 1000 */
+    double  ransac_prob;      /* 0.999 */
+    double  ransac_threshold; /* 1.0 px */
+    int32_t ransac_max_iters; /* 1000 */
+    int32_t ransac_adaptive;  /* 1 = OpenCV adaptive stop, 0 = always max_iters (timing runs) */
+    uint64_t ransac_seed;     /* 0xFFFFFFFFFFFFFFFF = cv::RNG((uint64)-1) */
+    /* intrinsics -- calibration/calibrationEUROC.xml:20 */
+    double  fx, fy, cx, cy;
+    /* F2FRansac -- src/VISystem.cpp:709 (1000 iterations), :523 (threshold 370) */
+    int32_t f2f_iters;        /* 1000 */
+    double  f2f_threshold;    /* 370  */
+} vis_params;
+
+/* wall-clock of the last call's device work, from hipEvents on the context stream
+ * (mirrors the elapsed_* members, include/Camera.hpp:121-126, include/Matcher.hpp:63-66) */
+typedef struct vis_timings {
+    float ms_total;
+    float ms_pyramid;      /* resize chain                     */
+    float ms_fast;         /* FAST score + NMS, all levels     */
+    float ms_select;       /* histogram cut + Harris + top-N   */
+    float ms_describe;     /* IC angle + blur + rBRIEF         */
+    float ms_knn;          /* both knn directions              */
+    float ms_filter;       /* ratio/sym/sort/grid              */
+    float ms_pose;         /* essential RANSAC + recoverPose   */
+    int32_t launches_fast; /* number of FAST kernel launches in the last call */
+    int32_t launches_total;
+} vis_timings;
+
+typedef struct vis_ctx vis_ctx;
+
+/* ---- lifetime ------------------------------------------------------------ */
+const char* vis_version(void);
+const char* vis_strerror(int code);
+/* replaces cv::cuda::getCudaEnabledDeviceCount(), src/main_vi_slamGPU.cpp:41 */
+int  vis_device_count(void);
+/* replaces cv::cuda::setDevice(0), src/main_vi_slamGPU.cpp:43, plus object construction */
+int  vis_create(int device, vis_ctx** out);
+void vis_destroy(vis_ctx* ctx);
+const char* vis_last_error(vis_ctx* ctx);
+void vis_default_params(vis_params* p);
+/* replaces cuda::ORB::create(1000) (src/CameraGPU.cpp:99), createBFMatcher(NORM_HAMMING)
+ * (src/MatcherGPU.cpp:30), Matcher::setImageDimensions (src/Matcher.cpp:30-34) */
+int  vis_set_params(vis_ctx* ctx, const vis_params* p);
+int  vis_get_params(vis_ctx* ctx, vis_params* p);
+/* enqueue on this hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = context's own stream */
+int  vis_set_stream(vis_ctx* ctx, void* hip_stream);
+int  vis_last_timings(vis_ctx* ctx, vis_timings* t);
+/* per-level geometry the context derived from params for a w x h input
+ * (ORB_Impl::detectAndCompute level sizes / quotas) */
+int  vis_level_geometry(vis_ctx* ctx, int w, int h, int32_t* widths, int32_t* heights,
+                        float* scales, int32_t* quotas);
+
+/* ---- single-frame API: one call per OpenCV(-CUDA) call site --------------- */
+/* Camera::Update, src/Camera.cpp:63-72: copy + 4x half-resolution levels.
+ * out_levels[l] (l=1..4) receives (w>>l)*(h>>l) bytes, tightly packed; out_levels[0] may be NULL. */
+int  vis_camera_update(vis_ctx* ctx, const uint8_t* img, int w, int h, int stride,
+                       uint8_t* const out_levels[5]);
+/* replaces frameGPU.upload + cuda::ORB::detectAndCompute + descriptorsGPU.download,
+ * src/CameraGPU.cpp:81,99-103 (CPU twin: src/Camera.cpp:87).  Keypoints/descriptors stay
+ * resident in device slot `frame_slot` for the matcher (Frame list, include/Camera.hpp:104). */
+int  vis_orb_detect_compute(vis_ctx* ctx, const uint8_t* img, int w, int h, int stride,
+                            int frame_slot, vis_keypoint* kps_out, uint8_t* desc_out,
+                            int cap, int* n_out);
+/* replaces descriptorsGPU[0/1].upload + 2x cuda knnMatch(k=2), src/MatcherGPU.cpp:49-56
+ * (CPU twin src/Matcher.cpp:86,88).  out12: n_q x 2, out21: n_t x 2 (missing neighbours:
+ * trainIdx = -1).  n_q/n_t are the slots' keypoint counts. */
+int  vis_bf_knn2_hamming(vis_ctx* ctx, int slot_q, int slot_t,
+                         vis_dmatch* out12, vis_dmatch* out21);
+/* same, on caller-provided host descriptor arrays (n x 32 bytes) */
+int  vis_bf_knn2_hamming_host(vis_ctx* ctx, const uint8_t* desc_q, int n_q,
+                              const uint8_t* desc_t, int n_t,
+                              vis_dmatch* out12, vis_dmatch* out21);
+/* fused Matcher::computeBestMatches (ratio, symmetry, y-sort, grid-cell best),
+ * src/Matcher.cpp:353-367 -> 96-244; writes goodMatches (<= root^2).  Also returns the
+ * symmetric matches when sym_out != NULL (Matcher::matches, capacity sym_cap). */
+int  vis_good_matches(vis_ctx* ctx, int slot_prev, int slot_cur,
+                      vis_dmatch* good, int cap, int* n_good,
+                      vis_dmatch* sym_out, int sym_cap, int* n_sym);
+/* same filter chain on host-provided knn results + keypoints (unit-testable piece) */
+int  vis_good_matches_host(vis_ctx* ctx, const vis_keypoint* kps1, int n1,
+                           const vis_keypoint* kps2, int n2,
+                           const vis_dmatch* knn12, const vis_dmatch* knn21,
+                           vis_dmatch* good, int cap, int* n_good,
+                           vis_dmatch* sym_out, int sym_cap, int* n_sym);
+/* replaces cv::findEssentialMat(p1,p2,focal,pp,RANSAC,0.999,1.0), src/VISystem.cpp:1679-1680.
+ * p1xy/p2xy: m x 2 floats (pixels).  E row-major. mask may be NULL. */
+int  vis_essential_ransac(vis_ctx* ctx, const float* p1xy, const float* p2xy, int m,
+                          double E[9], uint8_t* mask, int* n_inliers, int* iters_run);
+/* replaces cv::recoverPose(E,p1,p2,R,t,focal,pp), src/VISystem.cpp:1701 */
+int  vis_recover_pose(vis_ctx* ctx, const double E[9], const float* p1xy, const float* p2xy,
+                      int m, double R[9], double t[3], int* n_good);
+/* VISystem::F2FRansac, src/VISystem.cpp:612-769.  rot: 3x3 row-major f32 (IMU rotation),
+ * sample_idx: 2*iters explicit sample indices (the reference uses unseeded rand(), :712-713),
+ * scale: |t_GT|.  out: 3 floats. */
+int  vis_f2f_ransac(vis_ctx* ctx, const vis_keypoint* pts1, const vis_keypoint* pts2, int m,
+                    const float rot[9], const int32_t* sample_idx, int iters,
+                    float scale, float out_t[3], int* count_max);
+
+/* ---- batched stream API (throughput path) --------------------------------- */
+/* Plan device buffers for batches of up to `max_frames` w x h frames.  Frames in a
+ * batch are consecutive frames of ONE camera stream: frame i is matched against frame
+ * i-1 (Camera::computeGoodMatches: query = last saved frame, src/Camera.cpp:146-157);
+ * frame 0 is matched against the last frame of the previous vis_batch_run call
+ * (carried on device), or not at all after vis_batch_reset. */
+int  vis_batch_plan(vis_ctx* ctx, int w, int h, int stride, int max_frames);
+int  vis_batch_reset(vis_ctx* ctx);
+enum { VIS_STAGE_DETECT = 1, VIS_STAGE_MATCH = 2, VIS_STAGE_POSE = 4, VIS_STAGE_ALL = 7 };
+/* async on the context stream: d_frames = n_frames images resident in HBM (dev ptr,
+ * row stride from the plan, frame stride = stride*h). */
+int  vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n_frames, int stages);
+int  vis_batch_sync(vis_ctx* ctx);
+/* copy results of the last batch to host (synchronises). Any pointer may be NULL. */
+int  vis_batch_get_keypoints(vis_ctx* ctx, int frame, vis_keypoint* kps, uint8_t* desc,
+                             int cap, int* n_out);
+int  vis_batch_get_knn(vis_ctx* ctx, int frame, vis_dmatch* out12, int cap12, int* n12,
+                       vis_dmatch* out21, int cap21, int* n21);
+int  vis_batch_get_matches(vis_ctx* ctx, int frame, vis_dmatch* good, int cap, int* n_good,
+                           int* n_sym);
+int  vis_batch_get_pose(vis_ctx* ctx, int frame, double E[9], double R[9], double t[3],
+                        int* n_inliers, int* n_pose_good, int* iters_run);
+/* device-side error/overflow flags of the last batch (0 = clean) */
+int  vis_batch_status(vis_ctx* ctx, int* flags);
+
+/* ---- synthetic EuRoC-shaped stream ("S-752") -------- */
+/* Integer-only generator, identical bytes on every machine.  canvas: canvas_dim^2 bytes. */
+int  vis_synth_canvas(uint8_t* canvas, int canvas_dim, uint64_t seed);
+int  vis_synth_frame(const uint8_t* canvas, int canvas_dim, uint64_t seed, int t,
+                     int w, int h, uint8_t* out, int out_stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VISLAM_HIP_H_ */

@@ -1,0 +1,88 @@
+/*
+ * vis_oracle.h -- CPU ORACLE for the vi-slam Camera/Matcher/RANSAC hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the shipped product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * liboracle (oracle/_build/libvis_oracle.so).  The HIP library never links, includes
+ * or calls anything in this directory.
+ *
+ * What it restates: the arithmetic the reference's CPU path performs THROUGH OpenCV 3.2
+ * (cv::ORB::detectAndCompute at /root/reference/src/Camera.cpp:87, BFMatcher::knnMatch
+ * at src/Matcher.cpp:86,88, findEssentialMat/recoverPose at src/VISystem.cpp:1680,1701)
+ * plus the reference's own post-filters (src/Matcher.cpp:96-367) and F2FRansac
+ * (src/VISystem.cpp:612-769).  OpenCV 3.2 is an un-vendored dependency (README.md:3,15;
+ * opencv_install.md:47-63) that is absent from this environment, and the reference
+ * ships no tests, fixtures or golden vectors:
+ *
+ *      ****  PARITY UNPINNED versus real OpenCV  ****
+ *
+ * The OpenCV-owned steps follow the published algorithms as written up in SURVEY.md
+ * Appendix A; every function cites the reference call site it stands in for.  The
+ * reference cannot be compiled here (needs OpenCV + ROS + Eigen + Ceres), so there is
+ * no oracle/_ref build.
+ */
+#ifndef VIS_ORACLE_H_
+#define VIS_ORACLE_H_
+#include "../include/vislam_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ORB_Impl level sizes / scales / per-level quotas (Appendix A.1 items 2,3) */
+int orc_level_geometry(const vis_params* p, int w, int h, int32_t* widths, int32_t* heights,
+                       float* scales, int32_t* quotas);
+/* cv::resize(..., INTER_LINEAR) 8-bit fixed-point path (Appendix A.1 item 2) */
+int orc_resize_linear(const uint8_t* src, int sw, int sh, int sstride,
+                      uint8_t* dst, int dw, int dh, int dstride);
+/* Camera::Update half pyramid, src/Camera.cpp:68-70 (resize 0.5,0.5 == 2x2 box mean) */
+int orc_half_pyramid(const uint8_t* img, int w, int h, int stride, uint8_t* const out_levels[5]);
+/* cv::FAST(img, thr, nonmax=true): keypoints in row-major order; also the raw score map
+ * (0 for non-corners) when score_map != NULL (w*h bytes). returns count or <0 */
+int orc_fast_detect(const uint8_t* img, int w, int h, int stride, int threshold,
+                    int32_t* xs, int32_t* ys, int32_t* scores, int cap, uint8_t* score_map);
+/* GaussianBlur 7x7 sigma 2, BORDER_REFLECT_101, 8-bit fixed point (Appendix A.1 item 8) */
+int orc_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
+/* cv::ORB::detectAndCompute(img, noArray(), kps, desc), src/Camera.cpp:84-92.
+ * Output in canonical order (octave asc, response desc, y asc, x asc). */
+int orc_orb_detect_compute(const vis_params* p, const uint8_t* img, int w, int h, int stride,
+                           vis_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+/* BFMatcher(NORM_HAMMING).knnMatch(k=2) both directions, src/Matcher.cpp:83-94 */
+int orc_knn2_hamming(const uint8_t* d1, int n1, const uint8_t* d2, int n2,
+                     vis_dmatch* out12, vis_dmatch* out21);
+/* Matcher::computeBestMatches, src/Matcher.cpp:353-367 (-> 96-144, 329-352, 171-244) */
+int orc_good_matches(const vis_params* p, const vis_keypoint* kps1, int n1,
+                     const vis_keypoint* kps2, int n2,
+                     const vis_dmatch* knn12, const vis_dmatch* knn21,
+                     vis_dmatch* good, int cap, int* n_good,
+                     vis_dmatch* sym_out, int sym_cap, int* n_sym);
+/* 5-point minimal solver on 5 normalised correspondences: up to 10 E (row-major, unit
+ * Frobenius norm, x2^T E x1 = 0), ordered by ascending root z. returns count */
+int orc_five_point(const double* q1xy, const double* q2xy, double* Es);
+/* findEssentialMat(..., RANSAC, prob, thr), src/VISystem.cpp:1679-1680 */
+int orc_essential_ransac(const vis_params* p, const float* p1xy, const float* p2xy, int m,
+                         double E[9], uint8_t* mask, int* n_inliers, int* iters_run);
+/* recoverPose, src/VISystem.cpp:1701 */
+int orc_recover_pose(const vis_params* p, const double E[9], const float* p1xy,
+                     const float* p2xy, int m, double R[9], double t[3], int* n_good);
+/* VISystem::F2FRansac, src/VISystem.cpp:612-769 */
+int orc_f2f_ransac(const vis_params* p, const vis_keypoint* pts1, const vis_keypoint* pts2, int m,
+                   const float rot[9], const int32_t* sample_idx, int iters,
+                   float scale, float out_t[3], int* count_max);
+/* the sample sequence cv::RNG((uint64)-1) + getSubset would draw: idx5[iters*5] */
+int orc_ransac_samples(uint64_t seed, int count, int iters, int32_t* idx5);
+
+/* whole per-frame CPU pipeline for the cpu_baseline leg: detect cur, match against prev
+ * (knn both directions as the reference does), filters, essential RANSAC, recoverPose. */
+typedef struct orc_frame_result {
+    int n_kp, n_sym, n_good, n_inliers, n_pose_good, iters_run;
+    double E[9], R[9], t[3];
+} orc_frame_result;
+int orc_pipeline_frame(const vis_params* p, const uint8_t* img, int w, int h, int stride,
+                       const vis_keypoint* prev_kps, const uint8_t* prev_desc, int n_prev,
+                       vis_keypoint* kps, uint8_t* desc, int cap, orc_frame_result* res);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

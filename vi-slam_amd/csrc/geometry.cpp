@@ -1,0 +1,163 @@
+// geometry.cpp -- host-side tables of the detector: pyramid level geometry, per-level feature
+// quotas, cv::resize fixed-point coefficient tables, grid-filter band limits, and the
+// integer-only synthetic stream generator.  Plain C++ (no device code).
+//
+// Follows what cv::ORB / cv::resize derive for the reference call site
+// /root/reference/src/Camera.cpp:87 (cv::ORB::detectAndCompute) -- see SURVEY.md Appendix A.1
+// items 2-3 -- and Matcher::bestMatchesFilter's window arithmetic (/root/reference/src/Matcher.cpp:171-216).
+#include "vis_internal.h"
+#include <cmath>
+#include <cstring>
+
+static inline int round_half_even(double v) { return (int)std::lrint(v); }
+
+int vis_compute_levels(const vis_params& p, int w, int h, int stride0, LevelInfo* lv) {
+    if (p.nlevels < 1 || p.nlevels > VIS_MAX_LEVELS || p.nfeatures < 1) return VIS_E_INVALID;
+    if (w < 2 * p.edge_threshold + 8 || h < 2 * p.edge_threshold + 8 || w > 4095 || h > 4095) return VIS_E_INVALID;
+    const double sf = (double)p.scale_factor;            // ORB keeps the float argument in a double member
+    for (int l = 0; l < p.nlevels; l++) {
+        float s = (float)std::pow(sf, (double)l);
+        lv[l].scale = s;
+        lv[l].w = round_half_even((double)((float)w / s));
+        lv[l].h = round_half_even((double)((float)h / s));
+        if (lv[l].w < 8 || lv[l].h < 8) return VIS_E_INVALID;
+        lv[l].stride = (l == 0) ? stride0 : ((lv[l].w + 63) / 64) * 64;
+        lv[l].frame_bytes = (size_t)lv[l].stride * lv[l].h;
+        lv[l].cand_cap = ((lv[l].w + 1) / 2) * ((lv[l].h + 1) / 2);
+        lv[l].tiles_x = (lv[l].w + 63) / 64;
+        lv[l].tiles_y = (lv[l].h + 31) / 32;
+    }
+    float factor = (float)(1.0 / sf);
+    float nd = p.nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)p.nlevels));
+    int sum = 0;
+    for (int l = 0; l < p.nlevels - 1; l++) {
+        lv[l].quota = round_half_even((double)nd);
+        sum += lv[l].quota;
+        nd *= factor;
+    }
+    lv[p.nlevels - 1].quota = std::max(p.nfeatures - sum, 0);
+    for (int l = 0; l < p.nlevels; l++) {
+        int q = lv[l].quota;
+        // survivors of the FAST-score cut: 2*quota plus ties at the cut (FAST scores are small
+        // integers, ties are common); kept after the Harris cut: quota plus (rare) ties.
+        int sc = 2 * q + q / 2 + 256;
+        int pw = 64; while (pw < sc) pw <<= 1;
+        if (pw > 8192) return VIS_E_INVALID;             // LDS sort limit (64 KiB of keys)
+        lv[l].surv_cap = pw;
+        lv[l].keep_cap = q + q / 8 + 32;
+    }
+    return VIS_OK;
+}
+
+// cv::resize(INTER_LINEAR), 8-bit: xofs/ialpha/yofs/ibeta exactly as resize() builds them
+// (INTER_RESIZE_COEF_BITS = 11; coefficient = saturate_cast<short>(float_coef * 2048)).
+void vis_resize_tables(int sw, int sh, int dw, int dh, std::vector<int32_t>& xofs,
+                       std::vector<int16_t>& ialpha, std::vector<int32_t>& yofs,
+                       std::vector<int16_t>& ibeta) {
+    const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+    xofs.resize(dw); ialpha.resize(2 * (size_t)dw); yofs.resize(2 * (size_t)dh); ibeta.resize(2 * (size_t)dh);
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)std::floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[dx] = sx;
+        ialpha[2 * dx] = (int16_t)round_half_even((double)((1.f - fx) * 2048));
+        ialpha[2 * dx + 1] = (int16_t)round_half_even((double)(fx * 2048));
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)std::floor(fy);
+        fy -= sy;
+        // row indices are clamped (coefficients are not): store both clamped rows
+        int s0 = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);
+        int s1 = sy + 1 < 0 ? 0 : (sy + 1 >= sh ? sh - 1 : sy + 1);
+        yofs[2 * dy] = s0; yofs[2 * dy + 1] = s1;
+        ibeta[2 * dy] = (int16_t)round_half_even((double)((1.f - fy) * 2048));
+        ibeta[2 * dy + 1] = (int16_t)round_half_even((double)(fy * 2048));
+    }
+}
+
+// Matcher::bestMatchesFilter window limits: winW = w_size/floor(sqrt(n)) stored as float, limits
+// accumulated in float exactly like `h_final = h_final + winHSize` (src/Matcher.cpp:177-178,203,229).
+void vis_grid_limits(const vis_params& p, int* root, std::vector<float>& hf, std::vector<float>& wf) {
+    int r = (int)std::floor(std::sqrt((double)p.n_cells));
+    if (r < 1) r = 1;
+    if (r > VIS_MAX_GRID_ROOT) r = VIS_MAX_GRID_ROOT;
+    *root = r;
+    float winW = (float)(p.w_size / std::floor(std::sqrt((double)p.n_cells)));
+    float winH = (float)(p.h_size / std::floor(std::sqrt((double)p.n_cells)));
+    hf.resize(r); wf.resize(r);
+    float a = winH, b = winW;
+    for (int j = 0; j < r; j++) { hf[j] = a; wf[j] = b; a = a + winH; b = b + winW; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Synthetic EuRoC-shaped stream ("S-752"); integer arithmetic only so the
+// bytes are identical on every host.  PRNG = xorshift64*.
+struct XorShift64s {
+    uint64_t s;
+    explicit XorShift64s(uint64_t seed) : s(seed ? seed : 0x9E3779B97F4A7C15ULL) {}
+    uint64_t next() { s ^= s >> 12; s ^= s << 25; s ^= s >> 27; return s * 0x2545F4914F6CDD1DULL; }
+    uint32_t below(uint32_t n) { return (uint32_t)((next() >> 33) % n); }
+};
+
+extern "C" int vis_synth_canvas(uint8_t* canvas, int dim, uint64_t seed) {
+    if (!canvas || dim < 64) return VIS_E_INVALID;
+    XorShift64s rng(seed);
+    const size_t n = (size_t)dim * dim;
+    std::memset(canvas, 128, n);
+    const double area_ratio = (double)n / (4096.0 * 4096.0);
+    const int nrect = std::max(8, (int)(24000 * area_ratio));
+    const int nblob = std::max(8, (int)(12000 * area_ratio));
+    for (int i = 0; i < nrect; i++) {
+        int rw = 6 + (int)rng.below(59), rh = 6 + (int)rng.below(59);      // 6..64
+        int x = (int)rng.below((uint32_t)dim), y = (int)rng.below((uint32_t)dim);
+        uint8_t v = (uint8_t)rng.below(256);
+        for (int yy = y; yy < std::min(dim, y + rh); yy++) std::memset(canvas + (size_t)yy * dim + x, v, (size_t)std::min(rw, dim - x));
+    }
+    for (int i = 0; i < nblob; i++) {
+        int s = 3 + (int)rng.below(5);                                    // 3..7
+        int x = (int)rng.below((uint32_t)dim), y = (int)rng.below((uint32_t)dim);
+        uint8_t v = (uint8_t)rng.below(256);
+        for (int yy = y; yy < std::min(dim, y + s); yy++) std::memset(canvas + (size_t)yy * dim + x, v, (size_t)std::min(s, dim - x));
+    }
+    // one 3x3 box blur, replicate border, rounded integer mean
+    std::vector<uint8_t> src(canvas, canvas + n);
+    for (int y = 0; y < dim; y++) {
+        int y0 = y > 0 ? y - 1 : 0, y1 = y < dim - 1 ? y + 1 : dim - 1;
+        for (int x = 0; x < dim; x++) {
+            int x0 = x > 0 ? x - 1 : 0, x1 = x < dim - 1 ? x + 1 : dim - 1;
+            int s = src[(size_t)y0 * dim + x0] + src[(size_t)y0 * dim + x] + src[(size_t)y0 * dim + x1] +
+                    src[(size_t)y * dim + x0] + src[(size_t)y * dim + x] + src[(size_t)y * dim + x1] +
+                    src[(size_t)y1 * dim + x0] + src[(size_t)y1 * dim + x] + src[(size_t)y1 * dim + x1];
+            canvas[(size_t)y * dim + x] = (uint8_t)((s + 4) / 9);
+        }
+    }
+    return VIS_OK;
+}
+
+extern "C" int vis_synth_frame(const uint8_t* canvas, int dim, uint64_t seed, int t,
+                               int w, int h, uint8_t* out, int out_stride) {
+    if (!canvas || !out || w < 1 || h < 1 || w >= dim || h >= dim || out_stride < w || t < 0) return VIS_E_INVALID;
+    XorShift64s rng(seed ^ 0xD1B54A32D192ED03ULL);
+    const int rx = dim - w, ry = dim - h;
+    const int ox = (int)rng.below((uint32_t)rx), oy = (int)rng.below((uint32_t)ry);
+    const int x0 = (int)(((int64_t)ox + 12LL * t) % rx), y0 = (int)(((int64_t)oy + 8LL * t) % ry);
+    for (int y = 0; y < h; y++) {
+        const uint8_t* s = canvas + (size_t)(y0 + y) * dim + x0;
+        uint8_t* d = out + (size_t)y * out_stride;
+        for (int x = 0; x < w; x++) {
+            // counter-based per-pixel noise in {-2..2} (splitmix64 finaliser)
+            uint64_t z = seed + 0x9E3779B97F4A7C15ULL * (((uint64_t)(uint32_t)t << 32) + (uint64_t)((uint32_t)y * (uint32_t)w + (uint32_t)x) + 1ULL);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+            z ^= z >> 31;
+            int v = (int)s[x] + (int)(z % 5) - 2;
+            d[x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+    }
+    return VIS_OK;
+}

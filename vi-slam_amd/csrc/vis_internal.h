@@ -1,0 +1,120 @@
+// vis_internal.h -- internal declarations of libvislam_hip (MI355X / gfx950 only).
+// Product code: never includes or links anything under oracle/.
+#ifndef VIS_INTERNAL_H_
+#define VIS_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/vislam_hip.h"
+
+#define VIS_NSLOTS 32            // device keyframe slots of the single-frame API (Camera::frameList)
+#define VIS_RANSAC_MAX_M 8192    // max correspondences per RANSAC problem
+#define VIS_MAX_MODELS 10
+
+struct LevelInfo {
+    int w, h, stride;            // stride: bytes per row of the level buffer (level 0: caller's)
+    int quota;                   // nfeaturesPerLevel
+    float scale;                 // layerScale
+    size_t frame_bytes;          // stride*h
+    int cand_cap;                // ceil(w/2)*ceil(h/2): NMS upper bound, cannot overflow
+    int surv_cap;                // survivors of the FAST cut (2*quota + ties), LDS sort size
+    int keep_cap;                // kept per level (quota + ties)
+    int tiles_x, tiles_y;        // FAST tiles
+};
+
+// device-resident compact kNN entry: key = (dist << 16) | trainIdx, 0xFFFFFFFF = none
+struct PoseOut {
+    double E[9], R[9], t[3];
+    int n_inliers, n_pose_good, iters_run, n_points;
+};
+
+struct Plan {
+    int w = 0, h = 0, stride = 0, B = 0, L = 0;
+    int nrec = 0;                // keypoint/descriptor records (batch: B+1, single: VIS_NSLOTS)
+    int kcap = 0;                // keypoints per record (sum of keep_cap)
+    int npairs = 0;              // pair result capacity
+    int root = 0;                // grid root
+    LevelInfo lv[VIS_MAX_LEVELS];
+    // ---- device buffers
+    uint8_t* d_stage = nullptr;              // single-frame upload staging (stride x h)
+    uint8_t* d_pyr[VIS_MAX_LEVELS] = {};     // level l >= 1: B x h_l x stride_l
+    int32_t* d_xofs[VIS_MAX_LEVELS] = {};    // resize tables (level l from l-1)
+    int16_t* d_ialpha[VIS_MAX_LEVELS] = {};
+    int32_t* d_yofs[VIS_MAX_LEVELS] = {};
+    int16_t* d_ibeta[VIS_MAX_LEVELS] = {};
+    uint32_t* d_cand[VIS_MAX_LEVELS] = {};   // B x cand_cap packed (score<<24 | y<<12 | x)
+    int32_t* d_cand_cnt = nullptr;           // B x L
+    int32_t* d_hist = nullptr;               // B x L x 256
+    int32_t* d_seg_cnt = nullptr;            // B x L kept counts
+    float4*  d_seg_kp[VIS_MAX_LEVELS] = {};  // B x keep_cap (x, y, response, unused)
+    int32_t* d_flags = nullptr;              // device error flags (1 word)
+    // records
+    vis_keypoint* d_kps = nullptr;           // nrec x kcap
+    uint8_t* d_desc = nullptr;               // nrec x kcap x 32
+    int32_t* d_nkp = nullptr;                // nrec
+    // pairs
+    int32_t* d_pair_q = nullptr;             // npairs: query record index (-1 = no pair)
+    int32_t* d_pair_t = nullptr;
+    uint32_t* d_knn12 = nullptr;             // npairs x kcap x 2 keys
+    uint32_t* d_knn21 = nullptr;
+    vis_dmatch* d_sym = nullptr;             // npairs x kcap
+    int32_t* d_nsym = nullptr;
+    vis_dmatch* d_good = nullptr;            // npairs x root^2
+    int32_t* d_ngood = nullptr;
+    float* d_p1 = nullptr;                   // npairs x root^2 x 2
+    float* d_p2 = nullptr;
+    float* d_hf = nullptr;                   // root band limits (float accumulation on host)
+    float* d_wf = nullptr;
+    // pose
+    int32_t* d_samples = nullptr;            // npairs x max_iters x 5
+    double* d_models = nullptr;              // npairs x max_iters x 10 x 9
+    int32_t* d_counts = nullptr;             // npairs x max_iters x 10  (-1 = no model)
+    int32_t* d_rstate = nullptr;             // npairs x 4: niters, maxGood, bestIter, bestModel
+    PoseOut* d_pose = nullptr;               // npairs
+    int max_iters = 0;
+    bool have_prev = false;                  // batch: record 0 holds the previous batch's last frame
+    int last_n = 0;                          // frames in the last batch
+};
+
+struct vis_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    vis_params p;
+    std::string err;
+    Plan* single = nullptr;
+    Plan* batch = nullptr;
+    vis_timings tm;
+    hipEvent_t ev[10];
+    bool ev_ok = false;
+    // grow-only scratch for the *_host entry points
+    void* d_scratch = nullptr; size_t scratch_bytes = 0;
+    int slot_valid[VIS_NSLOTS];
+};
+
+#define HIPCHK(ctx, call)                                                          \
+    do { hipError_t e_ = (call);                                                   \
+         if (e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); \
+                                 return VIS_E_HIP; } } while (0)
+
+// ---- host-side geometry / tables (geometry.cpp) ----
+int  vis_compute_levels(const vis_params& p, int w, int h, int stride0, LevelInfo* lv);
+void vis_resize_tables(int sw, int sh, int dw, int dh, std::vector<int32_t>& xofs,
+                       std::vector<int16_t>& ialpha, std::vector<int32_t>& yofs,
+                       std::vector<int16_t>& ibeta);
+void vis_grid_limits(const vis_params& p, int* root, std::vector<float>& hf, std::vector<float>& wf);
+
+// ---- plan management (plan.hip) ----
+int  plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npairs, Plan** out);
+void plan_destroy(Plan* pl);
+
+// ---- kernel launchers (each enqueues on ctx->stream) ----
+int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int rec0);
+int launch_match(vis_ctx* ctx, Plan* pl, int npairs);
+int launch_filter(vis_ctx* ctx, Plan* pl, int npairs);
+int launch_pose(vis_ctx* ctx, Plan* pl, int npairs);
+int launch_half_pyramid(vis_ctx* ctx, const uint8_t* d_img, int w, int h, int stride, uint8_t* d_out[5]);
+
+#endif
