@@ -1,0 +1,177 @@
+"""ctypes binding of the CPU ORACLE (oracle/_build/libvis_oracle.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "_build", "libvis_oracle.so")
+lib = C.CDLL(LIB)
+
+import sys
+sys.path.insert(0, os.path.join(ROOT, "vi-slam_amd"))
+from vislam import DMATCH_DTYPE, KEYPOINT_DTYPE, Params  # noqa: E402  (POD layouts of the public header)
+
+vp, ci, ip = C.c_void_p, C.c_int, C.POINTER(C.c_int)
+
+
+class FrameResult(C.Structure):
+    _fields_ = [("n_kp", ci), ("n_sym", ci), ("n_good", ci), ("n_inliers", ci), ("n_pose_good", ci), ("iters_run", ci),
+                ("E", C.c_double * 9), ("R", C.c_double * 9), ("t", C.c_double * 3)]
+
+
+lib.orc_level_geometry.argtypes = [C.POINTER(Params), ci, ci, vp, vp, vp, vp]
+lib.orc_resize_linear.argtypes = [vp, ci, ci, ci, vp, ci, ci, ci]
+lib.orc_half_pyramid.argtypes = [vp, ci, ci, ci, C.POINTER(vp)]
+lib.orc_fast_detect.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
+lib.orc_gaussian_blur7.argtypes = [vp, ci, ci, ci, vp, ci]
+lib.orc_orb_detect_compute.argtypes = [C.POINTER(Params), vp, ci, ci, ci, vp, vp, ci, ip]
+lib.orc_knn2_hamming.argtypes = [vp, ci, vp, ci, vp, vp]
+lib.orc_good_matches.argtypes = [C.POINTER(Params), vp, ci, vp, ci, vp, vp, vp, ci, ip, vp, ci, ip]
+lib.orc_five_point.argtypes = [vp, vp, vp]
+lib.orc_essential_ransac.argtypes = [C.POINTER(Params), vp, vp, ci, vp, vp, ip, ip]
+lib.orc_recover_pose.argtypes = [C.POINTER(Params), vp, vp, vp, ci, vp, vp, ip]
+lib.orc_f2f_ransac.argtypes = [C.POINTER(Params), vp, vp, ci, vp, vp, ci, C.c_float, vp, ip]
+lib.orc_ransac_samples.argtypes = [C.c_uint64, ci, ci, vp]
+lib.orc_pipeline_frame.argtypes = [C.POINTER(Params), vp, ci, ci, ci, vp, vp, ci, vp, vp, ci, C.POINTER(FrameResult)]
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(vp)
+
+
+def level_geometry(p, w, h):
+    L = p.nlevels
+    ws, hs, q = (np.zeros(L, np.int32) for _ in range(3))
+    sc = np.zeros(L, np.float32)
+    assert lib.orc_level_geometry(C.byref(p), w, h, _p(ws), _p(hs), _p(sc), _p(q)) == 0
+    return ws, hs, sc, q
+
+
+def resize_linear(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    assert lib.orc_resize_linear(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw) == 0
+    return dst
+
+
+def half_pyramid(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    levels = [np.empty((h >> l, w >> l), np.uint8) for l in range(5)]
+    arr = (vp * 5)(*[l.ctypes.data for l in levels])
+    assert lib.orc_half_pyramid(_p(img), w, h, img.strides[0], arr) == 0
+    return levels
+
+
+def fast_detect(img, threshold=20):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cap = w * h // 4 + 16
+    xs, ys, sc = (np.zeros(cap, np.int32) for _ in range(3))
+    smap = np.zeros((h, w), np.uint8)
+    n = lib.orc_fast_detect(_p(img), w, h, img.strides[0], threshold, _p(xs), _p(ys), _p(sc), cap, _p(smap))
+    assert n >= 0
+    return xs[:n].copy(), ys[:n].copy(), sc[:n].copy(), smap
+
+
+def gaussian_blur7(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros_like(img)
+    assert lib.orc_gaussian_blur7(_p(img), img.shape[1], img.shape[0], img.strides[0], _p(out), out.strides[0]) == 0
+    return out
+
+
+def orb_detect_compute(p, img, cap=None):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cap = cap or (2 * p.nfeatures + 1024)
+    kps = np.zeros(cap, KEYPOINT_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    n = ci(0)
+    rc = lib.orc_orb_detect_compute(C.byref(p), _p(img), w, h, img.strides[0], _p(kps), _p(desc), cap, C.byref(n))
+    assert rc == 0, rc
+    return kps[:n.value].copy(), desc[:n.value].copy()
+
+
+def knn2_hamming(d1, d2):
+    d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 32)
+    d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 32)
+    o12 = np.zeros((len(d1), 2), DMATCH_DTYPE)
+    o21 = np.zeros((len(d2), 2), DMATCH_DTYPE)
+    assert lib.orc_knn2_hamming(_p(d1), len(d1), _p(d2), len(d2), _p(o12), _p(o21)) == 0
+    return o12, o21
+
+
+def good_matches(p, kps1, kps2, knn12, knn21):
+    kps1 = np.ascontiguousarray(kps1, KEYPOINT_DTYPE)
+    kps2 = np.ascontiguousarray(kps2, KEYPOINT_DTYPE)
+    knn12 = np.ascontiguousarray(knn12, DMATCH_DTYPE)
+    knn21 = np.ascontiguousarray(knn21, DMATCH_DTYPE)
+    good = np.zeros(1024, DMATCH_DTYPE)
+    sym = np.zeros(max(len(kps1), 1), DMATCH_DTYPE)
+    ng, ns = ci(0), ci(0)
+    rc = lib.orc_good_matches(C.byref(p), _p(kps1), len(kps1), _p(kps2), len(kps2), _p(knn12), _p(knn21), _p(good), 1024,
+                              C.byref(ng), _p(sym), len(sym), C.byref(ns))
+    assert rc == 0, rc
+    return good[:ng.value].copy(), sym[:ns.value].copy()
+
+
+def five_point(q1, q2):
+    q1 = np.ascontiguousarray(q1, np.float64).reshape(5, 2)
+    q2 = np.ascontiguousarray(q2, np.float64).reshape(5, 2)
+    Es = np.zeros((10, 9), np.float64)
+    n = lib.orc_five_point(_p(q1), _p(q2), _p(Es))
+    return Es[:n].reshape(-1, 3, 3).copy()
+
+
+def essential_ransac(p, p1, p2):
+    p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+    E = np.zeros(9)
+    mask = np.zeros(max(len(p1), 1), np.uint8)
+    ni, it = ci(0), ci(0)
+    assert lib.orc_essential_ransac(C.byref(p), _p(p1), _p(p2), len(p1), _p(E), _p(mask), C.byref(ni), C.byref(it)) == 0
+    return E.reshape(3, 3), mask[:len(p1)], ni.value, it.value
+
+
+def recover_pose(p, E, p1, p2):
+    E = np.ascontiguousarray(E, np.float64).reshape(9)
+    p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+    R, t = np.zeros(9), np.zeros(3)
+    ng = ci(0)
+    assert lib.orc_recover_pose(C.byref(p), _p(E), _p(p1), _p(p2), len(p1), _p(R), _p(t), C.byref(ng)) == 0
+    return R.reshape(3, 3), t, ng.value
+
+
+def f2f_ransac(p, pts1, pts2, rot, sample_idx, scale):
+    pts1 = np.ascontiguousarray(pts1, KEYPOINT_DTYPE)
+    pts2 = np.ascontiguousarray(pts2, KEYPOINT_DTYPE)
+    rot = np.ascontiguousarray(rot, np.float32).reshape(9)
+    idx = np.ascontiguousarray(sample_idx, np.int32).reshape(-1)
+    out = np.zeros(3, np.float32)
+    cm = ci(0)
+    rc = lib.orc_f2f_ransac(C.byref(p), _p(pts1), _p(pts2), len(pts1), _p(rot), _p(idx), len(idx) // 2, C.c_float(scale), _p(out), C.byref(cm))
+    assert rc == 0, rc
+    return out, cm.value
+
+
+def ransac_samples(seed, count, iters):
+    idx = np.zeros((iters, 5), np.int32)
+    assert lib.orc_ransac_samples(C.c_uint64(seed), count, iters, _p(idx)) == 0
+    return idx
+
+
+def pipeline_frame(p, img, prev=None, cap=None):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cap = cap or (2 * p.nfeatures + 1024)
+    kps = np.zeros(cap, KEYPOINT_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    res = FrameResult()
+    pk, pd, pn = (None, None, 0) if prev is None else (prev[0], prev[1], len(prev[0]))
+    rc = lib.orc_pipeline_frame(C.byref(p), _p(img), w, h, img.strides[0], _p(pk), _p(pd), pn, _p(kps), _p(desc), cap, C.byref(res))
+    assert rc == 0, rc
+    return kps[:res.n_kp].copy(), desc[:res.n_kp].copy(), res

@@ -1,0 +1,109 @@
+"""GPU parity: ORB detect+describe through the C ABI vs the CPU oracle (bit-exact)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(vislam, n=1000, levels=8, w=752, h=480):
+    p = vislam.default_params()
+    p.nfeatures, p.nlevels, p.w_size, p.h_size = n, levels, w, h
+    return p
+
+
+def _assert_same(k, d, ok, od):
+    assert len(k) == len(ok), (len(k), len(ok))
+    for f in ("octave", "x", "y", "response", "angle", "size", "class_id"):
+        bad = np.nonzero(k[f] != ok[f])[0]
+        assert len(bad) == 0, (f, bad[:5], k[f][bad[:5]], ok[f][bad[:5]])
+    assert k.tobytes() == ok.tobytes()
+    diff = np.nonzero((d != od).any(axis=1))[0]
+    assert len(diff) == 0, ("descriptor rows differ", diff[:10])
+
+
+@pytest.mark.parametrize("t", [0, 1, 37])
+def test_orb_752x480_bit_exact(vislam, orc, ctx, canvas, t):
+    p = _params(vislam)
+    ctx.set_params(p)
+    img = vislam.synth_frame(canvas, t, 752, 480)
+    k, d = ctx.orb_detect_compute(img, slot=0)
+    ok, od = orc.orb_detect_compute(p, img)
+    assert 900 <= len(ok) <= 1100
+    _assert_same(k, d, ok, od)
+
+
+@pytest.mark.parametrize("w,h,n,levels", [(320, 240, 300, 8), (641, 479, 500, 5), (188, 120, 200, 3), (1024, 768, 2000, 4)])
+def test_orb_other_shapes(vislam, orc, ctx, canvas, w, h, n, levels):
+    p = _params(vislam, n, levels, w, h)
+    ctx.set_params(p)
+    img = vislam.synth_frame(canvas, 3, w, h)
+    k, d = ctx.orb_detect_compute(img, slot=1)
+    ok, od = orc.orb_detect_compute(p, img)
+    _assert_same(k, d, ok, od)
+
+
+def test_orb_random_noise_image(vislam, orc, ctx):
+    """dense corners everywhere: exercises ties at the FAST cut and big candidate lists"""
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (240, 320), dtype=np.uint8)
+    p = _params(vislam, 400, 6, 320, 240)
+    ctx.set_params(p)
+    k, d = ctx.orb_detect_compute(img, slot=0)
+    ok, od = orc.orb_detect_compute(p, img)
+    _assert_same(k, d, ok, od)
+
+
+def test_orb_flat_image_no_keypoints(vislam, orc, ctx):
+    p = _params(vislam, 500, 8, 320, 240)
+    ctx.set_params(p)
+    img = np.full((240, 320), 77, np.uint8)
+    k, d = ctx.orb_detect_compute(img, slot=0)
+    assert len(k) == 0 and len(d) == 0
+
+
+def test_orb_strided_input(vislam, orc, ctx, canvas):
+    p = _params(vislam, 500, 8, 400, 300)
+    ctx.set_params(p)
+    big = vislam.synth_frame(canvas, 9, 512, 300)
+    view = big[:, 50:450]                 # non-contiguous rows (stride 512)
+    img = np.ascontiguousarray(view)
+    k, d = ctx.orb_detect_compute(img, slot=0)
+    ok, od = orc.orb_detect_compute(p, img)
+    _assert_same(k, d, ok, od)
+
+
+def test_camera_update_half_pyramid(vislam, orc, ctx, canvas):
+    img = vislam.synth_frame(canvas, 2, 752, 480)
+    got = ctx.camera_update(img)
+    ref = orc.half_pyramid(img)
+    for l in range(5):
+        assert got[l].shape == ref[l].shape
+        assert (got[l] == ref[l]).all(), l
+
+
+def test_batch_matches_single(vislam, orc, canvas):
+    """batched device path == single-frame path == oracle, including the carried frame across batches"""
+    import torch
+    p = _params(vislam)
+    c = vislam.Context(0, p)
+    frames = np.stack([vislam.synth_frame(canvas, t, 752, 480) for t in range(5)])
+    dev = torch.from_numpy(frames).cuda()
+    c.batch_plan(752, 480, 752, 3)
+    c.batch_run(dev.data_ptr(), 3)
+    c.batch_sync()
+    assert c.batch_status() == 0
+    res = [c.batch_keypoints(i) for i in range(3)]
+    c.batch_run(dev.data_ptr() + 3 * 752 * 480, 2)
+    c.batch_sync()
+    res += [c.batch_keypoints(i) for i in range(2)]
+    prev = None
+    for t in range(5):
+        ok, od, r = orc.pipeline_frame(p, frames[t], prev)
+        _assert_same(res[t][0], res[t][1], ok, od)
+        prev = (ok, od)
+    # pair results of the second batch: frame 3 is matched against the carried frame 2
+    g, nsym = c.batch_matches(0)
+    o12, o21 = orc.knn2_hamming(res[2][1], res[3][1])
+    og, osym = orc.good_matches(p, res[2][0], res[3][0], o12, o21)
+    assert nsym == len(osym) and g.tobytes() == og.tobytes()
+    c.close()

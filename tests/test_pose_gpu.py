@@ -1,0 +1,119 @@
+"""GPU parity: essential RANSAC / recoverPose / F2FRansac vs the CPU oracle.
+Stated tolerance (floating point, FP64 on both sides, same algorithm, different libm):
+  E (unit Frobenius norm, sign-normalised): max abs diff <= 1e-9
+  R, t: max abs diff <= 1e-9 ; inlier mask, inlier count, iterations run: identical."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def two_view(n, seed, outliers=0.0, noise=0.0, depth=(4.0, 12.0)):
+    rng = np.random.default_rng(seed)
+    K = np.array([[458.654, 0, 367.215], [0, 458.654, 248.375], [0, 0, 1]])
+    ang = rng.normal(0, 0.05, 3)
+    th = np.linalg.norm(ang)
+    k = ang / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    t = rng.normal(0, 1, 3)
+    t /= np.linalg.norm(t)
+    X = np.stack([rng.uniform(-3, 3, n), rng.uniform(-2, 2, n), rng.uniform(*depth, n)], 1)
+    x1 = (K @ X.T).T
+    x1 = x1[:, :2] / x1[:, 2:]
+    X2 = (R @ X.T).T + t
+    x2 = (K @ X2.T).T
+    x2 = x2[:, :2] / x2[:, 2:]
+    x1 += rng.normal(0, noise, x1.shape)
+    x2 += rng.normal(0, noise, x2.shape)
+    nout = int(outliers * n)
+    x2[:nout] = rng.uniform(0, 480, (nout, 2))
+    return x1.astype(np.float32), x2.astype(np.float32), R, t
+
+
+def _cmpE(E, oE):
+    s = 1.0 if float((E * oE).sum()) >= 0 else -1.0
+    return np.abs(E - s * oE).max()
+
+
+@pytest.mark.parametrize("n,outl,noise,seed", [(49, 0.0, 0.0, 1), (49, 0.3, 0.3, 2), (200, 0.5, 0.5, 3), (30, 0.2, 0.2, 4), (6, 0, 0, 5), (5, 0, 0, 6), (4, 0, 0, 7)])
+def test_essential_ransac_and_pose(vislam, orc, ctx, n, outl, noise, seed):
+    p = vislam.default_params()
+    p.fy = p.fx
+    ctx.set_params(p)
+    x1, x2, R, t = two_view(n, seed, outl, noise)
+    E, mask, ninl, iters = ctx.essential_ransac(x1, x2)
+    oE, omask, oninl, oiters = orc.essential_ransac(p, x1, x2)
+    assert (ninl, iters) == (oninl, oiters)
+    assert (mask == omask).all()
+    if oninl == 0:
+        assert np.abs(E).max() == 0
+        return
+    assert _cmpE(E, oE) <= TOL
+    Rg, tg, ng = ctx.recover_pose(oE, x1, x2)
+    Ro, to, no = orc.recover_pose(p, oE, x1, x2)
+    assert ng == no
+    assert np.abs(Rg - Ro).max() <= TOL and np.abs(tg - to).max() <= TOL
+    if outl == 0.0 and n >= 30:       # sanity against ground truth
+        assert np.abs(Ro - R).max() < 1e-3 and np.abs(to - t).max() < 1e-3
+
+
+def test_ransac_fixed_iterations(vislam, orc, ctx):
+    p = vislam.default_params()
+    p.fy = p.fx
+    p.ransac_adaptive = 0
+    p.ransac_max_iters = 300
+    ctx.set_params(p)
+    x1, x2, R, t = two_view(400, 11, 0.4, 0.4)
+    E, mask, ninl, iters = ctx.essential_ransac(x1, x2)
+    oE, omask, oninl, oiters = orc.essential_ransac(p, x1, x2)
+    assert iters == oiters == 300 and ninl == oninl and (mask == omask).all()
+    assert _cmpE(E, oE) <= TOL
+
+
+def test_f2f_ransac(vislam, orc, ctx):
+    p = vislam.default_params()
+    ctx.set_params(p)
+    x1, x2, R, t = two_view(40, 21, 0.1, 0.2)
+    KP = vislam.KEYPOINT_DTYPE
+    a, b = np.zeros(40, KP), np.zeros(40, KP)
+    a["x"], a["y"], b["x"], b["y"] = x1[:, 0], x1[:, 1], x2[:, 0], x2[:, 1]
+    rng = np.random.default_rng(3)
+    idx = rng.integers(0, 39, (1000, 2)).astype(np.int32)       # rand() % (n-1), src/VISystem.cpp:712-713
+    got, cg = ctx.f2f_ransac(a, b, R.T.astype(np.float32), idx, 0.37)
+    ref, co = orc.f2f_ransac(p, a, b, R.T.astype(np.float32), idx, 0.37)
+    assert cg == co
+    assert np.abs(got - ref).max() <= 1e-6
+    z, c0 = ctx.f2f_ransac(a[:1], b[:1], np.eye(3, dtype=np.float32), idx[:0], 1.0)
+    assert (z == 0).all() and c0 == 0
+
+
+def test_batch_pipeline_pose(vislam, orc, canvas):
+    """end-to-end batched path: detect -> match -> pose vs the oracle's per-frame pipeline"""
+    import torch
+    p = vislam.default_params()
+    p.fy = p.fx
+    c = vislam.Context(0, p)
+    n = 6
+    frames = np.stack([vislam.synth_frame(canvas, t, 752, 480) for t in range(n)])
+    dev = torch.from_numpy(frames).cuda()
+    c.batch_plan(752, 480, 752, n)
+    c.batch_run(dev.data_ptr(), n)
+    c.batch_sync()
+    assert c.batch_status() == 0
+    prev = None
+    for t in range(n):
+        ok, od, r = orc.pipeline_frame(p, frames[t], prev)
+        prev = (ok, od)
+        g, nsym = c.batch_matches(t)
+        pose = c.batch_pose(t)
+        assert nsym == r.n_sym and len(g) == r.n_good
+        assert pose["n_inliers"] == r.n_inliers and pose["iters_run"] == r.iters_run, t
+        if r.n_inliers:
+            oE = np.array(r.E).reshape(3, 3)
+            assert _cmpE(pose["E"], oE) <= TOL
+            assert pose["n_pose_good"] == r.n_pose_good
+            assert np.abs(pose["R"] - np.array(r.R).reshape(3, 3)).max() <= 1e-7
+            assert np.abs(pose["t"] - np.array(r.t)).max() <= 1e-7
+    c.close()

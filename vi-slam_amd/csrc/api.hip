@@ -1,0 +1,716 @@
+// api.hip -- the C ABI of libvislam_hip.so (include/vislam_hip.h): context, plans, single-frame
+// entry points (one per OpenCV-CUDA call site of the reference) and the batched stream path.
+// Host code only; kernels live in detect.hip / match.hip / pose.hip.
+#include "vis_internal.h"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+static const char* VIS_VERSION_STR = "vislam_hip 0.1 (gfx950)";
+
+extern "C" const char* vis_version(void) { return VIS_VERSION_STR; }
+
+extern "C" const char* vis_strerror(int code) {
+    switch (code) {
+        case VIS_OK: return "ok";
+        case VIS_E_INVALID: return "invalid argument";
+        case VIS_E_NODEVICE: return "no HIP device";
+        case VIS_E_HIP: return "HIP runtime error";
+        case VIS_E_CAPACITY: return "capacity exceeded";
+        case VIS_E_STATE: return "invalid state / call order";
+        case VIS_E_NOMEM: return "out of memory";
+        default: return "unknown error";
+    }
+}
+
+extern "C" int vis_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" void vis_default_params(vis_params* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->nfeatures = 1000; p->nlevels = 8; p->scale_factor = 1.2f; p->edge_threshold = 31; p->patch_size = 31;
+    p->fast_threshold = 20; p->ratio = 0.8f; p->n_cells = 49; p->w_size = 752; p->h_size = 480;
+    p->sym_mode = VIS_SYM_REFERENCE_EFFECTIVE;
+    p->ransac_prob = 0.999; p->ransac_threshold = 1.0; p->ransac_max_iters = 1000; p->ransac_adaptive = 1;
+    p->ransac_seed = 0xFFFFFFFFFFFFFFFFULL;
+    p->fx = 458.654; p->fy = 457.296; p->cx = 367.215; p->cy = 248.375;     // calibrationEUROC.xml:20
+    p->f2f_iters = 1000; p->f2f_threshold = 370.0;
+}
+
+static int validate_params(const vis_params& p) {
+    if (p.nfeatures < 1 || p.nlevels < 1 || p.nlevels > VIS_MAX_LEVELS) return VIS_E_INVALID;
+    if (!(p.scale_factor > 1.0f)) return VIS_E_INVALID;
+    if (p.patch_size != 31) return VIS_E_INVALID;                 // the rBRIEF pattern is learned for 31x31
+    if (p.edge_threshold < 22 || p.edge_threshold > 255) return VIS_E_INVALID;   // 43x43 raw patch must stay inside
+    if (p.fast_threshold < 1 || p.fast_threshold > 254) return VIS_E_INVALID;
+    if (p.n_cells < 1 || p.w_size < 1 || p.h_size < 1) return VIS_E_INVALID;
+    if (p.ransac_max_iters < 1 || p.ransac_max_iters > 100000) return VIS_E_INVALID;
+    if (!(p.ransac_prob > 0 && p.ransac_prob < 1) || !(p.fx > 0) || !(p.fy > 0)) return VIS_E_INVALID;
+    if (p.f2f_iters < 0) return VIS_E_INVALID;
+    return VIS_OK;
+}
+
+extern "C" int vis_create(int device, vis_ctx** out) {
+    if (!out) return VIS_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return VIS_E_NODEVICE;
+    if (device < 0 || device >= n) return VIS_E_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return VIS_E_HIP;
+    vis_ctx* ctx = new (std::nothrow) vis_ctx();
+    if (!ctx) return VIS_E_NOMEM;
+    ctx->device = device;
+    vis_default_params(&ctx->p);
+    std::memset(&ctx->tm, 0, sizeof(ctx->tm));
+    for (int i = 0; i < VIS_NSLOTS; i++) ctx->slot_valid[i] = 0;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return VIS_E_HIP; }
+    ctx->stream = ctx->own_stream;
+    ctx->ev_ok = true;
+    for (int i = 0; i < 10; i++) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) ctx->ev_ok = false;
+    *out = ctx;
+    return VIS_OK;
+}
+
+extern "C" void vis_destroy(vis_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    plan_destroy(ctx->single); plan_destroy(ctx->batch);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    for (int i = 0; i < 10; i++) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" const char* vis_last_error(vis_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int vis_set_params(vis_ctx* ctx, const vis_params* p) {
+    if (!ctx || !p) return VIS_E_INVALID;
+    int rc = validate_params(*p);
+    if (rc) return rc;
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->p = *p;
+    // geometry depends on the params: drop plans (re-created lazily / by vis_batch_plan)
+    plan_destroy(ctx->single); ctx->single = nullptr;
+    plan_destroy(ctx->batch); ctx->batch = nullptr;
+    for (int i = 0; i < VIS_NSLOTS; i++) ctx->slot_valid[i] = 0;
+    return VIS_OK;
+}
+
+extern "C" int vis_get_params(vis_ctx* ctx, vis_params* p) {
+    if (!ctx || !p) return VIS_E_INVALID;
+    *p = ctx->p;
+    return VIS_OK;
+}
+
+extern "C" int vis_set_stream(vis_ctx* ctx, void* s) {
+    if (!ctx) return VIS_E_INVALID;
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    return VIS_OK;
+}
+
+extern "C" int vis_last_timings(vis_ctx* ctx, vis_timings* t) {
+    if (!ctx || !t) return VIS_E_INVALID;
+    *t = ctx->tm;
+    return VIS_OK;
+}
+
+extern "C" int vis_level_geometry(vis_ctx* ctx, int w, int h, int32_t* widths, int32_t* heights,
+                                  float* scales, int32_t* quotas) {
+    if (!ctx) return VIS_E_INVALID;
+    LevelInfo lv[VIS_MAX_LEVELS];
+    int rc = vis_compute_levels(ctx->p, w, h, w, lv);
+    if (rc) return rc;
+    for (int l = 0; l < ctx->p.nlevels; l++) {
+        if (widths) widths[l] = lv[l].w;
+        if (heights) heights[l] = lv[l].h;
+        if (scales) scales[l] = lv[l].scale;
+        if (quotas) quotas[l] = lv[l].quota;
+    }
+    return VIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ plans
+template <class T> static int dalloc(vis_ctx* ctx, T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    HIPCHK(ctx, hipMalloc((void**)p, count * sizeof(T)));
+    return VIS_OK;
+}
+#define DALLOC(ptr, count) do { int rc_ = dalloc(ctx, &(ptr), (count)); if (rc_) { plan_destroy(pl); return rc_; } } while (0)
+
+void plan_destroy(Plan* pl) {
+    if (!pl) return;
+    auto F = [](void* p) { if (p) (void)hipFree(p); };
+    F(pl->d_stage);
+    for (int l = 0; l < VIS_MAX_LEVELS; l++) {
+        F(pl->d_pyr[l]); F(pl->d_xofs[l]); F(pl->d_ialpha[l]); F(pl->d_yofs[l]); F(pl->d_ibeta[l]);
+        F(pl->d_cand[l]); F(pl->d_seg_kp[l]);
+    }
+    F(pl->d_cand_cnt); F(pl->d_hist); F(pl->d_seg_cnt); F(pl->d_flags);
+    F(pl->d_kps); F(pl->d_desc); F(pl->d_nkp);
+    F(pl->d_pair_q); F(pl->d_pair_t); F(pl->d_pair_q_noprev); F(pl->d_knn12); F(pl->d_knn21);
+    F(pl->d_sym); F(pl->d_nsym); F(pl->d_good); F(pl->d_ngood); F(pl->d_p1); F(pl->d_p2); F(pl->d_hf); F(pl->d_wf);
+    F(pl->d_n1); F(pl->d_n2); F(pl->d_mask); F(pl->d_samples); F(pl->d_models); F(pl->d_counts); F(pl->d_rstate); F(pl->d_pose);
+    delete pl;
+}
+
+int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npairs, Plan** out) {
+    *out = nullptr;
+    if (B < 1 || nrec < 1 || npairs < 1 || stride < w || (stride & 3)) return VIS_E_INVALID;
+    Plan* pl = new (std::nothrow) Plan();
+    if (!pl) return VIS_E_NOMEM;
+    pl->w = w; pl->h = h; pl->stride = stride; pl->B = B; pl->L = ctx->p.nlevels; pl->nrec = nrec; pl->npairs = npairs;
+    int rc = vis_compute_levels(ctx->p, w, h, stride, pl->lv);
+    if (rc) { delete pl; return rc; }
+    const int L = pl->L;
+    int kcap = 0; for (int l = 0; l < L; l++) kcap += pl->lv[l].keep_cap;
+    if (kcap > 65535) { delete pl; return VIS_E_INVALID; }       // packed 16-bit indices in the matcher
+    pl->kcap = kcap;
+    std::vector<float> hf, wf; vis_grid_limits(ctx->p, &pl->root, hf, wf);
+    const int ncell = pl->root * pl->root;
+    pl->max_iters = ctx->p.ransac_max_iters;
+    DALLOC(pl->d_stage, (size_t)stride * h);
+    for (int l = 1; l < L; l++) {
+        const LevelInfo& V = pl->lv[l]; const LevelInfo& U = pl->lv[l - 1];
+        DALLOC(pl->d_pyr[l], V.frame_bytes * B);
+        std::vector<int32_t> xofs, yofs; std::vector<int16_t> ia, ib;
+        vis_resize_tables(U.w, U.h, V.w, V.h, xofs, ia, yofs, ib);
+        DALLOC(pl->d_xofs[l], xofs.size()); DALLOC(pl->d_ialpha[l], ia.size());
+        DALLOC(pl->d_yofs[l], yofs.size()); DALLOC(pl->d_ibeta[l], ib.size());
+        HIPCHK(ctx, hipMemcpy(pl->d_xofs[l], xofs.data(), xofs.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(pl->d_ialpha[l], ia.data(), ia.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(pl->d_yofs[l], yofs.data(), yofs.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(pl->d_ibeta[l], ib.data(), ib.size() * 2, hipMemcpyHostToDevice));
+    }
+    for (int l = 0; l < L; l++) {
+        DALLOC(pl->d_cand[l], (size_t)pl->lv[l].cand_cap * B);
+        DALLOC(pl->d_seg_kp[l], (size_t)pl->lv[l].keep_cap * B);
+    }
+    DALLOC(pl->d_cand_cnt, (size_t)B * L); DALLOC(pl->d_hist, (size_t)B * L * 256); DALLOC(pl->d_seg_cnt, (size_t)B * L);
+    DALLOC(pl->d_flags, 4);
+    HIPCHK(ctx, hipMemset(pl->d_flags, 0, 16));
+    DALLOC(pl->d_kps, (size_t)nrec * kcap); DALLOC(pl->d_desc, (size_t)nrec * kcap * 32); DALLOC(pl->d_nkp, nrec);
+    HIPCHK(ctx, hipMemset(pl->d_nkp, 0, (size_t)nrec * 4));
+    HIPCHK(ctx, hipMemset(pl->d_desc, 0, (size_t)nrec * kcap * 32));
+    DALLOC(pl->d_pair_q, npairs); DALLOC(pl->d_pair_t, npairs); DALLOC(pl->d_pair_q_noprev, npairs);
+    {
+        std::vector<int32_t> q(npairs), t(npairs), qn(npairs);
+        for (int i = 0; i < npairs; i++) { q[i] = i; t[i] = i + 1; qn[i] = i == 0 ? -1 : i; }
+        HIPCHK(ctx, hipMemcpy(pl->d_pair_q, q.data(), (size_t)npairs * 4, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(pl->d_pair_t, t.data(), (size_t)npairs * 4, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(pl->d_pair_q_noprev, qn.data(), (size_t)npairs * 4, hipMemcpyHostToDevice));
+    }
+    DALLOC(pl->d_knn12, (size_t)npairs * kcap * 2); DALLOC(pl->d_knn21, (size_t)npairs * kcap * 2);
+    DALLOC(pl->d_sym, (size_t)npairs * kcap); DALLOC(pl->d_nsym, npairs);
+    DALLOC(pl->d_good, (size_t)npairs * ncell); DALLOC(pl->d_ngood, npairs);
+    DALLOC(pl->d_p1, (size_t)npairs * ncell * 2); DALLOC(pl->d_p2, (size_t)npairs * ncell * 2);
+    DALLOC(pl->d_hf, pl->root); DALLOC(pl->d_wf, pl->root);
+    HIPCHK(ctx, hipMemcpy(pl->d_hf, hf.data(), (size_t)pl->root * 4, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(pl->d_wf, wf.data(), (size_t)pl->root * 4, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemset(pl->d_nsym, 0, (size_t)npairs * 4));
+    HIPCHK(ctx, hipMemset(pl->d_ngood, 0, (size_t)npairs * 4));
+    DALLOC(pl->d_n1, (size_t)npairs * ncell * 2); DALLOC(pl->d_n2, (size_t)npairs * ncell * 2);
+    DALLOC(pl->d_mask, (size_t)npairs * ncell);
+    DALLOC(pl->d_samples, (size_t)npairs * pl->max_iters * 5);
+    DALLOC(pl->d_models, (size_t)npairs * pl->max_iters * 90);
+    DALLOC(pl->d_counts, (size_t)npairs * pl->max_iters * 10);
+    DALLOC(pl->d_rstate, (size_t)npairs * VIS_RSTATE_WORDS);
+    DALLOC(pl->d_pose, npairs);
+    HIPCHK(ctx, hipMemset(pl->d_pose, 0, (size_t)npairs * sizeof(PoseOut)));
+    *out = pl;
+    return VIS_OK;
+}
+
+int launch_pose(vis_ctx* ctx, Plan* pl, int npairs) {
+    if (npairs <= 0) return VIS_OK;
+    return pose_run(ctx, npairs, pl->root * pl->root, pl->max_iters, pl->d_p1, pl->d_p2, pl->d_ngood, pl->d_n1, pl->d_n2,
+                    pl->d_samples, pl->d_models, pl->d_counts, pl->d_rstate, nullptr, pl->d_mask, pl->d_pose, 1, 1);
+}
+
+static int ensure_scratch(vis_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->scratch_bytes) return VIS_OK;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    ctx->d_scratch = nullptr; ctx->scratch_bytes = 0;
+    HIPCHK(ctx, hipMalloc(&ctx->d_scratch, bytes));
+    ctx->scratch_bytes = bytes;
+    return VIS_OK;
+}
+struct Carver {
+    char* base; size_t off;
+    template <class T> T* take(size_t count) { off = (off + 255) & ~(size_t)255; T* p = (T*)(base + off); off += count * sizeof(T); return p; }
+};
+
+static int ensure_single(vis_ctx* ctx, int w, int h) {
+    (void)hipSetDevice(ctx->device);
+    if (ctx->single && ctx->single->w == w && ctx->single->h == h) return VIS_OK;
+    (void)hipStreamSynchronize(ctx->stream);
+    plan_destroy(ctx->single); ctx->single = nullptr;
+    for (int i = 0; i < VIS_NSLOTS; i++) ctx->slot_valid[i] = 0;
+    const int stride = ((w + 63) / 64) * 64;
+    return plan_create(ctx, w, h, stride, 1, VIS_NSLOTS, 1, &ctx->single);
+}
+
+static void key_to_dmatch(uint32_t key, int q, vis_dmatch* m) {
+    m->queryIdx = q;
+    if (key == 0xFFFFFFFFu) { m->trainIdx = -1; m->imgIdx = -1; m->distance = FLT_MAX; }
+    else { m->trainIdx = (int)(key & 0xFFFF); m->imgIdx = 0; m->distance = (float)(key >> 16); }
+}
+
+static int check_flags(vis_ctx* ctx, Plan* pl) {
+    int32_t fl = 0;
+    HIPCHK(ctx, hipMemcpy(&fl, pl->d_flags, 4, hipMemcpyDeviceToHost));
+    if (fl) { ctx->err = "device capacity flag set: " + std::to_string(fl); HIPCHK(ctx, hipMemset(pl->d_flags, 0, 4)); return VIS_E_CAPACITY; }
+    return VIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ single-frame API
+extern "C" int vis_camera_update(vis_ctx* ctx, const uint8_t* img, int w, int h, int stride, uint8_t* const out_levels[5]) {
+    if (!ctx || !img || !out_levels || w < 16 || h < 16 || stride < w) return VIS_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    size_t lvl_bytes[5]; size_t total = (size_t)w * h;
+    lvl_bytes[0] = (size_t)w * h;
+    for (int l = 1; l < 5; l++) { lvl_bytes[l] = (size_t)(w >> l) * (h >> l); total += lvl_bytes[l] + 256; }
+    int rc = ensure_scratch(ctx, total + 1024);
+    if (rc) return rc;
+    Carver cv{(char*)ctx->d_scratch, 0};
+    uint8_t* d[5];
+    for (int l = 0; l < 5; l++) d[l] = cv.take<uint8_t>(lvl_bytes[l]);
+    HIPCHK(ctx, hipMemcpy2DAsync(d[0], w, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_half_pyramid(ctx, d[0], w, h, w, d);
+    if (rc) return rc;
+    for (int l = 0; l < 5; l++)
+        if (out_levels[l]) HIPCHK(ctx, hipMemcpyAsync(out_levels[l], d[l], lvl_bytes[l], hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return VIS_OK;
+}
+
+static void collect_detect_timings(vis_ctx* ctx) {
+    if (!ctx->ev_ok) return;
+    float a = 0;
+    if (hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->tm.ms_pyramid = a;
+    if (hipEventElapsedTime(&a, ctx->ev[1], ctx->ev[2]) == hipSuccess) ctx->tm.ms_fast = a;
+    if (hipEventElapsedTime(&a, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->tm.ms_select = a;
+    if (hipEventElapsedTime(&a, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->tm.ms_describe = a;
+}
+
+extern "C" int vis_orb_detect_compute(vis_ctx* ctx, const uint8_t* img, int w, int h, int stride, int frame_slot,
+                                      vis_keypoint* kps_out, uint8_t* desc_out, int cap, int* n_out) {
+    if (!ctx || !img || !n_out || frame_slot < 0 || frame_slot >= VIS_NSLOTS || stride < w) return VIS_E_INVALID;
+    int rc = ensure_single(ctx, w, h);
+    if (rc) return rc;
+    Plan* pl = ctx->single;
+    std::memset(&ctx->tm, 0, sizeof(ctx->tm));
+    HIPCHK(ctx, hipMemcpy2DAsync(pl->d_stage, pl->stride, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[0], ctx->stream);
+    rc = launch_detect(ctx, pl, pl->d_stage, 1, frame_slot);
+    if (rc) return rc;
+    int32_t n = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&n, pl->d_nkp + frame_slot, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    collect_detect_timings(ctx);
+    { float a = 0; if (ctx->ev_ok && hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[4]) == hipSuccess) ctx->tm.ms_total = a; }
+    rc = check_flags(ctx, pl);
+    if (rc) return rc;
+    ctx->slot_valid[frame_slot] = 1;
+    *n_out = n;
+    if (n > cap && (kps_out || desc_out)) return VIS_E_CAPACITY;
+    if (kps_out && n) HIPCHK(ctx, hipMemcpy(kps_out, pl->d_kps + (size_t)frame_slot * pl->kcap, (size_t)n * sizeof(vis_keypoint), hipMemcpyDeviceToHost));
+    if (desc_out && n) HIPCHK(ctx, hipMemcpy(desc_out, pl->d_desc + (size_t)frame_slot * pl->kcap * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
+    return VIS_OK;
+}
+
+static int set_single_pair(vis_ctx* ctx, Plan* pl, int slot_q, int slot_t) {
+    if (!pl) return VIS_E_STATE;
+    if (slot_q < 0 || slot_q >= VIS_NSLOTS || slot_t < 0 || slot_t >= VIS_NSLOTS) return VIS_E_INVALID;
+    if (!ctx->slot_valid[slot_q] || !ctx->slot_valid[slot_t]) return VIS_E_STATE;
+    int32_t q = slot_q, t = slot_t;
+    HIPCHK(ctx, hipMemcpy(pl->d_pair_q, &q, 4, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(pl->d_pair_t, &t, 4, hipMemcpyHostToDevice));
+    return VIS_OK;
+}
+
+static int download_knn(vis_ctx* ctx, const uint32_t* d_keys, int n, vis_dmatch* out) {
+    if (!out || n <= 0) return VIS_OK;
+    std::vector<uint32_t> k(2 * (size_t)n);
+    HIPCHK(ctx, hipMemcpy(k.data(), d_keys, k.size() * 4, hipMemcpyDeviceToHost));
+    for (int q = 0; q < n; q++) { key_to_dmatch(k[2 * q], q, out + 2 * q); key_to_dmatch(k[2 * q + 1], q, out + 2 * q + 1); }
+    return VIS_OK;
+}
+
+extern "C" int vis_bf_knn2_hamming(vis_ctx* ctx, int slot_q, int slot_t, vis_dmatch* out12, vis_dmatch* out21) {
+    if (!ctx) return VIS_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    Plan* pl = ctx->single;
+    int rc = set_single_pair(ctx, pl, slot_q, slot_t);
+    if (rc) return rc;
+    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[4], ctx->stream);
+    rc = launch_match(ctx, pl, 1);
+    if (rc) return rc;
+    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[5], ctx->stream);
+    int32_t nq = 0, nt = 0;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    { float a = 0; if (ctx->ev_ok && hipEventElapsedTime(&a, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->tm.ms_knn = a; }
+    HIPCHK(ctx, hipMemcpy(&nq, pl->d_nkp + slot_q, 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(&nt, pl->d_nkp + slot_t, 4, hipMemcpyDeviceToHost));
+    rc = download_knn(ctx, pl->d_knn12, nq, out12);
+    if (rc) return rc;
+    return download_knn(ctx, pl->d_knn21, nt, out21);
+}
+
+extern "C" int vis_bf_knn2_hamming_host(vis_ctx* ctx, const uint8_t* desc_q, int n_q, const uint8_t* desc_t, int n_t,
+                                        vis_dmatch* out12, vis_dmatch* out21) {
+    if (!ctx || n_q < 0 || n_t < 0 || (n_q && !desc_q) || (n_t && !desc_t)) return VIS_E_INVALID;
+    if (n_q > 65535 || n_t > 65535) return VIS_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    const int kcap = std::max(std::max(n_q, n_t), 1);
+    int rc = ensure_scratch(ctx, (size_t)kcap * 32 * 2 + (size_t)kcap * 8 * 2 + 4096);
+    if (rc) return rc;
+    Carver cv{(char*)ctx->d_scratch, 0};
+    Plan tp;
+    tp.kcap = kcap;
+    tp.d_desc = cv.take<uint8_t>((size_t)kcap * 64);
+    tp.d_nkp = cv.take<int32_t>(2); tp.d_pair_q = cv.take<int32_t>(1); tp.d_pair_t = cv.take<int32_t>(1);
+    tp.d_knn12 = cv.take<uint32_t>((size_t)kcap * 2); tp.d_knn21 = cv.take<uint32_t>((size_t)kcap * 2);
+    const int32_t nk[2] = {n_q, n_t}, zero = 0, one = 1;
+    if (n_q) HIPCHK(ctx, hipMemcpy(tp.d_desc, desc_q, (size_t)n_q * 32, hipMemcpyHostToDevice));
+    if (n_t) HIPCHK(ctx, hipMemcpy(tp.d_desc + (size_t)kcap * 32, desc_t, (size_t)n_t * 32, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(tp.d_nkp, nk, 8, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(tp.d_pair_q, &zero, 4, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(tp.d_pair_t, &one, 4, hipMemcpyHostToDevice));
+    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[4], ctx->stream);
+    rc = launch_match(ctx, &tp, 1);
+    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[5], ctx->stream);
+    if (rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    { float a = 0; if (ctx->ev_ok && hipEventElapsedTime(&a, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->tm.ms_knn = a; }
+    rc = download_knn(ctx, tp.d_knn12, n_q, out12);
+    if (rc) return rc;
+    rc = download_knn(ctx, tp.d_knn21, n_t, out21);
+    tp = Plan();       // scratch-owned pointers: nothing to free
+    return rc;
+}
+
+static int download_matches(vis_ctx* ctx, Plan* pl, int pair, vis_dmatch* good, int cap, int* n_good,
+                            vis_dmatch* sym_out, int sym_cap, int* n_sym) {
+    int32_t ng = 0, ns = 0;
+    HIPCHK(ctx, hipMemcpy(&ng, pl->d_ngood + pair, 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(&ns, pl->d_nsym + pair, 4, hipMemcpyDeviceToHost));
+    if (n_good) *n_good = ng;
+    if (n_sym) *n_sym = ns;
+    if (good) {
+        if (ng > cap) return VIS_E_CAPACITY;
+        if (ng) HIPCHK(ctx, hipMemcpy(good, pl->d_good + (size_t)pair * pl->root * pl->root, (size_t)ng * sizeof(vis_dmatch), hipMemcpyDeviceToHost));
+    }
+    if (sym_out) {
+        if (ns > sym_cap) return VIS_E_CAPACITY;
+        if (ns) HIPCHK(ctx, hipMemcpy(sym_out, pl->d_sym + (size_t)pair * pl->kcap, (size_t)ns * sizeof(vis_dmatch), hipMemcpyDeviceToHost));
+    }
+    return VIS_OK;
+}
+
+extern "C" int vis_good_matches(vis_ctx* ctx, int slot_prev, int slot_cur, vis_dmatch* good, int cap, int* n_good,
+                                vis_dmatch* sym_out, int sym_cap, int* n_sym) {
+    if (!ctx) return VIS_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    Plan* pl = ctx->single;
+    int rc = set_single_pair(ctx, pl, slot_prev, slot_cur);
+    if (rc) return rc;
+    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[4], ctx->stream);
+    rc = launch_match(ctx, pl, 1);
+    if (rc) return rc;
+    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[5], ctx->stream);
+    rc = launch_filter(ctx, pl, 1);
+    if (rc) return rc;
+    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[6], ctx->stream);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    { float a = 0;
+      if (ctx->ev_ok && hipEventElapsedTime(&a, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->tm.ms_knn = a;
+      if (ctx->ev_ok && hipEventElapsedTime(&a, ctx->ev[5], ctx->ev[6]) == hipSuccess) ctx->tm.ms_filter = a; }
+    return download_matches(ctx, pl, 0, good, cap, n_good, sym_out, sym_cap, n_sym);
+}
+
+static uint32_t dmatch_to_key(const vis_dmatch& m) {
+    if (m.trainIdx < 0) return 0xFFFFFFFFu;
+    return ((uint32_t)m.distance << 16) | (uint32_t)(m.trainIdx & 0xFFFF);
+}
+
+extern "C" int vis_good_matches_host(vis_ctx* ctx, const vis_keypoint* kps1, int n1, const vis_keypoint* kps2, int n2,
+                                     const vis_dmatch* knn12, const vis_dmatch* knn21,
+                                     vis_dmatch* good, int cap, int* n_good,
+                                     vis_dmatch* sym_out, int sym_cap, int* n_sym) {
+    if (!ctx || n1 < 0 || n2 < 0 || n1 > 65535 || n2 > 65535) return VIS_E_INVALID;
+    if ((n1 && (!kps1 || !knn12)) || (n2 && (!kps2 || !knn21))) return VIS_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    const int kcap = std::max(std::max(n1, n2), 1);
+    int root; std::vector<float> hf, wf; vis_grid_limits(ctx->p, &root, hf, wf);
+    const int ncell = root * root;
+    size_t need = (size_t)kcap * (2 * sizeof(vis_keypoint) + 16 + sizeof(vis_dmatch)) + (size_t)ncell * (sizeof(vis_dmatch) + 16) + 16384;
+    int rc = ensure_scratch(ctx, need);
+    if (rc) return rc;
+    Carver cv{(char*)ctx->d_scratch, 0};
+    Plan tp; tp.kcap = kcap; tp.root = root;
+    tp.d_kps = cv.take<vis_keypoint>((size_t)kcap * 2);
+    tp.d_nkp = cv.take<int32_t>(2); tp.d_pair_q = cv.take<int32_t>(1); tp.d_pair_t = cv.take<int32_t>(1);
+    tp.d_knn12 = cv.take<uint32_t>((size_t)kcap * 2); tp.d_knn21 = cv.take<uint32_t>((size_t)kcap * 2);
+    tp.d_sym = cv.take<vis_dmatch>(kcap); tp.d_nsym = cv.take<int32_t>(1);
+    tp.d_good = cv.take<vis_dmatch>(ncell); tp.d_ngood = cv.take<int32_t>(1);
+    tp.d_p1 = cv.take<float>((size_t)ncell * 2); tp.d_p2 = cv.take<float>((size_t)ncell * 2);
+    tp.d_hf = cv.take<float>(root); tp.d_wf = cv.take<float>(root);
+    std::vector<uint32_t> k12(2 * (size_t)kcap, 0xFFFFFFFFu), k21(2 * (size_t)kcap, 0xFFFFFFFFu);
+    for (int i = 0; i < 2 * n1; i++) k12[i] = dmatch_to_key(knn12[i]);
+    for (int i = 0; i < 2 * n2; i++) k21[i] = dmatch_to_key(knn21[i]);
+    const int32_t nk[2] = {n1, n2}, zero = 0, one = 1;
+    if (n1) HIPCHK(ctx, hipMemcpy(tp.d_kps, kps1, (size_t)n1 * sizeof(vis_keypoint), hipMemcpyHostToDevice));
+    if (n2) HIPCHK(ctx, hipMemcpy(tp.d_kps + kcap, kps2, (size_t)n2 * sizeof(vis_keypoint), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(tp.d_nkp, nk, 8, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(tp.d_pair_q, &zero, 4, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(tp.d_pair_t, &one, 4, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(tp.d_knn12, k12.data(), k12.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(tp.d_knn21, k21.data(), k21.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(tp.d_hf, hf.data(), (size_t)root * 4, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(tp.d_wf, wf.data(), (size_t)root * 4, hipMemcpyHostToDevice));
+    rc = launch_filter(ctx, &tp, 1);
+    if (rc) { tp = Plan(); return rc; }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    rc = download_matches(ctx, &tp, 0, good, cap, n_good, sym_out, sym_cap, n_sym);
+    tp = Plan();
+    return rc;
+}
+
+// shared by vis_essential_ransac / vis_recover_pose
+static int pose_host(vis_ctx* ctx, const float* p1xy, const float* p2xy, int m, const double* E_in,
+                     int do_ransac, int do_pose, uint8_t* mask, PoseOut* out) {
+    (void)hipSetDevice(ctx->device);
+    if (m > VIS_RANSAC_MAX_M) return VIS_E_CAPACITY;
+    const int mcap = std::max(m, 1);
+    const int iters = ctx->p.ransac_max_iters;
+    size_t need = (size_t)mcap * (16 + 32 + 1) + (size_t)iters * (20 + 720 + 40) + 65536;
+    int rc = ensure_scratch(ctx, need);
+    if (rc) return rc;
+    Carver cv{(char*)ctx->d_scratch, 0};
+    float* d_p1 = cv.take<float>((size_t)mcap * 2); float* d_p2 = cv.take<float>((size_t)mcap * 2);
+    int32_t* d_npts = cv.take<int32_t>(1);
+    double* d_n1 = cv.take<double>((size_t)mcap * 2); double* d_n2 = cv.take<double>((size_t)mcap * 2);
+    int32_t* d_samples = cv.take<int32_t>((size_t)iters * 5);
+    double* d_models = cv.take<double>((size_t)iters * 90);
+    int32_t* d_counts = cv.take<int32_t>((size_t)iters * 10);
+    int32_t* d_rstate = cv.take<int32_t>(VIS_RSTATE_WORDS);
+    double* d_E = cv.take<double>(9);
+    uint8_t* d_mask = cv.take<uint8_t>(mcap);
+    PoseOut* d_pose = cv.take<PoseOut>(1);
+    if (m) {
+        HIPCHK(ctx, hipMemcpy(d_p1, p1xy, (size_t)m * 8, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(d_p2, p2xy, (size_t)m * 8, hipMemcpyHostToDevice));
+    }
+    const int32_t mm = m;
+    HIPCHK(ctx, hipMemcpy(d_npts, &mm, 4, hipMemcpyHostToDevice));
+    if (E_in) HIPCHK(ctx, hipMemcpy(d_E, E_in, 72, hipMemcpyHostToDevice));
+    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[6], ctx->stream);
+    rc = pose_run(ctx, 1, mcap, iters, d_p1, d_p2, d_npts, d_n1, d_n2, d_samples, d_models, d_counts, d_rstate,
+                  E_in ? d_E : nullptr, d_mask, d_pose, do_ransac, do_pose);
+    if (rc) return rc;
+    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[7], ctx->stream);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    { float a = 0; if (ctx->ev_ok && hipEventElapsedTime(&a, ctx->ev[6], ctx->ev[7]) == hipSuccess) ctx->tm.ms_pose = a; }
+    HIPCHK(ctx, hipMemcpy(out, d_pose, sizeof(PoseOut), hipMemcpyDeviceToHost));
+    if (mask && m) HIPCHK(ctx, hipMemcpy(mask, d_mask, (size_t)m, hipMemcpyDeviceToHost));
+    return VIS_OK;
+}
+
+extern "C" int vis_essential_ransac(vis_ctx* ctx, const float* p1xy, const float* p2xy, int m,
+                                    double E[9], uint8_t* mask, int* n_inliers, int* iters_run) {
+    if (!ctx || m < 0 || (m && (!p1xy || !p2xy)) || !E) return VIS_E_INVALID;
+    PoseOut o;
+    int rc = pose_host(ctx, p1xy, p2xy, m, nullptr, 1, 0, mask, &o);
+    if (rc) return rc;
+    std::memcpy(E, o.E, 72);
+    if (n_inliers) *n_inliers = o.n_inliers;
+    if (iters_run) *iters_run = o.iters_run;
+    return VIS_OK;
+}
+
+extern "C" int vis_recover_pose(vis_ctx* ctx, const double E[9], const float* p1xy, const float* p2xy, int m,
+                                double R[9], double t[3], int* n_good) {
+    if (!ctx || !E || m < 0 || (m && (!p1xy || !p2xy)) || !R || !t) return VIS_E_INVALID;
+    PoseOut o;
+    int rc = pose_host(ctx, p1xy, p2xy, m, E, 0, 1, nullptr, &o);
+    if (rc) return rc;
+    std::memcpy(R, o.R, 72); std::memcpy(t, o.t, 24);
+    if (n_good) *n_good = o.n_pose_good;
+    return VIS_OK;
+}
+
+extern "C" int vis_f2f_ransac(vis_ctx* ctx, const vis_keypoint* pts1, const vis_keypoint* pts2, int m, const float rot[9],
+                              const int32_t* sample_idx, int iters, float scale, float out_t[3], int* count_max) {
+    if (!ctx || !out_t || m < 0 || iters < 0 || !rot || (iters && !sample_idx) || (m && (!pts1 || !pts2))) return VIS_E_INVALID;
+    out_t[0] = out_t[1] = out_t[2] = 0.f;
+    if (count_max) *count_max = 0;
+    if (m < 2 || iters == 0) return VIS_OK;                       // SPEC: M < 2 -> zero vector
+    for (int i = 0; i < 2 * iters; i++) if (sample_idx[i] < 0 || sample_idx[i] >= m) return VIS_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    int rc = ensure_scratch(ctx, (size_t)m * (2 * sizeof(vis_keypoint) + 24) + (size_t)iters * 24 + 8192);
+    if (rc) return rc;
+    Carver cv{(char*)ctx->d_scratch, 0};
+    vis_keypoint* d1 = cv.take<vis_keypoint>(m); vis_keypoint* d2 = cv.take<vis_keypoint>(m);
+    float* d_rot = cv.take<float>(9); int32_t* d_idx = cv.take<int32_t>((size_t)iters * 2);
+    double* d_nv = cv.take<double>((size_t)m * 3); float* d_cnt = cv.take<float>((size_t)iters * 4);
+    HIPCHK(ctx, hipMemcpy(d1, pts1, (size_t)m * sizeof(vis_keypoint), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(d2, pts2, (size_t)m * sizeof(vis_keypoint), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(d_rot, rot, 36, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(d_idx, sample_idx, (size_t)iters * 8, hipMemcpyHostToDevice));
+    rc = f2f_run(ctx, d1, d2, m, d_rot, d_idx, iters, d_nv, d_cnt);
+    if (rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<float> c((size_t)iters * 4);
+    HIPCHK(ctx, hipMemcpy(c.data(), d_cnt, c.size() * 4, hipMemcpyDeviceToHost));
+    // `if (count > countMax)`: first strictly larger count wins, iterations in order (src/VISystem.cpp:737-741)
+    float countMax = 0; float best[3] = {0, 0, 0};
+    for (int i = 0; i < iters; i++)
+        if (c[4 * (size_t)i] > countMax) { countMax = c[4 * (size_t)i]; best[0] = c[4 * (size_t)i + 1]; best[1] = c[4 * (size_t)i + 2]; best[2] = c[4 * (size_t)i + 3]; }
+    for (int k = 0; k < 3; k++) out_t[k] = scale * best[k];
+    if (count_max) *count_max = (int)countMax;
+    return VIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ batch API
+extern "C" int vis_batch_plan(vis_ctx* ctx, int w, int h, int stride, int max_frames) {
+    if (!ctx || max_frames < 1 || max_frames > 4096) return VIS_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    plan_destroy(ctx->batch); ctx->batch = nullptr;
+    return plan_create(ctx, w, h, stride, max_frames, max_frames + 1, max_frames, &ctx->batch);
+}
+
+extern "C" int vis_batch_reset(vis_ctx* ctx) {
+    if (!ctx || !ctx->batch) return VIS_E_STATE;
+    ctx->batch->have_prev = false; ctx->batch->last_n = 0; ctx->batch->carry_from = 0; ctx->batch->pair0_valid = false;
+    return VIS_OK;
+}
+
+extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int stages) {
+    if (!ctx || !d_frames) return VIS_E_INVALID;
+    Plan* pl = ctx->batch;
+    if (!pl) return VIS_E_STATE;
+    if (n < 1 || n > pl->B || ((uintptr_t)d_frames & 3)) return VIS_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    ctx->tm.launches_total = 0;
+    // carry the previous batch's last frame (record last_n) into record 0 before it is overwritten
+    if ((stages & VIS_STAGE_DETECT) && pl->carry_from > 0) {
+        const int c = pl->carry_from;
+        HIPCHK(ctx, hipMemcpyAsync(pl->d_kps, pl->d_kps + (size_t)c * pl->kcap, (size_t)pl->kcap * sizeof(vis_keypoint), hipMemcpyDeviceToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(pl->d_desc, pl->d_desc + (size_t)c * pl->kcap * 32, (size_t)pl->kcap * 32, hipMemcpyDeviceToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(pl->d_nkp, pl->d_nkp + c, 4, hipMemcpyDeviceToDevice, st));
+        pl->have_prev = true; pl->carry_from = 0;
+    }
+    pl->pair0_valid = pl->have_prev;
+    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[0], st);
+    int rc;
+    if (stages & VIS_STAGE_DETECT) { rc = launch_detect(ctx, pl, d_frames, n, 1); if (rc) return rc; }
+    else if (ctx->ev_ok) for (int i = 1; i <= 4; i++) (void)hipEventRecord(ctx->ev[i], st);
+    // pair i: query = record i (frame i-1, or the carried frame for i = 0), train = record i+1 (frame i)
+    int32_t* saved_q = pl->d_pair_q;
+    if (!pl->have_prev) pl->d_pair_q = pl->d_pair_q_noprev;
+    rc = VIS_OK;
+    if (stages & VIS_STAGE_MATCH) {
+        rc = launch_match(ctx, pl, n);
+        if (!rc) { if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[5], st); rc = launch_filter(ctx, pl, n); }
+        if (!rc && ctx->ev_ok) (void)hipEventRecord(ctx->ev[6], st);
+    } else if (ctx->ev_ok) { (void)hipEventRecord(ctx->ev[5], st); (void)hipEventRecord(ctx->ev[6], st); }
+    if (!rc && (stages & VIS_STAGE_POSE)) rc = launch_pose(ctx, pl, n);
+    pl->d_pair_q = saved_q;
+    if (rc) return rc;
+    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[7], st);
+    if (stages & VIS_STAGE_DETECT) pl->carry_from = n;
+    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[8], st);
+    pl->last_n = n;
+    return VIS_OK;
+}
+
+extern "C" int vis_batch_sync(vis_ctx* ctx) {
+    if (!ctx) return VIS_E_INVALID;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->ev_ok) {
+        collect_detect_timings(ctx);
+        float a = 0;
+        if (hipEventElapsedTime(&a, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->tm.ms_knn = a;
+        if (hipEventElapsedTime(&a, ctx->ev[5], ctx->ev[6]) == hipSuccess) ctx->tm.ms_filter = a;
+        if (hipEventElapsedTime(&a, ctx->ev[6], ctx->ev[7]) == hipSuccess) ctx->tm.ms_pose = a;
+        if (hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[8]) == hipSuccess) ctx->tm.ms_total = a;
+    }
+    return VIS_OK;
+}
+
+extern "C" int vis_batch_status(vis_ctx* ctx, int* flags) {
+    if (!ctx || !ctx->batch || !flags) return VIS_E_STATE;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    int32_t fl = 0;
+    HIPCHK(ctx, hipMemcpy(&fl, ctx->batch->d_flags, 4, hipMemcpyDeviceToHost));
+    *flags = fl;
+    return VIS_OK;
+}
+
+extern "C" int vis_batch_get_keypoints(vis_ctx* ctx, int frame, vis_keypoint* kps, uint8_t* desc, int cap, int* n_out) {
+    if (!ctx || !ctx->batch) return VIS_E_STATE;
+    Plan* pl = ctx->batch;
+    if (frame < 0 || frame >= pl->last_n) return VIS_E_INVALID;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    int32_t n = 0;
+    HIPCHK(ctx, hipMemcpy(&n, pl->d_nkp + frame + 1, 4, hipMemcpyDeviceToHost));
+    if (n_out) *n_out = n;
+    if ((kps || desc) && n > cap) return VIS_E_CAPACITY;
+    if (kps && n) HIPCHK(ctx, hipMemcpy(kps, pl->d_kps + (size_t)(frame + 1) * pl->kcap, (size_t)n * sizeof(vis_keypoint), hipMemcpyDeviceToHost));
+    if (desc && n) HIPCHK(ctx, hipMemcpy(desc, pl->d_desc + (size_t)(frame + 1) * pl->kcap * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
+    return VIS_OK;
+}
+
+extern "C" int vis_batch_get_knn(vis_ctx* ctx, int frame, vis_dmatch* out12, int cap12, int* n12,
+                                 vis_dmatch* out21, int cap21, int* n21) {
+    if (!ctx || !ctx->batch) return VIS_E_STATE;
+    Plan* pl = ctx->batch;
+    if (frame < 0 || frame >= pl->last_n) return VIS_E_INVALID;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    int32_t nq = 0, nt = 0;
+    HIPCHK(ctx, hipMemcpy(&nq, pl->d_nkp + frame, 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(&nt, pl->d_nkp + frame + 1, 4, hipMemcpyDeviceToHost));
+    if (frame == 0 && !pl->pair0_valid) { nq = 0; nt = 0; }      // first frame of a stream has no pair
+    if (n12) *n12 = nq;
+    if (n21) *n21 = nt;
+    if (out12) { if (2 * nq > cap12) return VIS_E_CAPACITY; int rc = download_knn(ctx, pl->d_knn12 + (size_t)frame * pl->kcap * 2, nq, out12); if (rc) return rc; }
+    if (out21) { if (2 * nt > cap21) return VIS_E_CAPACITY; int rc = download_knn(ctx, pl->d_knn21 + (size_t)frame * pl->kcap * 2, nt, out21); if (rc) return rc; }
+    return VIS_OK;
+}
+
+extern "C" int vis_batch_get_matches(vis_ctx* ctx, int frame, vis_dmatch* good, int cap, int* n_good, int* n_sym) {
+    if (!ctx || !ctx->batch) return VIS_E_STATE;
+    Plan* pl = ctx->batch;
+    if (frame < 0 || frame >= pl->last_n) return VIS_E_INVALID;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return download_matches(ctx, pl, frame, good, cap, n_good, nullptr, 0, n_sym);
+}
+
+extern "C" int vis_batch_get_pose(vis_ctx* ctx, int frame, double E[9], double R[9], double t[3],
+                                  int* n_inliers, int* n_pose_good, int* iters_run) {
+    if (!ctx || !ctx->batch) return VIS_E_STATE;
+    Plan* pl = ctx->batch;
+    if (frame < 0 || frame >= pl->last_n) return VIS_E_INVALID;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    PoseOut o;
+    HIPCHK(ctx, hipMemcpy(&o, pl->d_pose + frame, sizeof(PoseOut), hipMemcpyDeviceToHost));
+    if (E) std::memcpy(E, o.E, 72);
+    if (R) std::memcpy(R, o.R, 72);
+    if (t) std::memcpy(t, o.t, 24);
+    if (n_inliers) *n_inliers = o.n_inliers;
+    if (n_pose_good) *n_pose_good = o.n_pose_good;
+    if (iters_run) *iters_run = o.iters_run;
+    return VIS_OK;
+}

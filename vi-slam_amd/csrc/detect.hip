@@ -1,0 +1,545 @@
+// detect.hip -- ORB detect + describe on gfx950 (MI355X), batched over frames.
+//
+// Replaces the OpenCV-CUDA call site  cuda::ORB::create(1000)->detectAndCompute(frameGPU, ...)
+// (/root/reference/src/CameraGPU.cpp:99-103) and its CPU twin cv::ORB::detectAndCompute
+// (/root/reference/src/Camera.cpp:87); results are bit-identical to the CPU path restated in
+// oracle/orb.cpp (tests/test_detect_gpu.py).
+//
+// Kernel chain per batch of B frames (all on one stream, no host sync):
+//   k_resize   (per level l>=1)  cv::resize INTER_LINEAR 8-bit fixed point, level l-1 -> l
+//   k_fast     (per level)       FAST-9/16 score into an LDS tile + 3x3 NMS + border cull;
+//                                packed candidates + per-(frame,level) score histogram
+//   k_select   (1 launch)        block per (frame,level): histogram cut = retainBest(2*quota)
+//                                on the FAST score, Harris on survivors, LDS bitonic sort by
+//                                (response desc, y, x) = canonical order, retainBest(quota)
+//   k_describe (1 launch)        wave per keypoint: 43x43 raw patch -> LDS, IC angle, 7-tap
+//                                fixed-point blur evaluated only where rBRIEF samples, 256
+//                                tests packed with wave ballots
+// HBM traffic model: every pyramid pixel is read once by k_fast and once as the
+// next level's resize source; candidates/keypoints are O(N) and tiny.
+#include "vis_internal.h"
+#include <cfloat>
+#include <cmath>
+
+// ------------------------------------------------------------------------------------------------
+// k_resize: one thread = 4 horizontally adjacent destination pixels (one 32-bit store).
+__global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, int sw, int sstride, size_t sframe,
+                                                uint8_t* __restrict__ dst, int dw, int dh, int dstride, size_t dframe,
+                                                const int32_t* __restrict__ xofs, const int16_t* __restrict__ ialpha,
+                                                const int32_t* __restrict__ yofs, const int16_t* __restrict__ ibeta) {
+    const int dx4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int dy = blockIdx.y * 4 + threadIdx.y;
+    const int f = blockIdx.z;
+    if (dx4 >= dw || dy >= dh) return;
+    const uint8_t* S0 = src + (size_t)f * sframe + (size_t)yofs[2 * dy] * sstride;
+    const uint8_t* S1 = src + (size_t)f * sframe + (size_t)yofs[2 * dy + 1] * sstride;
+    const int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int dx = dx4 + k;
+        if (dx < dw) {
+            const int sx = xofs[dx];
+            const int sx1 = min(sx + 1, sw - 1);
+            const int a0 = ialpha[2 * dx], a1 = ialpha[2 * dx + 1];
+            const int r0 = S0[sx] * a0 + S0[sx1] * a1;
+            const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+            const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            out |= (uint32_t)(v & 255) << (8 * k);
+        }
+    }
+    *reinterpret_cast<uint32_t*>(dst + (size_t)f * dframe + (size_t)dy * dstride + dx4) = out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_fast
+#define FT_W 64
+#define FT_H 32
+#define PX_W (FT_W + 8)      // 72 bytes per LDS pixel row (3 ring + 1 NMS halo each side)
+#define PX_H (FT_H + 8)
+#define SC_W (FT_W + 2)
+#define SC_H (FT_H + 2)
+#define SC_S 68              // LDS score row stride
+
+__device__ __forceinline__ int fast_score16(const uint8_t* c, int t) {
+    const int S = PX_W;
+    const int v = c[0];
+    int d[16];
+    d[0] = v - c[3 * S];       d[1] = v - c[3 * S + 1];   d[2] = v - c[2 * S + 2];   d[3] = v - c[S + 3];
+    d[4] = v - c[3];           d[5] = v - c[-S + 3];      d[6] = v - c[-2 * S + 2];  d[7] = v - c[-3 * S + 1];
+    d[8] = v - c[-3 * S];      d[9] = v - c[-3 * S - 1];  d[10] = v - c[-2 * S - 2]; d[11] = v - c[-S - 3];
+    d[12] = v - c[-3];         d[13] = v - c[S - 3];      d[14] = v - c[2 * S - 2];  d[15] = v - c[3 * S - 1];
+    // necessary condition for a 9-arc: every opposite pair has a member in the arc
+    int mn = 255, mx = -255;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        mn = min(mn, max(d[k], d[k + 8]));
+        mx = max(mx, min(d[k], d[k + 8]));
+    }
+    if (mn <= t && mx >= -t) return 0;
+    // A = max over the 16 arcs of min(d), Bv = max over arcs of min(-d) = -(min over arcs of max(d))
+    int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
+    int A = -255, Bm = 255;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
+        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
+        A = max(A, lo9);
+        Bm = min(Bm, hi9);
+    }
+    const int s = max(A, -Bm) - 1;      // cornerScore<16>: largest threshold that still passes
+    return s >= t ? s : 0;
+}
+
+__global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ img, int w, int h, int stride, size_t frame_bytes,
+                                              int threshold, int edge, uint32_t* __restrict__ cand, int cand_cap,
+                                              int32_t* __restrict__ cand_cnt, int32_t* __restrict__ hist, int level, int L) {
+    __shared__ __attribute__((aligned(16))) uint32_t px[PX_H * PX_W / 4];
+    __shared__ uint8_t sc[SC_H * SC_S];
+    __shared__ uint32_t lhist[256];
+    __shared__ uint32_t lcand[FT_W * FT_H / 4];
+    __shared__ int lcount, gbase;
+    const int tid = threadIdx.x;
+    const int ox = blockIdx.x * FT_W, oy = blockIdx.y * FT_H, f = blockIdx.z;
+    // tiles that cannot emit (entirely inside the culled border) do nothing
+    if (ox + FT_W <= edge || ox >= w - edge || oy + FT_H <= edge || oy >= h - edge) return;
+    const uint8_t* base = img + (size_t)f * frame_bytes;
+    lhist[tid] = 0;
+    if (tid == 0) lcount = 0;
+    for (int wv = tid; wv < PX_H * (PX_W / 4); wv += 256) {
+        const int r = wv / (PX_W / 4), cw = wv % (PX_W / 4);
+        const int gx = ox - 4 + cw * 4, gy = oy - 4 + r;
+        uint32_t v = 0;
+        if (gy >= 0 && gy < h && gx >= 0 && gx + 3 < stride)
+            v = *reinterpret_cast<const uint32_t*>(base + (size_t)gy * stride + gx);
+        px[wv] = v;
+    }
+    __syncthreads();
+    const uint8_t* pxb = reinterpret_cast<const uint8_t*>(px);
+    // real scores are needed one pixel beyond the emit region (NMS neighbours), nowhere else
+    const int lox = max(3, edge - 1), hix = min(w - 3, w - edge + 1);
+    const int loy = max(3, edge - 1), hiy = min(h - 3, h - edge + 1);
+    for (int i = tid; i < SC_H * SC_W; i += 256) {
+        const int sy = i / SC_W, sx = i % SC_W;
+        const int gx = ox - 1 + sx, gy = oy - 1 + sy;
+        int s = 0;
+        if (gx >= lox && gx < hix && gy >= loy && gy < hiy) s = fast_score16(pxb + (sy + 3) * PX_W + (sx + 3), threshold);
+        sc[sy * SC_S + sx] = (uint8_t)s;
+    }
+    __syncthreads();
+    for (int i = tid; i < FT_W * FT_H; i += 256) {
+        const int ty = i / FT_W, tx = i % FT_W;
+        const int gx = ox + tx, gy = oy + ty;
+        const uint8_t* p = sc + (ty + 1) * SC_S + (tx + 1);
+        const int s = p[0];
+        if (s && gx >= edge && gx < w - edge && gy >= edge && gy < h - edge &&
+            s > p[-1] && s > p[1] && s > p[-SC_S - 1] && s > p[-SC_S] && s > p[-SC_S + 1] &&
+            s > p[SC_S - 1] && s > p[SC_S] && s > p[SC_S + 1]) {
+            const int slot = atomicAdd(&lcount, 1);
+            lcand[slot] = ((uint32_t)s << 24) | ((uint32_t)gy << 12) | (uint32_t)gx;
+            atomicAdd(&lhist[s], 1u);
+        }
+    }
+    __syncthreads();
+    const int n = lcount;
+    if (n == 0) return;
+    const int seg = f * L + level;
+    if (tid == 0) gbase = atomicAdd(&cand_cnt[seg], n);
+    __syncthreads();
+    const int gb = gbase;
+    for (int i = tid; i < n; i += 256)
+        if (gb + i < cand_cap) cand[(size_t)f * cand_cap + gb + i] = lcand[i];
+    if (lhist[tid]) atomicAdd(&hist[(size_t)seg * 256 + tid], (int)lhist[tid]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_select
+struct LevelArgs {
+    const uint8_t* img; size_t frame_bytes;
+    const uint32_t* cand; float4* seg_kp;
+    int w, h, stride, quota, surv_cap, keep_cap, cand_cap; float scale;
+};
+struct DetLevels { LevelArgs lv[VIS_MAX_LEVELS]; int L; };
+
+__device__ __forceinline__ uint32_t fmap(float f) {            // order-preserving float -> uint
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float funmap(uint32_t m) {
+    uint32_t u = (m & 0x80000000u) ? (m & 0x7FFFFFFFu) : ~m;
+    return __uint_as_float(u);
+}
+
+// HarrisResponses(blockSize 7, k 0.04) at integer (x,y) of one level
+__device__ float harris7(const uint8_t* __restrict__ img, int stride, int x, int y) {
+    int a = 0, b = 0, c = 0;
+    const uint8_t* p0 = img + (size_t)(y - 4) * stride + (x - 4);
+    int r0[9], r1[9], r2[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) { r0[j] = p0[j]; r1[j] = p0[stride + j]; }
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const uint8_t* pr = p0 + (size_t)(i + 2) * stride;
+#pragma unroll
+        for (int j = 0; j < 9; j++) r2[j] = pr[j];
+#pragma unroll
+        for (int j = 1; j <= 7; j++) {
+            const int Ix = (r1[j + 1] - r1[j - 1]) * 2 + (r0[j + 1] - r0[j - 1]) + (r2[j + 1] - r2[j - 1]);
+            const int Iy = (r2[j] - r0[j]) * 2 + (r2[j - 1] - r0[j - 1]) + (r2[j + 1] - r0[j + 1]);
+            a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
+        }
+#pragma unroll
+        for (int j = 0; j < 9; j++) { r0[j] = r1[j]; r1[j] = r2[j]; }
+    }
+    const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+    const float scale_sq_sq = scale * scale * scale * scale;
+    const float fa = (float)a, fb = (float)b, fc = (float)c;
+    const float s = fa + fb;
+    return (fa * fb - fc * fc - 0.04f * s * s) * scale_sq_sq;
+}
+
+__global__ __launch_bounds__(256) void k_select(DetLevels D, const int32_t* __restrict__ cand_cnt,
+                                                const int32_t* __restrict__ hist, int32_t* __restrict__ seg_cnt,
+                                                int32_t* __restrict__ flags, int max_surv) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+    const int tid = threadIdx.x;
+    const int l = blockIdx.x, f = blockIdx.y;
+    const LevelArgs A = D.lv[l];
+    int* sv = reinterpret_cast<int*>(smem + (size_t)max_surv * 8);   // all LDS in the dynamic region (16-B aligned base)
+    int& s_cut = sv[0]; int& s_n = sv[1]; int& s_keep = sv[2];
+    const int seg = f * D.L + l;
+    int C = cand_cnt[seg];
+    if (C > A.cand_cap) { C = A.cand_cap; if (tid == 0) atomicOr(flags, 1); }
+    if (tid == 0) {
+        const int n = 2 * A.quota;
+        int cut = 0;
+        if (C > n) {                                  // KeyPointsFilter::retainBest(2*quota) on FAST score
+            cut = 256;
+            if (n > 0) { int acc = 0; for (int s = 255; s >= 0; s--) { acc += hist[(size_t)seg * 256 + s]; if (acc >= n) { cut = s; break; } } }
+        }
+        s_cut = cut; s_n = 0; s_keep = 0;
+    }
+    __syncthreads();
+    const uint32_t* cand = A.cand + (size_t)f * A.cand_cap;
+    const int cut = s_cut;
+    for (int i = tid; i < C; i += 256) {
+        const uint32_t c = cand[i];
+        if ((int)(c >> 24) >= cut) {
+            const int slot = atomicAdd(&s_n, 1);
+            if (slot < A.surv_cap) keys[slot] = c;
+        }
+    }
+    __syncthreads();
+    int S = s_n;
+    if (S > A.surv_cap) { S = A.surv_cap; if (tid == 0) atomicOr(flags, 2); }
+    int P2 = 2; while (P2 < S) P2 <<= 1;
+    const uint8_t* img = A.img + (size_t)f * A.frame_bytes;
+    for (int i = tid; i < P2; i += 256) {
+        uint64_t key = ~0ull;
+        if (i < S) {
+            const uint32_t c = (uint32_t)keys[i];
+            const int x = c & 0xFFF, y = (c >> 12) & 0xFFF;
+            const float r = harris7(img, A.stride, x, y);
+            key = ((uint64_t)(~fmap(r)) << 32) | ((uint64_t)y << 16) | (uint64_t)x;
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P2; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t a = keys[i], b = keys[ixj];
+                    const bool asc = (i & k) == 0;
+                    if ((a > b) == asc) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // KeyPointsFilter::retainBest(quota) on the Harris response: keep every response >= the quota-th
+    const int q = A.quota;
+    if (S <= q) { if (tid == 0) s_keep = S; }
+    else if (q > 0) {
+        const uint32_t cutm = (uint32_t)(keys[q - 1] >> 32);
+        for (int i = tid; i < S; i += 256) {
+            const uint32_t m = (uint32_t)(keys[i] >> 32);
+            const uint32_t mn = (i + 1 < S) ? (uint32_t)(keys[i + 1] >> 32) : 0xFFFFFFFFu;
+            if (m <= cutm && (i + 1 == S || mn > cutm)) s_keep = i + 1;
+        }
+    }
+    __syncthreads();
+    int keep = s_keep;
+    if (keep > A.keep_cap) { keep = A.keep_cap; if (tid == 0) atomicOr(flags, 4); }
+    float4* out = A.seg_kp + (size_t)f * A.keep_cap;
+    for (int i = tid; i < keep; i += 256) {
+        const uint64_t k = keys[i];
+        out[i] = make_float4((float)(int)(k & 0xFFFF), (float)(int)((k >> 16) & 0xFFFF), funmap(~(uint32_t)(k >> 32)), 0.f);
+    }
+    if (tid == 0) seg_cnt[seg] = keep;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_describe: one wave per keypoint
+#define PR 21                 // raw patch radius: 18 (max rotated sample offset) + 3 (blur taps)
+#define PW 43
+#define PS 44                 // raw patch LDS row stride
+#define HW 37                 // horizontally blurred columns kept (patch cols 3..39)
+#define HS 38
+#define WAVE_LDS (PW * PS + PW * HS * 2 + 12)     // bytes per wave, multiple of 4
+
+__device__ const int8_t g_pattern[256 * 4] = {
+#include "orb_pattern.inc"
+};
+
+// LDS traffic inside ONE wave is processed in issue order; only the compiler must be kept from
+// reordering the accesses (waves of a block use disjoint LDS regions, some exit early).
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+                         __builtin_amdgcn_wave_barrier();                        \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+struct DescArgs {
+    int umax[16];
+    int kq[7];                // 7-tap Gaussian, Q8
+    float rad_per_deg;        // (float)(CV_PI/180.f)
+    int patch_size;
+};
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float p1 = 0.9997878412794807f * (float)(180 / M_PI);
+    const float p3 = -0.3258083974640975f * (float)(180 / M_PI);
+    const float p5 = 0.1555786518463281f * (float)(180 / M_PI);
+    const float p7 = -0.04432655554792128f * (float)(180 / M_PI);
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// deterministic double sin/cos: Cody-Waite by pi/2 + fdlibm kernels, IEEE + - * only (no FMA)
+__device__ __forceinline__ void sincos_det(double x, double* s, double* c) {
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double PIO2_HI = 1.57079632673412561417e+00;
+    const double PIO2_LO = 6.07710050650619224932e-11;
+    const double kd = rint(x * TWO_OVER_PI);
+    const int k = (int)kd;
+    const double r = (x - kd * PIO2_HI) - kd * PIO2_LO;
+    const double z = r * r;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double ps = S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6))));
+    const double sr = r + (r * z) * ps;
+    const double pc = C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6))));
+    const double cr = (1.0 - 0.5 * z) + (z * z) * pc;
+    switch (k & 3) {
+        case 0: *s = sr;  *c = cr;  break;
+        case 1: *s = cr;  *c = -sr; break;
+        case 2: *s = -sr; *c = -cr; break;
+        default: *s = -cr; *c = sr; break;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const int32_t* __restrict__ seg_cnt,
+                                                  vis_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
+                                                  int32_t* __restrict__ nkp, int kcap, int rec0,
+                                                  int32_t* __restrict__ flags) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * WAVE_LDS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int f = blockIdx.y;
+    const int g = blockIdx.x * 4 + wv;
+    // locate (level, index) of packed keypoint g: level-major, canonical order inside a level
+    int total = 0, lev = -1, idx = 0;
+    for (int l = 0; l < D.L; l++) {
+        const int c = seg_cnt[f * D.L + l];
+        if (lev < 0 && g < total + c) { lev = l; idx = g - total; }
+        total += c;
+    }
+    if (total > kcap) { total = kcap; if (g == 0 && lane == 0) atomicOr(flags, 8); }
+    if (g == 0 && lane == 0) nkp[rec0 + f] = total;
+    if (lev < 0 || g >= kcap) return;
+    const LevelArgs A = D.lv[lev];
+    const float4 kpr = A.seg_kp[(size_t)f * A.keep_cap + idx];
+    const int x0 = (int)kpr.x, y0 = (int)kpr.y;
+    uint8_t* raw = lds + wv * WAVE_LDS;
+    uint16_t* hb = reinterpret_cast<uint16_t*>(raw + PW * PS);
+    const uint8_t* img = A.img + (size_t)f * A.frame_bytes + (size_t)(y0 - PR) * A.stride + (x0 - PR);
+    for (int i = lane; i < PW * PW; i += 64) {
+        const int r = i / PW, c = i - r * PW;
+        raw[r * PS + c] = img[(size_t)r * A.stride + c];
+    }
+    WAVE_SYNC();
+    // IC angle over the radius-15 disc
+    int m01 = 0, m10 = 0;
+    for (int i = lane; i < 31 * 31; i += 64) {
+        const int vv = i / 31 - 15, uu = i % 31 - 15;
+        const int av = vv < 0 ? -vv : vv, au = uu < 0 ? -uu : uu;
+        if (au <= G.umax[av]) {
+            const int I = raw[(PR + vv) * PS + (PR + uu)];
+            m10 += uu * I; m01 += vv * I;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    // horizontal 7-tap pass over all 43 rows, patch columns 3..39
+    for (int i = lane; i < PW * HW; i += 64) {
+        const int r = i / HW, c = i - r * HW;
+        const uint8_t* p = raw + r * PS + c;
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) s += G.kq[k] * p[k];
+        hb[r * HS + c] = (uint16_t)s;                 // <= 255*257 = 65535
+    }
+    WAVE_SYNC();
+    float ang = angle;
+    ang *= G.rad_per_deg;
+    double sd, cd;
+    sincos_det((double)ang, &sd, &cd);
+    const float a = (float)cd, b = (float)sd;
+    unsigned long long words[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int bit = lane + 64 * k;
+        const char4 pt = *reinterpret_cast<const char4*>(g_pattern + 4 * bit);
+        int val[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const float px = (float)(e ? pt.z : pt.x), py = (float)(e ? pt.w : pt.y);
+            const float fx = px * a - py * b;
+            const float fy = px * b + py * a;
+            const int ix = __float2int_rn(fx), iy = __float2int_rn(fy);
+            const uint16_t* hp = hb + (PR + iy - 3) * HS + (PR + ix - 3);
+            int s = 0;
+#pragma unroll
+            for (int j = 0; j < 7; j++) s += G.kq[j] * hp[j * HS];
+            s = (s + (1 << 15)) >> 16;
+            val[e] = s > 255 ? 255 : s;
+        }
+        words[k] = __ballot(val[0] < val[1]);
+    }
+    uint8_t* dout = desc + ((size_t)(rec0 + f) * kcap + g) * 32;
+    if (lane < 4) reinterpret_cast<unsigned long long*>(dout)[lane] = words[lane];
+    if (lane == 0) {
+        vis_keypoint kp;
+        kp.x = kpr.x * A.scale; kp.y = kpr.y * A.scale;
+        kp.size = (float)G.patch_size * A.scale;
+        kp.angle = angle; kp.response = kpr.z; kp.octave = lev; kp.class_id = -1;
+        kps[(size_t)(rec0 + f) * kcap + g] = kp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Camera::Update half pyramid (src/Camera.cpp:68-70): exact 2x2 box mean (a+b+c+d+2)>>2
+__global__ void k_half(const uint8_t* __restrict__ src, int sw, int sstride, uint8_t* __restrict__ dst, int dw, int dh) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= dw || y >= dh) return;
+    const uint8_t* s = src + (size_t)(2 * y) * sstride + 2 * x;
+    dst[(size_t)y * dw + x] = (uint8_t)((s[0] + s[1] + s[sstride] + s[sstride + 1] + 2) >> 2);
+    (void)sw;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+static void fill_det_levels(const Plan* pl, const uint8_t* d_frames, DetLevels& D) {
+    D.L = pl->L;
+    for (int l = 0; l < pl->L; l++) {
+        LevelArgs& A = D.lv[l];
+        A.img = l == 0 ? d_frames : pl->d_pyr[l];
+        A.frame_bytes = pl->lv[l].frame_bytes;
+        A.cand = pl->d_cand[l]; A.seg_kp = pl->d_seg_kp[l];
+        A.w = pl->lv[l].w; A.h = pl->lv[l].h; A.stride = pl->lv[l].stride;
+        A.quota = pl->lv[l].quota; A.surv_cap = pl->lv[l].surv_cap; A.keep_cap = pl->lv[l].keep_cap;
+        A.cand_cap = pl->lv[l].cand_cap; A.scale = pl->lv[l].scale;
+    }
+}
+
+static void fill_desc_args(const vis_params& p, DescArgs& G) {
+    // ORB umax table for halfPatchSize = 15 (computed exactly as ORB_Impl does)
+    const int hp = p.patch_size / 2;
+    int umax[17] = {0};
+    int v, v0, vmax = (int)std::floor(hp * std::sqrt(2.f) / 2 + 1);
+    int vmin = (int)std::ceil(hp * std::sqrt(2.f) / 2);
+    for (v = 0; v <= vmax; ++v) umax[v] = (int)std::lrint(std::sqrt((double)hp * hp - v * v));
+    for (v = hp, v0 = 0; v >= vmin; --v) { while (umax[v0] == umax[v0 + 1]) ++v0; umax[v] = v0; ++v0; }
+    for (int i = 0; i < 16; i++) G.umax[i] = umax[i];
+    // getGaussianKernel(7, 2, CV_32F) -> Q8 integers (cvRound(k*256))
+    const int n = 7; const double sigma = 2.0;
+    double scale2X = -0.5 / (sigma * sigma), sum = 0; float cf[7];
+    for (int i = 0; i < n; i++) { double x = i - (n - 1) * 0.5; cf[i] = (float)std::exp(scale2X * x * x); sum += cf[i]; }
+    sum = 1. / sum;
+    for (int i = 0; i < n; i++) { cf[i] = (float)(cf[i] * sum); G.kq[i] = (int)std::lrint((double)cf[i] * 256.0); }
+    G.rad_per_deg = (float)(M_PI / 180.f);
+    G.patch_size = p.patch_size;
+}
+
+int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int rec0) {
+    hipStream_t st = ctx->stream;
+    const int L = pl->L;
+    HIPCHK(ctx, hipMemsetAsync(pl->d_cand_cnt, 0, sizeof(int32_t) * (size_t)pl->B * L, st));
+    HIPCHK(ctx, hipMemsetAsync(pl->d_hist, 0, sizeof(int32_t) * (size_t)pl->B * L * 256, st));
+    HIPCHK(ctx, hipMemsetAsync(pl->d_seg_cnt, 0, sizeof(int32_t) * (size_t)pl->B * L, st));
+    DetLevels D; fill_det_levels(pl, d_frames, D);
+    DescArgs G; fill_desc_args(ctx->p, G);
+    int nfast = 0;
+    for (int l = 1; l < L; l++) {
+        const LevelInfo& V = pl->lv[l];
+        const LevelInfo& U = pl->lv[l - 1];
+        dim3 grid((V.w + 255) / 256, (V.h + 3) / 4, n), block(64, 4);
+        hipLaunchKernelGGL(k_resize, grid, block, 0, st, D.lv[l - 1].img, U.w, U.stride, U.frame_bytes,
+                           pl->d_pyr[l], V.w, V.h, V.stride, V.frame_bytes,
+                           pl->d_xofs[l], pl->d_ialpha[l], pl->d_yofs[l], pl->d_ibeta[l]);
+    }
+    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[1], st);
+    for (int l = 0; l < L; l++) {
+        const LevelInfo& V = pl->lv[l];
+        dim3 grid(V.tiles_x, V.tiles_y, n);
+        hipLaunchKernelGGL(k_fast, grid, dim3(256), 0, st, D.lv[l].img, V.w, V.h, V.stride, V.frame_bytes,
+                           ctx->p.fast_threshold, ctx->p.edge_threshold, pl->d_cand[l], V.cand_cap,
+                           pl->d_cand_cnt, pl->d_hist, l, L);
+        nfast++;
+    }
+    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[2], st);
+    int max_surv = 0; for (int l = 0; l < L; l++) max_surv = std::max(max_surv, pl->lv[l].surv_cap);
+    hipLaunchKernelGGL(k_select, dim3(L, n), dim3(256), (size_t)max_surv * 8 + 16, st, D, pl->d_cand_cnt, pl->d_hist,
+                       pl->d_seg_cnt, pl->d_flags, max_surv);
+    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[3], st);
+    hipLaunchKernelGGL(k_describe, dim3((pl->kcap + 3) / 4, n), dim3(256), 0, st, D, G, pl->d_seg_cnt,
+                       pl->d_kps, pl->d_desc, pl->d_nkp, pl->kcap, rec0, pl->d_flags);
+    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[4], st);
+    ctx->tm.launches_fast = nfast;
+    ctx->tm.launches_total = 2 * L - 1 + 2;
+    HIPCHK(ctx, hipGetLastError());
+    return VIS_OK;
+}
+
+int launch_half_pyramid(vis_ctx* ctx, const uint8_t* d_img, int w, int h, int stride, uint8_t* d_out[5]) {
+    const uint8_t* src = d_img; int sw = w, sh = h, ss = stride;
+    for (int l = 1; l < 5; l++) {
+        const int dw = sw >> 1, dh = sh >> 1;
+        if (dw < 1 || dh < 1) return VIS_E_INVALID;
+        dim3 block(64, 4), grid((dw + 63) / 64, (dh + 3) / 4);
+        hipLaunchKernelGGL(k_half, grid, block, 0, ctx->stream, src, sw, ss, d_out[l], dw, dh);
+        src = d_out[l]; sw = dw; sh = dh; ss = dw;
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return VIS_OK;
+}

@@ -1,0 +1,196 @@
+// match.hip -- brute-force Hamming 2-NN (both directions) and the reference's match filters on gfx950.
+//
+// k_knn2   replaces descriptorsGPU[0/1].upload + 2 x cuda::DescriptorMatcher::knnMatch(k=2)
+//          (/root/reference/src/MatcherGPU.cpp:49-56; CPU twin Matcher::computeMatches,
+//          /root/reference/src/Matcher.cpp:83-94).  Descriptors never leave HBM between detect and match.
+// k_filter fuses Matcher::computeBestMatches (/root/reference/src/Matcher.cpp:353-367):
+//          nnFilter :148-169, computeSymMatches :96-144, sortMatches :329-352,
+//          bestMatchesFilter :171-244 and getGoodMatches :295-303 -- O(N) instead of the
+//          reference's O(N1*N2) iterator scan.
+// Bit-exact against oracle/match.cpp (tests/test_match_gpu.py).
+#include "vis_internal.h"
+
+// One lane = one query row; the train descriptor of the current iteration is wave-uniform, so the
+// compiler keeps it in SGPRs (s_load_dwordx8) and the inner loop is 8 x (v_xor, v_bcnt accumulate)
+// + 3 ops of top-2 maintenance on the packed key (dist << 16 | trainIdx).  Keeping the two smallest
+// keys reproduces cv::batchDistance's order: ascending distance, ties -> lower train index first.
+__global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ desc, const int32_t* __restrict__ nkp, int kcap,
+                                              const int32_t* __restrict__ pair_q, const int32_t* __restrict__ pair_t,
+                                              uint32_t* __restrict__ knn12, uint32_t* __restrict__ knn21) {
+    const int pair = blockIdx.y, dir = blockIdx.z;
+    const int rq = dir == 0 ? pair_q[pair] : pair_t[pair];
+    const int rt = dir == 0 ? pair_t[pair] : pair_q[pair];
+    if (rq < 0 || rt < 0) return;
+    const int nq = min(nkp[rq], kcap), nt = min(nkp[rt], kcap);
+    if ((int)(blockIdx.x * blockDim.x) >= nq) return;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint4* Q = reinterpret_cast<const uint4*>(desc + ((size_t)rq * kcap + min(q, nq - 1)) * 32);
+    const uint4 qa = Q[0], qb = Q[1];
+    const uint4* T = reinterpret_cast<const uint4*>(desc + (size_t)rt * kcap * 32);
+    uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
+    for (int t = 0; t < nt; t++) {
+        const uint4 ta = T[2 * t], tb = T[2 * t + 1];
+        uint32_t d = __popc(qa.x ^ ta.x);
+        d += __popc(qa.y ^ ta.y); d += __popc(qa.z ^ ta.z); d += __popc(qa.w ^ ta.w);
+        d += __popc(qb.x ^ tb.x); d += __popc(qb.y ^ tb.y); d += __popc(qb.z ^ tb.z); d += __popc(qb.w ^ tb.w);
+        const uint32_t key = (d << 16) | (uint32_t)t;
+        k1 = min(k1, max(k0, key));
+        k0 = min(k0, key);
+    }
+    if (q < nq) {
+        uint32_t* out = (dir == 0 ? knn12 : knn21) + ((size_t)pair * kcap + q) * 2;
+        out[0] = k0; out[1] = k1;
+    }
+}
+
+__device__ __forceinline__ uint32_t fmap_f(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ bool ratio_survives(uint32_t k0, uint32_t k1, double ratio) {
+    if (k0 == 0xFFFFFFFFu || k1 == 0xFFFFFFFFu) return false;               // fewer than 2 neighbours
+    const double d0 = (double)(float)(k0 >> 16), d1 = (double)(float)(k1 >> 16);
+    return !(d0 > ratio * d1);                                              // src/Matcher.cpp:158
+}
+
+// block per pair.  dynamic LDS: keys[P] (u64) | cell[root*root] (u32) | scan[blockDim] (int) | misc
+__global__ __launch_bounds__(256) void k_filter(const vis_keypoint* __restrict__ kps, const int32_t* __restrict__ nkp, int kcap,
+                                                const int32_t* __restrict__ pair_q, const int32_t* __restrict__ pair_t,
+                                                const uint32_t* __restrict__ knn12, const uint32_t* __restrict__ knn21,
+                                                double ratio, int sym_mode, int root,
+                                                const float* __restrict__ hf, const float* __restrict__ wf,
+                                                vis_dmatch* __restrict__ sym_out, int32_t* __restrict__ nsym_out,
+                                                vis_dmatch* __restrict__ good_out, int32_t* __restrict__ ngood_out,
+                                                float* __restrict__ p1, float* __restrict__ p2, int keys_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+    uint32_t* cell = reinterpret_cast<uint32_t*>(smem + (size_t)keys_cap * 8);
+    int* scan = reinterpret_cast<int*>(cell + root * root);
+    int* misc = scan + 256;
+    const int tid = threadIdx.x, pair = blockIdx.x;
+    const int rq = pair_q[pair], rt = pair_t[pair];
+    const int ncell = root * root;
+    if (rq < 0 || rt < 0) { if (tid == 0) { nsym_out[pair] = 0; ngood_out[pair] = 0; } return; }
+    const int n1 = min(nkp[rq], kcap), n2 = min(nkp[rt], kcap);
+    const vis_keypoint* K1 = kps + (size_t)rq * kcap;
+    const vis_keypoint* K2 = kps + (size_t)rt * kcap;
+    const uint32_t* A = knn12 + (size_t)pair * kcap * 2;
+    const uint32_t* Bk = knn21 + (size_t)pair * kcap * 2;
+    vis_dmatch* sym = sym_out + (size_t)pair * kcap;
+    // ---- computeSymMatches: ordered compaction over q (chunk per thread + block scan)
+    const int chunk = (n1 + 255) / 256;
+    const int qb = tid * chunk, qe = min(n1, qb + chunk);
+    int cnt = 0;
+    for (int q = qb; q < qe; q++) {
+        const uint32_t a0 = A[2 * q], a1 = A[2 * q + 1];
+        bool ok = ratio_survives(a0, a1, ratio);
+        if (ok) {
+            const int t = a0 & 0xFFFF;
+            ok = t < n2;
+            if (ok) {
+                const uint32_t b0 = Bk[2 * t], b1 = Bk[2 * t + 1];
+                ok = (b0 != 0xFFFFFFFFu) && (int)(b0 & 0xFFFF) == q;
+                if (ok && sym_mode == VIS_SYM_INTENDED) ok = ratio_survives(b0, b1, ratio);
+            }
+        }
+        cnt += ok ? 1 : 0;
+    }
+    scan[tid] = cnt;
+    __syncthreads();
+    if (tid == 0) { int acc = 0; for (int i = 0; i < 256; i++) { int c = scan[i]; scan[i] = acc; acc += c; } misc[0] = acc; }
+    __syncthreads();
+    const int nsym = misc[0];
+    int pos = scan[tid];
+    for (int q = qb; q < qe; q++) {
+        const uint32_t a0 = A[2 * q], a1 = A[2 * q + 1];
+        bool ok = ratio_survives(a0, a1, ratio);
+        if (ok) {
+            const int t = a0 & 0xFFFF;
+            ok = t < n2;
+            if (ok) {
+                const uint32_t b0 = Bk[2 * t], b1 = Bk[2 * t + 1];
+                ok = (b0 != 0xFFFFFFFFu) && (int)(b0 & 0xFFFF) == q;
+                if (ok && sym_mode == VIS_SYM_INTENDED) ok = ratio_survives(b0, b1, ratio);
+            }
+            if (ok) {
+                vis_dmatch m; m.queryIdx = q; m.trainIdx = t; m.imgIdx = -1; m.distance = (float)(a0 >> 16);
+                sym[pos] = m;
+                // sortMatches key: y ascending, ties keep symmetric-match order (stable)
+                keys[pos] = ((uint64_t)fmap_f(K1[q].y) << 32) | (uint32_t)pos;
+                pos++;
+            }
+        }
+    }
+    int P2 = 2; while (P2 < nsym) P2 <<= 1;
+    __syncthreads();
+    for (int i = nsym + tid; i < P2; i += 256) keys[i] = ~0ull;
+    for (int i = tid; i < ncell; i += 256) cell[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (int k = 2; k <= P2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P2; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t a = keys[i], b = keys[ixj];
+                    const bool asc = (i & k) == 0;
+                    if ((a > b) == asc) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // ---- bestMatchesFilter: band = first j with y <= hf[j]; column = steps until x <= wf[i] (clamped);
+    // per cell the strictly smallest distance, first in sorted order wins ties -> min of (dist<<16 | sorted pos)
+    for (int s = tid; s < nsym; s += 256) {
+        const vis_dmatch m = sym[(uint32_t)keys[s]];
+        const float y = K1[m.queryIdx].y, x = K1[m.queryIdx].x;
+        int band = -1;
+        for (int j = 0; j < root; j++) if (y <= hf[j]) { band = j; break; }
+        if (band < 0) continue;
+        int col = 0;
+        while (col < root - 1 && x > wf[col]) col++;
+        atomicMin(&cell[band * root + col], ((uint32_t)m.distance << 16) | (uint32_t)s);
+    }
+    __syncthreads();
+    // ordered compaction of the occupied cells (band-major, column ascending)
+    if (tid == 0) {
+        int n = 0;
+        vis_dmatch* good = good_out + (size_t)pair * ncell;
+        float* q1 = p1 + (size_t)pair * ncell * 2;
+        float* q2 = p2 + (size_t)pair * ncell * 2;
+        for (int c = 0; c < ncell; c++) {
+            const uint32_t v = cell[c];
+            if (v == 0xFFFFFFFFu) continue;
+            const vis_dmatch m = sym[(uint32_t)keys[v & 0xFFFF]];
+            good[n] = m;
+            q1[2 * n] = K1[m.queryIdx].x; q1[2 * n + 1] = K1[m.queryIdx].y;     // getGoodMatches
+            q2[2 * n] = K2[m.trainIdx].x; q2[2 * n + 1] = K2[m.trainIdx].y;
+            n++;
+        }
+        ngood_out[pair] = n;
+        nsym_out[pair] = nsym;
+    }
+}
+
+int launch_match(vis_ctx* ctx, Plan* pl, int npairs) {
+    if (npairs <= 0) return VIS_OK;
+    // small problems: one wave per block so a single pair still spreads over many CUs
+    const int bs = (npairs * ((pl->kcap + 255) / 256) * 2 >= 512) ? 256 : 64;
+    dim3 grid((pl->kcap + bs - 1) / bs, npairs, 2);
+    hipLaunchKernelGGL(k_knn2, grid, dim3(bs), 0, ctx->stream, pl->d_desc, pl->d_nkp, pl->kcap,
+                       pl->d_pair_q, pl->d_pair_t, pl->d_knn12, pl->d_knn21);
+    HIPCHK(ctx, hipGetLastError());
+    return VIS_OK;
+}
+
+int launch_filter(vis_ctx* ctx, Plan* pl, int npairs) {
+    if (npairs <= 0) return VIS_OK;
+    int keys_cap = 2; while (keys_cap < pl->kcap) keys_cap <<= 1;
+    const size_t lds = (size_t)keys_cap * 8 + (size_t)pl->root * pl->root * 4 + 256 * 4 + 16;
+    hipLaunchKernelGGL(k_filter, dim3(npairs), dim3(256), lds, ctx->stream, pl->d_kps, pl->d_nkp, pl->kcap,
+                       pl->d_pair_q, pl->d_pair_t, pl->d_knn12, pl->d_knn21, (double)ctx->p.ratio, ctx->p.sym_mode,
+                       pl->root, pl->d_hf, pl->d_wf, pl->d_sym, pl->d_nsym, pl->d_good, pl->d_ngood,
+                       pl->d_p1, pl->d_p2, keys_cap);
+    HIPCHK(ctx, hipGetLastError());
+    return VIS_OK;
+}

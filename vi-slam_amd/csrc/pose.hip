@@ -1,0 +1,675 @@
+// pose.hip -- batched essential-matrix RANSAC (5-point + Sampson), recoverPose (cheirality vote) and
+// F2FRansac on gfx950, FP64 VALU.
+//
+// Replaces the calib3d calls of VISystem::EstimatePoseFeaturesRansac
+//   findEssentialMat(p1,p2,focal,pp,RANSAC,0.999,1.0)   /root/reference/src/VISystem.cpp:1679-1680
+//   recoverPose(E,p1,p2,R,t,focal,pp)                   /root/reference/src/VISystem.cpp:1701
+// and the reference's own VISystem::F2FRansac            /root/reference/src/VISystem.cpp:612-769.
+//
+// Parallelisation: RANSAC is sequential only in (a) its cv::RNG sample stream and (b) the
+// "first strictly better model wins / adaptive iteration count" scan.  Both are O(iters) scalar work;
+// everything expensive (minimal solver, M Sampson errors per model) is independent per hypothesis:
+//   k_pose_prep   block/pair : normalise points, thread 0 replays cv::RNG -> sample table
+//   k_ransac_hyp  lane/hypothesis : 5-point solve (<=10 E) + inlier count per E
+//   k_ransac_scan thread/pair : replays RANSACPointSetRegistrator::run's accept/update rule in order
+//   k_pose_final  block/pair : inlier mask of the winner, SVD, 4x M DLT triangulations, cheirality vote
+// The first 64 hypotheses are evaluated and scanned first; the remaining ones exit immediately when
+// the adaptive iteration count already stopped (the common case on good matches).
+// Algorithm and operation order mirror oracle/pose.cpp; compared with a stated tolerance
+// (tests/test_pose_gpu.py), not bit-exactly.
+#include "vis_internal.h"
+#include <cfloat>
+
+#define DEV __device__ __forceinline__
+
+struct PoseTables { int8_t q_of[4][4]; int8_t c_of[10][4]; };
+constexpr int QE[10][3] = {{2,0,0},{1,1,0},{1,0,1},{0,2,0},{0,1,1},{0,0,2},{1,0,0},{0,1,0},{0,0,1},{0,0,0}};
+constexpr int CE[20][3] = {{3,0,0},{0,3,0},{2,1,0},{1,2,0},{2,0,1},{2,0,0},{0,2,1},{0,2,0},{1,1,1},{1,1,0},
+                           {1,0,2},{1,0,1},{1,0,0},{0,1,2},{0,1,1},{0,1,0},{0,0,3},{0,0,2},{0,0,1},{0,0,0}};
+constexpr PoseTables make_tables() {
+    PoseTables t{};
+    const int ve[4][3] = {{1,0,0},{0,1,0},{0,0,1},{0,0,0}};
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++)
+        for (int m = 0; m < 10; m++)
+            if (QE[m][0] == ve[i][0] + ve[j][0] && QE[m][1] == ve[i][1] + ve[j][1] && QE[m][2] == ve[i][2] + ve[j][2]) t.q_of[i][j] = (int8_t)m;
+    for (int m = 0; m < 10; m++) for (int v = 0; v < 4; v++)
+        for (int c = 0; c < 20; c++)
+            if (CE[c][0] == QE[m][0] + ve[v][0] && CE[c][1] == QE[m][1] + ve[v][1] && CE[c][2] == QE[m][2] + ve[v][2]) t.c_of[m][v] = (int8_t)c;
+    return t;
+}
+__device__ const PoseTables g_tb = make_tables();
+
+DEV void cross3(const double* a, const double* b, double* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+DEV double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+__device__ void jacobi_eig(int n, double* A, double* V) {
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = 0;
+        for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < n; p++)
+            for (int q = p + 1; q < n; q++) {
+                const double apq = A[p * n + q];
+                if (fabs(apq) < 1e-300) continue;
+                const double app = A[p * n + p], aqq = A[q * n + q];
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; k++) {
+                    const double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - s * akq;
+                    A[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; k++) {
+                    const double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk;
+                    A[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; k++) {
+                    const double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - s * vkq;
+                    V[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+DEV void mul_ll(const double* a, const double* b, double* q) {
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) q[g_tb.q_of[i][j]] += a[i] * b[j];
+}
+DEV void mul_ql(const double* q, const double* l, double* c, double sgn) {
+    for (int m = 0; m < 10; m++) for (int v = 0; v < 4; v++) c[g_tb.c_of[m][v]] += sgn * (q[m] * l[v]);
+}
+DEV double poly_eval(const double* c, int deg, double x) {
+    double r = c[deg];
+    for (int i = deg - 1; i >= 0; i--) r = r * x + c[i];
+    return r;
+}
+
+struct Sturm { double c[12][11]; int deg[12]; int n; };
+
+__device__ void sturm_build(const double* p, int deg, Sturm& S) {
+    for (int i = 0; i <= deg; i++) S.c[0][i] = p[i];
+    S.deg[0] = deg; S.n = 1;
+    if (deg == 0) return;
+    for (int i = 1; i <= deg; i++) S.c[1][i - 1] = p[i] * i;
+    S.deg[1] = deg - 1; S.n = 2;
+    while (S.deg[S.n - 1] > 0) {
+        const double* a = S.c[S.n - 2]; const int da = S.deg[S.n - 2];
+        const double* b = S.c[S.n - 1]; const int db = S.deg[S.n - 1];
+        double r[11];
+        for (int i = 0; i <= da; i++) r[i] = a[i];
+        for (int k = da - db; k >= 0; k--) {
+            const double f = r[db + k] / b[db];
+            for (int i = 0; i <= db; i++) r[i + k] -= f * b[i];
+            r[db + k] = 0.0;
+        }
+        int dr = db - 1;
+        double mx = 0; for (int i = 0; i <= dr; i++) mx = fmax(mx, fabs(r[i]));
+        double ma = 0; for (int i = 0; i <= da; i++) ma = fmax(ma, fabs(a[i]));
+        if (mx <= 1e-14 * ma) break;
+        while (dr > 0 && fabs(r[dr]) <= 1e-14 * mx) dr--;
+        for (int i = 0; i <= dr; i++) S.c[S.n][i] = -r[i];
+        S.deg[S.n] = dr; S.n++;
+        if (S.n >= 12) break;
+    }
+}
+__device__ int sturm_count(const Sturm& S, double x) {
+    int changes = 0, last = 0;
+    for (int k = 0; k < S.n; k++) {
+        const double v = poly_eval(S.c[k], S.deg[k], x);
+        const int s = v > 0 ? 1 : (v < 0 ? -1 : 0);
+        if (s == 0) continue;
+        if (last != 0 && s != last) changes++;
+        last = s;
+    }
+    return changes;
+}
+
+struct Iv { double lo, hi; int nlo, nhi; };
+#define IV_STACK 96
+
+__device__ int real_roots(const double* cin, int deg, double* roots) {
+    double c[11]; double mx = 0;
+    for (int i = 0; i <= deg; i++) mx = fmax(mx, fabs(cin[i]));
+    if (mx == 0) return 0;
+    for (int i = 0; i <= deg; i++) c[i] = cin[i] / mx;
+    while (deg > 0 && fabs(c[deg]) < 1e-15) deg--;
+    if (deg == 0) return 0;
+    Sturm S; sturm_build(c, deg, S);
+    double B = 0;
+    for (int i = 0; i < deg; i++) B = fmax(B, fabs(c[i] / c[deg]));
+    B += 1.0;
+    Iv stack[IV_STACK]; int sp = 0;
+    const int nlo = sturm_count(S, -B), nhi = sturm_count(S, B);
+    int nroots = 0;
+    if (nlo - nhi <= 0) return 0;
+    stack[sp++] = Iv{-B, B, nlo, nhi};
+    while (sp > 0 && nroots < deg) {
+        const Iv iv = stack[--sp];
+        const int cnt = iv.nlo - iv.nhi;
+        if (cnt <= 0) continue;
+        const double mid = 0.5 * (iv.lo + iv.hi);
+        const bool tiny = (iv.hi - iv.lo) <= 1e-13 * B || mid <= iv.lo || mid >= iv.hi;
+        if (cnt == 1 || tiny) {
+            double lo = iv.lo, hi = iv.hi;
+            double flo = poly_eval(c, deg, lo), fhi = poly_eval(c, deg, hi);
+            if (!tiny && ((flo < 0) != (fhi < 0))) {
+                for (int it = 0; it < 200; it++) {
+                    const double m = 0.5 * (lo + hi);
+                    if (m <= lo || m >= hi) break;
+                    const double fm = poly_eval(c, deg, m);
+                    if ((fm < 0) == (flo < 0)) { lo = m; flo = fm; } else { hi = m; fhi = fm; }
+                }
+                roots[nroots++] = 0.5 * (lo + hi);
+            } else if (!tiny) {
+                if (sp + 2 <= IV_STACK) {
+                    const int nm = sturm_count(S, mid);
+                    stack[sp++] = Iv{mid, iv.hi, nm, iv.nhi};
+                    stack[sp++] = Iv{iv.lo, mid, iv.nlo, nm};
+                }
+            } else {
+                roots[nroots++] = mid;
+            }
+            continue;
+        }
+        if (sp + 2 > IV_STACK) { roots[nroots++] = mid; continue; }
+        const int nm = sturm_count(S, mid);
+        stack[sp++] = Iv{mid, iv.hi, nm, iv.nhi};
+        stack[sp++] = Iv{iv.lo, mid, iv.nlo, nm};
+    }
+    return nroots;
+}
+
+DEV void pmul(const double* a, int da, const double* b, int db, double* o) {
+    for (int i = 0; i <= da + db; i++) o[i] = 0;
+    for (int i = 0; i <= da; i++) for (int j = 0; j <= db; j++) o[i + j] += a[i] * b[j];
+}
+
+// 5-point minimal solver; Es: up to 10 row-major E with x2^T E x1 = 0, ascending root order
+__device__ int five_point(const double* q1, const double* q2, double* Es) {
+    double A[9][5];
+    for (int i = 0; i < 5; i++) {
+        const double x1 = q1[2 * i], y1 = q1[2 * i + 1], x2 = q2[2 * i], y2 = q2[2 * i + 1];
+        A[0][i] = x2 * x1; A[1][i] = x2 * y1; A[2][i] = x2;
+        A[3][i] = y2 * x1; A[4][i] = y2 * y1; A[5][i] = y2;
+        A[6][i] = x1; A[7][i] = y1; A[8][i] = 1.0;
+    }
+    double vs[5][9]; double betas[5];
+    for (int k = 0; k < 5; k++) {
+        double nrm = 0;
+        for (int i = k; i < 9; i++) nrm += A[i][k] * A[i][k];
+        nrm = sqrt(nrm);
+        for (int i = 0; i < 9; i++) vs[k][i] = 0;
+        if (nrm < 1e-300) { betas[k] = 0; continue; }
+        const double alpha = A[k][k] >= 0 ? -nrm : nrm;
+        for (int i = k; i < 9; i++) vs[k][i] = A[i][k];
+        vs[k][k] -= alpha;
+        double vn = 0; for (int i = k; i < 9; i++) vn += vs[k][i] * vs[k][i];
+        if (vn < 1e-300) { betas[k] = 0; continue; }
+        betas[k] = 2.0 / vn;
+        for (int j = k; j < 5; j++) {
+            double d = 0; for (int i = k; i < 9; i++) d += vs[k][i] * A[i][j];
+            d *= betas[k];
+            for (int i = k; i < 9; i++) A[i][j] -= d * vs[k][i];
+        }
+    }
+    double Bs[4][9];
+    for (int j = 0; j < 4; j++) {
+        double e[9];
+        for (int i = 0; i < 9; i++) e[i] = 0;
+        e[5 + j] = 1.0;
+        for (int k = 4; k >= 0; k--) {
+            double d = 0; for (int i = k; i < 9; i++) d += vs[k][i] * e[i];
+            d *= betas[k];
+            for (int i = k; i < 9; i++) e[i] -= d * vs[k][i];
+        }
+        for (int i = 0; i < 9; i++) Bs[j][i] = e[i];
+    }
+    double El[3][3][4];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) for (int v = 0; v < 4; v++) El[r][c][v] = Bs[v][3 * r + c];
+    double M[10][20];
+    for (int r = 0; r < 10; r++) for (int c = 0; c < 20; c++) M[r][c] = 0;
+    {
+        const int ta[3] = {0, 1, 2}, tb[3] = {1, 0, 0}, tc[3] = {2, 2, 1}, td[3] = {2, 2, 1}, te[3] = {1, 0, 0};
+        const double sg[3] = {1.0, -1.0, 1.0};
+        for (int k = 0; k < 3; k++) {
+            double q[10], q2[10];
+            for (int i = 0; i < 10; i++) { q[i] = 0; q2[i] = 0; }
+            mul_ll(El[1][tb[k]], El[2][tc[k]], q);
+            mul_ll(El[1][td[k]], El[2][te[k]], q2);
+            for (int i = 0; i < 10; i++) q[i] -= q2[i];
+            mul_ql(q, El[0][ta[k]], M[0], sg[k]);
+        }
+    }
+    {
+        double EEt[3][3][10];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+            for (int m = 0; m < 10; m++) EEt[i][j][m] = 0;
+            for (int k = 0; k < 3; k++) mul_ll(El[i][k], El[j][k], EEt[i][j]);
+        }
+        double tr[10];
+        for (int m = 0; m < 10; m++) tr[m] = 0.5 * ((EEt[0][0][m] + EEt[1][1][m]) + EEt[2][2][m]);
+        for (int i = 0; i < 3; i++) for (int m = 0; m < 10; m++) EEt[i][i][m] -= tr[m];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
+            for (int k = 0; k < 3; k++) mul_ql(EEt[i][k], El[k][j], M[1 + 3 * i + j], 1.0);
+    }
+    for (int col = 0; col < 10; col++) {
+        int piv = col; double best = fabs(M[col][col]);
+        for (int r = col + 1; r < 10; r++) if (fabs(M[r][col]) > best) { best = fabs(M[r][col]); piv = r; }
+        if (best < 1e-300) return 0;
+        if (piv != col) for (int c = 0; c < 20; c++) { const double t = M[piv][c]; M[piv][c] = M[col][c]; M[col][c] = t; }
+        const double inv = 1.0 / M[col][col];
+        for (int c = col; c < 20; c++) M[col][c] *= inv;
+        for (int r = 0; r < 10; r++) {
+            if (r == col) continue;
+            const double f = M[r][col];
+            if (f == 0.0) continue;
+            for (int c = col; c < 20; c++) M[r][c] -= f * M[col][c];
+        }
+    }
+    double Bx[3][4], By[3][4], B1[3][5];
+    for (int i = 0; i < 3; i++) {
+        const double* a = &M[4 + 2 * i][10];
+        const double* b = &M[5 + 2 * i][10];
+        Bx[i][0] = a[2]; Bx[i][1] = a[1] - b[2]; Bx[i][2] = a[0] - b[1]; Bx[i][3] = -b[0];
+        By[i][0] = a[5]; By[i][1] = a[4] - b[5]; By[i][2] = a[3] - b[4]; By[i][3] = -b[3];
+        B1[i][0] = a[9]; B1[i][1] = a[8] - b[9]; B1[i][2] = a[7] - b[8]; B1[i][3] = a[6] - b[7]; B1[i][4] = -b[6];
+    }
+    double c10[11]; for (int i = 0; i <= 10; i++) c10[i] = 0;
+    {
+        double t1[8], t2[8], m[8], o[11];
+        pmul(By[1], 3, B1[2], 4, t1); pmul(B1[1], 4, By[2], 3, t2);
+        for (int i = 0; i <= 7; i++) m[i] = t1[i] - t2[i];
+        pmul(Bx[0], 3, m, 7, o); for (int i = 0; i <= 10; i++) c10[i] += o[i];
+        pmul(Bx[1], 3, B1[2], 4, t1); pmul(B1[1], 4, Bx[2], 3, t2);
+        for (int i = 0; i <= 7; i++) m[i] = t1[i] - t2[i];
+        pmul(By[0], 3, m, 7, o); for (int i = 0; i <= 10; i++) c10[i] -= o[i];
+        double u1[7], u2[7], mm[7];
+        pmul(Bx[1], 3, By[2], 3, u1); pmul(By[1], 3, Bx[2], 3, u2);
+        for (int i = 0; i <= 6; i++) mm[i] = u1[i] - u2[i];
+        pmul(B1[0], 4, mm, 6, o); for (int i = 0; i <= 10; i++) c10[i] += o[i];
+    }
+    double roots[10];
+    const int nr = real_roots(c10, 10, roots);
+    int count = 0;
+    for (int ri = 0; ri < nr && count < 10; ri++) {
+        const double z = roots[ri];
+        double Bz[3][3];
+        for (int i = 0; i < 3; i++) {
+            Bz[i][0] = poly_eval(Bx[i], 3, z);
+            Bz[i][1] = poly_eval(By[i], 3, z);
+            Bz[i][2] = poly_eval(B1[i], 4, z);
+        }
+        double c01[3], c02[3], c12[3];
+        cross3(Bz[0], Bz[1], c01); cross3(Bz[0], Bz[2], c02); cross3(Bz[1], Bz[2], c12);
+        const double n01 = dot3(c01, c01), n02 = dot3(c02, c02), n12 = dot3(c12, c12);
+        double nv[3] = {c01[0], c01[1], c01[2]}; double nn = n01;
+        if (n02 > nn) { nv[0] = c02[0]; nv[1] = c02[1]; nv[2] = c02[2]; nn = n02; }
+        if (n12 > nn) { nv[0] = c12[0]; nv[1] = c12[1]; nv[2] = c12[2]; nn = n12; }
+        if (!(nn > 0)) continue;
+        const double inv = 1.0 / sqrt(nn);
+        const double w = nv[2] * inv;
+        if (fabs(w) < 1e-10) continue;
+        const double x = (nv[0] * inv) / w, y = (nv[1] * inv) / w;
+        double E[9]; double fn = 0;
+        for (int i = 0; i < 9; i++) {
+            E[i] = ((x * Bs[0][i] + y * Bs[1][i]) + z * Bs[2][i]) + Bs[3][i];
+            fn += E[i] * E[i];
+        }
+        fn = sqrt(fn);
+        if (!(fn > 0)) continue;
+        for (int i = 0; i < 9; i++) Es[9 * count + i] = E[i] / fn;
+        count++;
+    }
+    return count;
+}
+
+DEV int sampson_inlier(const double* E, double x1, double y1, double x2, double y2, float t) {
+    const double Ex0 = (E[0] * x1 + E[1] * y1) + E[2];
+    const double Ex1 = (E[3] * x1 + E[4] * y1) + E[5];
+    const double Ex2 = (E[6] * x1 + E[7] * y1) + E[8];
+    const double Et0 = (E[0] * x2 + E[3] * y2) + E[6];
+    const double Et1 = (E[1] * x2 + E[4] * y2) + E[7];
+    const double x2tEx1 = (x2 * Ex0 + y2 * Ex1) + Ex2;
+    const double a = Ex0 * Ex0, b = Ex1 * Ex1, c = Et0 * Et0, d = Et1 * Et1;
+    const float err = (float)(x2tEx1 * x2tEx1 / (((a + b) + c) + d));
+    return err <= t ? 1 : 0;
+}
+
+// cv::RNG
+struct CvRng {
+    unsigned long long state;
+    DEV unsigned next() { state = (unsigned long long)(unsigned)state * 4164903690ULL + (unsigned)(state >> 32); return (unsigned)state; }
+    DEV int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
+};
+
+struct PoseParams {
+    double fx_inv, cx, cy, thr, prob;
+    unsigned long long seed;
+    int max_iters, adaptive, mcap;
+};
+
+// rstate: [0] niters, [1] maxGood, [2] best hypothesis index (-1 none), [3] best model, [4] next iteration to scan,
+//         [5] special (1 = M==5 shortcut, 2 = M<5), [6] M, [7] iterations run
+#define RS 8
+
+__global__ __launch_bounds__(256) void k_pose_prep(PoseParams P, const float* __restrict__ p1, const float* __restrict__ p2,
+                                                   const int32_t* __restrict__ npts, double* __restrict__ n1, double* __restrict__ n2,
+                                                   int32_t* __restrict__ samples, int32_t* __restrict__ rstate) {
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int M = min(npts[pair], P.mcap);
+    const float* a = p1 + (size_t)pair * P.mcap * 2;
+    const float* b = p2 + (size_t)pair * P.mcap * 2;
+    double* o1 = n1 + (size_t)pair * P.mcap * 2;
+    double* o2 = n2 + (size_t)pair * P.mcap * 2;
+    for (int i = tid; i < M; i += 256) {
+        o1[2 * i] = ((double)a[2 * i] - P.cx) * P.fx_inv; o1[2 * i + 1] = ((double)a[2 * i + 1] - P.cy) * P.fx_inv;
+        o2[2 * i] = ((double)b[2 * i] - P.cx) * P.fx_inv; o2[2 * i + 1] = ((double)b[2 * i + 1] - P.cy) * P.fx_inv;
+    }
+    if (tid == 0) {
+        int32_t* rs = rstate + (size_t)pair * RS;
+        int32_t* sm = samples + (size_t)pair * P.max_iters * 5;
+        rs[1] = 0; rs[2] = -1; rs[3] = 0; rs[4] = 0; rs[6] = M; rs[7] = 0;
+        if (M < 5) { rs[0] = 0; rs[5] = 2; }
+        else if (M == 5) { rs[0] = 1; rs[5] = 1; for (int k = 0; k < 5; k++) sm[k] = k; }
+        else {
+            rs[0] = max(P.max_iters, 1); rs[5] = 0;
+            CvRng rng; rng.state = P.seed ? P.seed : 0xffffffffULL;
+            for (int it = 0; it < P.max_iters; it++) {          // getSubset: 5 distinct, redraw on duplicates
+                int idx[5];
+                for (int i = 0; i < 5; i++) {
+                    for (;;) {
+                        const int v = idx[i] = rng.uniform(0, M);
+                        int j = 0;
+                        for (; j < i; j++) if (v == idx[j]) break;
+                        if (j == i) break;
+                    }
+                }
+                for (int k = 0; k < 5; k++) sm[5 * it + k] = idx[k];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_ransac_hyp(PoseParams P, int h0, const double* __restrict__ n1, const double* __restrict__ n2,
+                                                   const int32_t* __restrict__ samples, const int32_t* __restrict__ rstate,
+                                                   double* __restrict__ models, int32_t* __restrict__ counts) {
+    const int pair = blockIdx.y;
+    const int h = h0 + blockIdx.x * 64 + threadIdx.x;
+    const int32_t* rs = rstate + (size_t)pair * RS;
+    const int niters = rs[0], M = rs[6];
+    if (h0 + (int)blockIdx.x * 64 >= niters) return;               // adaptive stop already below this block
+    const bool active = h < niters && h < max(P.max_iters, 1);
+    const double* a = n1 + (size_t)pair * P.mcap * 2;
+    const double* b = n2 + (size_t)pair * P.mcap * 2;
+    double Es[90];
+    int nm = 0;
+    if (active) {
+        const int32_t* sm = samples + ((size_t)pair * P.max_iters + h) * 5;
+        double s1[10], s2[10];
+        for (int k = 0; k < 5; k++) {
+            const int id = sm[k];
+            s1[2 * k] = a[2 * id]; s1[2 * k + 1] = a[2 * id + 1];
+            s2[2 * k] = b[2 * id]; s2[2 * k + 1] = b[2 * id + 1];
+        }
+        nm = five_point(s1, s2, Es);
+    }
+    if (!active) return;
+    const float t = (float)(P.thr * P.thr);
+    double* mo = models + ((size_t)pair * P.max_iters + h) * 90;
+    int32_t* co = counts + ((size_t)pair * P.max_iters + h) * 10;
+    for (int m = 0; m < 10; m++) {
+        int good = -1;
+        if (m < nm) {
+            good = 0;
+            const double* E = Es + 9 * m;
+            for (int i = 0; i < M; i++) good += sampson_inlier(E, a[2 * i], a[2 * i + 1], b[2 * i], b[2 * i + 1], t);
+            for (int k = 0; k < 9; k++) mo[9 * m + k] = E[k];
+        }
+        co[m] = good;
+    }
+}
+
+DEV int update_num_iters(double p, double ep, int modelPoints, int maxIters) {
+    p = fmax(p, 0.); p = fmin(p, 1.);
+    ep = fmax(ep, 0.); ep = fmin(ep, 1.);
+    double num = fmax(1. - p, DBL_MIN);
+    double denom = 1. - pow(1. - ep, (double)modelPoints);
+    if (denom < DBL_MIN) return 0;
+    num = log(num); denom = log(denom);
+    return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)rint(num / denom);
+}
+
+// replay RANSACPointSetRegistrator::run's loop over hypotheses [rs[4], min(hi, niters))
+__global__ void k_ransac_scan(PoseParams P, int hi, int npairs, const int32_t* __restrict__ counts, int32_t* __restrict__ rstate) {
+    const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= npairs) return;
+    int32_t* rs = rstate + (size_t)pair * RS;
+    if (rs[5] != 0) { if (rs[5] == 1) { rs[2] = 0; rs[3] = 0; rs[1] = 5; rs[7] = 1; rs[4] = 1; } return; }
+    int niters = rs[0], maxGood = rs[1], iter = rs[4];
+    const int M = rs[6];
+    for (; iter < niters && iter < hi; iter++) {
+        const int32_t* co = counts + ((size_t)pair * P.max_iters + iter) * 10;
+        for (int i = 0; i < 10; i++) {
+            const int good = co[i];
+            if (good < 0) break;
+            if (good > max(maxGood, 4)) {
+                rs[2] = iter; rs[3] = i; maxGood = good;
+                if (P.adaptive) niters = update_num_iters(P.prob, (double)(M - good) / M, 5, niters);
+            }
+        }
+    }
+    rs[0] = niters; rs[1] = maxGood; rs[4] = iter; rs[7] = iter;
+}
+
+__device__ void svd3_decompose(const double* E, double* U, double* Vt) {
+    double A[9], V[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double s = 0; for (int k = 0; k < 3; k++) s += E[3 * k + i] * E[3 * k + j];
+        A[3 * i + j] = s;
+    }
+    jacobi_eig(3, A, V);
+    int ord[3] = {0, 1, 2};
+    // sort by descending eigenvalue, ties keep index order
+    for (int i = 0; i < 3; i++) for (int j = i + 1; j < 3; j++) {
+        const bool sw = (A[4 * ord[j]] > A[4 * ord[i]]) || (A[4 * ord[j]] == A[4 * ord[i]] && ord[j] < ord[i]);
+        if (sw) { const int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+    }
+    double v0[3], v1[3], v2[3];
+    for (int k = 0; k < 3; k++) { v0[k] = V[3 * k + ord[0]]; v1[k] = V[3 * k + ord[1]]; }
+    cross3(v0, v1, v2);
+    double u0[3], u1[3], u2[3];
+    for (int r = 0; r < 3; r++) { u0[r] = dot3(E + 3 * r, v0); u1[r] = dot3(E + 3 * r, v1); }
+    const double n0 = sqrt(dot3(u0, u0));
+    for (int r = 0; r < 3; r++) u0[r] /= n0;
+    const double pr = dot3(u0, u1);
+    for (int r = 0; r < 3; r++) u1[r] -= pr * u0[r];
+    const double nn1 = sqrt(dot3(u1, u1));
+    for (int r = 0; r < 3; r++) u1[r] /= nn1;
+    cross3(u0, u1, u2);
+    for (int r = 0; r < 3; r++) { U[3 * r] = u0[r]; U[3 * r + 1] = u1[r]; U[3 * r + 2] = u2[r]; }
+    for (int c = 0; c < 3; c++) { Vt[c] = v0[c]; Vt[3 + c] = v1[c]; Vt[6 + c] = v2[c]; }
+}
+
+DEV void mat3_mul(const double* A, const double* B, double* C) {
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double s = 0; for (int k = 0; k < 3; k++) s += A[3 * i + k] * B[3 * k + j];
+        C[3 * i + j] = s;
+    }
+}
+
+__device__ bool cheirality(const double* R, const double* t, double x1, double y1, double x2, double y2) {
+    const double P[12] = {R[0], R[1], R[2], t[0], R[3], R[4], R[5], t[1], R[6], R[7], R[8], t[2]};
+    double A[16];
+    A[0] = -1; A[1] = 0;  A[2] = x1; A[3] = 0;
+    A[4] = 0;  A[5] = -1; A[6] = y1; A[7] = 0;
+    for (int c = 0; c < 4; c++) { A[8 + c] = x2 * P[8 + c] - P[c]; A[12 + c] = y2 * P[8 + c] - P[4 + c]; }
+    double AtA[16], V[16];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) {
+        double s = 0; for (int k = 0; k < 4; k++) s += A[4 * k + i] * A[4 * k + j];
+        AtA[4 * i + j] = s;
+    }
+    jacobi_eig(4, AtA, V);
+    int mn = 0; for (int i = 1; i < 4; i++) if (AtA[5 * i] < AtA[5 * mn]) mn = i;
+    const double X[4] = {V[mn], V[4 + mn], V[8 + mn], V[12 + mn]};
+    bool ok = (X[2] * X[3]) > 0;
+    const double Xn[3] = {X[0] / X[3], X[1] / X[3], X[2] / X[3]};
+    ok = ok && (Xn[2] < 50.0);
+    const double z2 = ((P[8] * Xn[0] + P[9] * Xn[1]) + P[10] * Xn[2]) + P[11];
+    ok = ok && (z2 > 0) && (z2 < 50.0);
+    return ok;
+}
+
+// block per pair: winner's inlier mask + recoverPose.  do_pose = 0 -> only the mask / E (findEssentialMat)
+__global__ __launch_bounds__(256) void k_pose_final(PoseParams P, const double* __restrict__ n1, const double* __restrict__ n2,
+                                                    const double* __restrict__ models, const int32_t* __restrict__ rstate,
+                                                    const double* __restrict__ E_in, uint8_t* __restrict__ mask_out,
+                                                    PoseOut* __restrict__ out, int do_pose) {
+    __shared__ double sE[9], sR[2][9], sT[3];
+    __shared__ int sgood[4], sinl;
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int32_t* rs = rstate + (size_t)pair * RS;
+    const int M = rs[6];
+    const double* a = n1 + (size_t)pair * P.mcap * 2;
+    const double* b = n2 + (size_t)pair * P.mcap * 2;
+    const bool have = E_in ? true : (rs[2] >= 0);
+    if (tid < 9) sE[tid] = !have ? 0.0 : (E_in ? E_in[(size_t)pair * 9 + tid] : models[((size_t)pair * P.max_iters + rs[2]) * 90 + 9 * rs[3] + tid]);
+    if (tid < 4) sgood[tid] = 0;
+    if (tid == 0) sinl = 0;
+    __syncthreads();
+    const float t = (float)(P.thr * P.thr);
+    if (!E_in) {
+        for (int i = tid; i < M; i += 256) {
+            int f = have ? sampson_inlier(sE, a[2 * i], a[2 * i + 1], b[2 * i], b[2 * i + 1], t) : 0;
+            if (have && rs[5] == 1) f = 1;                         // M == 5: all-ones mask
+            if (mask_out) mask_out[(size_t)pair * P.mcap + i] = (uint8_t)f;
+            if (f) atomicAdd(&sinl, 1);
+        }
+    }
+    if (tid == 0 && do_pose && have) {
+        double U[9], Vt[9]; svd3_decompose(sE, U, Vt);
+        const double W[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1}, Wt[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1};
+        double T[9];
+        mat3_mul(U, W, T); mat3_mul(T, Vt, sR[0]);
+        mat3_mul(U, Wt, T); mat3_mul(T, Vt, sR[1]);
+        sT[0] = U[2]; sT[1] = U[5]; sT[2] = U[8];
+    }
+    __syncthreads();
+    if (do_pose && have) {
+        for (int w = tid; w < 4 * M; w += 256) {
+            const int c = w / M, i = w - c * M;
+            const double tt[3] = {c < 2 ? sT[0] : -sT[0], c < 2 ? sT[1] : -sT[1], c < 2 ? sT[2] : -sT[2]};
+            if (cheirality(sR[c & 1], tt, a[2 * i], a[2 * i + 1], b[2 * i], b[2 * i + 1])) atomicAdd(&sgood[c], 1);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        PoseOut o;
+        for (int i = 0; i < 9; i++) { o.E[i] = sE[i]; o.R[i] = 0; }
+        o.t[0] = o.t[1] = o.t[2] = 0;
+        o.n_inliers = E_in ? 0 : (have ? (rs[5] == 1 ? 5 : rs[1]) : 0);
+        o.iters_run = rs[7]; o.n_points = M; o.n_pose_good = 0;
+        if (do_pose && have) {
+            const int* g = sgood;
+            int sel;
+            if (g[0] >= g[1] && g[0] >= g[2] && g[0] >= g[3]) sel = 0;
+            else if (g[1] >= g[0] && g[1] >= g[2] && g[1] >= g[3]) sel = 1;
+            else if (g[2] >= g[0] && g[2] >= g[1] && g[2] >= g[3]) sel = 2;
+            else sel = 3;
+            for (int i = 0; i < 9; i++) o.R[i] = sR[sel & 1][i];
+            for (int i = 0; i < 3; i++) o.t[i] = sel < 2 ? sT[i] : -sT[i];
+            o.n_pose_good = g[sel];
+        }
+        out[pair] = o;
+    }
+}
+
+// ---- F2FRansac (src/VISystem.cpp:612-769): lane per iteration, shared normal vectors
+__global__ __launch_bounds__(256) void k_f2f(const vis_keypoint* __restrict__ pts1, const vis_keypoint* __restrict__ pts2, int m,
+                                             float fx, float fy, float cx, float cy, const float* __restrict__ rot,
+                                             const int32_t* __restrict__ sample_idx, int iters, double threshold,
+                                             double* __restrict__ nv, float* __restrict__ counts) {
+    // phase 1 (grid-stride over points) is done by a first launch with iters == 0
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (iters == 0) {
+        if (gid >= m) return;
+        const float u1 = pts1[gid].x, v1 = pts1[gid].y, u2 = pts2[gid].x, v2 = pts2[gid].y;
+        double a[3] = {(double)((u1 - cx) / fx), (double)((v1 - cy) / fy), 1.0};
+        double b[3] = {(double)((u2 - cx) / fx), (double)((v2 - cy) / fy), 1.0};
+        const double na = sqrt((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
+        const double nb = sqrt((b[0] * b[0] + b[1] * b[1]) + b[2] * b[2]);
+        for (int k = 0; k < 3; k++) { a[k] /= na; b[k] /= nb; }
+        double Rm[9]; for (int i = 0; i < 9; i++) Rm[i] = (double)rot[i];
+        const double rb[3] = {(Rm[0] * b[0] + Rm[1] * b[1]) + Rm[2] * b[2], (Rm[3] * b[0] + Rm[4] * b[1]) + Rm[5] * b[2],
+                              (Rm[6] * b[0] + Rm[7] * b[1]) + Rm[8] * b[2]};
+        cross3(a, rb, nv + 3 * (size_t)gid);
+        return;
+    }
+    if (gid >= iters) return;
+    const int i1 = sample_idx[2 * gid], i2 = sample_idx[2 * gid + 1];
+    double d[3]; cross3(nv + 3 * (size_t)i1, nv + 3 * (size_t)i2, d);
+    float count = -1.f;                                            // -1: degenerate sample (skipped by the reference)
+    if (d[0] != 0.0 || d[1] != 0.0 || d[2] != 0.0) {
+        const double dn = sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+        for (int k = 0; k < 3; k++) d[k] /= dn;
+        count = 0.f;
+        for (int i = 0; i < m; i++) {
+            const double error = -1000.0 / log10(fabs(dot3(d, nv + 3 * (size_t)i)));
+            if (error < threshold) count += 1.f;
+        }
+    }
+    counts[4 * (size_t)gid] = count;
+    counts[4 * (size_t)gid + 1] = (float)d[0]; counts[4 * (size_t)gid + 2] = (float)d[1]; counts[4 * (size_t)gid + 3] = (float)d[2];
+}
+
+// ------------------------------------------------------------------------------------------------
+static PoseParams make_pose_params(const vis_ctx* ctx, int max_iters, int mcap) {
+    PoseParams P;
+    P.fx_inv = 1. / ctx->p.fx; P.cx = ctx->p.cx; P.cy = ctx->p.cy;
+    P.thr = ctx->p.ransac_threshold / ctx->p.fx;        // findEssentialMat: threshold /= focal
+    P.prob = ctx->p.ransac_prob; P.seed = ctx->p.ransac_seed;
+    P.max_iters = max_iters; P.adaptive = ctx->p.ransac_adaptive; P.mcap = mcap;
+    return P;
+}
+
+// generic driver used by the batch path and the host-pointer entry points.
+// d_p1/d_p2: npairs x mcap x 2 floats; d_npts: npairs
+int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p1, const float* d_p2, const int32_t* d_npts,
+             double* d_n1, double* d_n2, int32_t* d_samples, double* d_models, int32_t* d_counts, int32_t* d_rstate,
+             const double* d_E_in, uint8_t* d_mask, PoseOut* d_pose, int do_ransac, int do_pose) {
+    hipStream_t st = ctx->stream;
+    const PoseParams P = make_pose_params(ctx, max_iters, mcap);
+    hipLaunchKernelGGL(k_pose_prep, dim3(npairs), dim3(256), 0, st, P, d_p1, d_p2, d_npts, d_n1, d_n2, d_samples, d_rstate);
+    if (do_ransac) {
+        const int first = std::min(64, std::max(max_iters, 1));
+        hipLaunchKernelGGL(k_ransac_hyp, dim3(1, npairs), dim3(64), 0, st, P, 0, d_n1, d_n2, d_samples, d_rstate, d_models, d_counts);
+        hipLaunchKernelGGL(k_ransac_scan, dim3((npairs + 63) / 64), dim3(64), 0, st, P, first, npairs, d_counts, d_rstate);
+        if (max_iters > first) {
+            hipLaunchKernelGGL(k_ransac_hyp, dim3((max_iters - first + 63) / 64, npairs), dim3(64), 0, st, P, first, d_n1, d_n2,
+                               d_samples, d_rstate, d_models, d_counts);
+            hipLaunchKernelGGL(k_ransac_scan, dim3((npairs + 63) / 64), dim3(64), 0, st, P, max_iters, npairs, d_counts, d_rstate);
+        }
+    }
+    hipLaunchKernelGGL(k_pose_final, dim3(npairs), dim3(256), 0, st, P, d_n1, d_n2, d_models, d_rstate, d_E_in, d_mask, d_pose, do_pose);
+    HIPCHK(ctx, hipGetLastError());
+    return VIS_OK;
+}
+
+int f2f_run(vis_ctx* ctx, const vis_keypoint* d_pts1, const vis_keypoint* d_pts2, int m, const float* d_rot,
+            const int32_t* d_idx, int iters, double* d_nv, float* d_counts) {
+    hipStream_t st = ctx->stream;
+    const float fx = (float)ctx->p.fx, fy = (float)ctx->p.fy, cx = (float)ctx->p.cx, cy = (float)ctx->p.cy;
+    hipLaunchKernelGGL(k_f2f, dim3((m + 255) / 256), dim3(256), 0, st, d_pts1, d_pts2, m, fx, fy, cx, cy, d_rot, d_idx, 0,
+                       ctx->p.f2f_threshold, d_nv, d_counts);
+    if (iters > 0)
+        hipLaunchKernelGGL(k_f2f, dim3((iters + 255) / 256), dim3(256), 0, st, d_pts1, d_pts2, m, fx, fy, cx, cy, d_rot, d_idx, iters,
+                           ctx->p.f2f_threshold, d_nv, d_counts);
+    HIPCHK(ctx, hipGetLastError());
+    return VIS_OK;
+}

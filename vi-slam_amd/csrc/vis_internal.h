@@ -68,6 +68,10 @@ struct Plan {
     float* d_hf = nullptr;                   // root band limits (float accumulation on host)
     float* d_wf = nullptr;
     // pose
+    double* d_n1 = nullptr;                  // npairs x root^2 x 2 normalised points
+    double* d_n2 = nullptr;
+    uint8_t* d_mask = nullptr;               // npairs x root^2 inlier mask of the winning E
+    int32_t* d_pair_q_noprev = nullptr;      // same as d_pair_q with pair 0 disabled
     int32_t* d_samples = nullptr;            // npairs x max_iters x 5
     double* d_models = nullptr;              // npairs x max_iters x 10 x 9
     int32_t* d_counts = nullptr;             // npairs x max_iters x 10  (-1 = no model)
@@ -76,6 +80,8 @@ struct Plan {
     int max_iters = 0;
     bool have_prev = false;                  // batch: record 0 holds the previous batch's last frame
     int last_n = 0;                          // frames in the last batch
+    int carry_from = 0;                      // record to copy into record 0 at the next run (0 = none)
+    bool pair0_valid = false;                // last run: frame 0 had a predecessor
 };
 
 struct vis_ctx {
@@ -116,5 +122,11 @@ int launch_match(vis_ctx* ctx, Plan* pl, int npairs);
 int launch_filter(vis_ctx* ctx, Plan* pl, int npairs);
 int launch_pose(vis_ctx* ctx, Plan* pl, int npairs);
 int launch_half_pyramid(vis_ctx* ctx, const uint8_t* d_img, int w, int h, int stride, uint8_t* d_out[5]);
+int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p1, const float* d_p2, const int32_t* d_npts,
+             double* d_n1, double* d_n2, int32_t* d_samples, double* d_models, int32_t* d_counts, int32_t* d_rstate,
+             const double* d_E_in, uint8_t* d_mask, PoseOut* d_pose, int do_ransac, int do_pose);
+int f2f_run(vis_ctx* ctx, const vis_keypoint* d_pts1, const vis_keypoint* d_pts2, int m, const float* d_rot,
+            const int32_t* d_idx, int iters, double* d_nv, float* d_counts);
+#define VIS_RSTATE_WORDS 8
 
 #endif

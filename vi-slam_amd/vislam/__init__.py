@@ -1,0 +1,360 @@
+"""vislam -- thin ctypes binding over the C ABI of libvislam_hip.so (include/vislam_hip.h).
+
+This is plumbing for tests and bench.py; the product is the shared library.  The classes here
+mirror the reference's surface for the hot path (names, argument meaning, error behaviour):
+
+  Context.orb_detect_compute   <-> CameraGPU::detectAndComputeGPUFeatures  (src/CameraGPU.cpp:71-117)
+  Context.bf_knn2_hamming      <-> MatcherGPU::computeGPUMatches           (src/MatcherGPU.cpp:44-66)
+  Context.good_matches         <-> Matcher::computeBestMatches             (src/Matcher.cpp:353-367)
+  Context.essential_ransac / recover_pose <-> VISystem::EstimatePoseFeaturesRansac (src/VISystem.cpp:1679-1701)
+  Context.f2f_ransac           <-> VISystem::F2FRansac                      (src/VISystem.cpp:612-769)
+
+There is NO CPU fallback: if the HIP library is missing, importing this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+# PyTorch (plumbing for device memory / streams / torch.distributed in tests and bench.py) bundles its
+# own libamdhip64.so.7.  Two HIP runtimes in one process cannot both own the GPU, so when torch is
+# installed it is imported FIRST: the loader then resolves this library's libamdhip64.so.7 dependency
+# to the copy that is already mapped.  The library itself has no torch dependency.
+try:  # pragma: no cover
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    torch = None
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "..", "lib", "libvislam_hip.so")
+
+
+class VisError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        super().__init__(f"{where}: error {code} ({_strerror(code)}) {detail}")
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("nfeatures", C.c_int32), ("nlevels", C.c_int32), ("scale_factor", C.c_float),
+        ("edge_threshold", C.c_int32), ("patch_size", C.c_int32), ("fast_threshold", C.c_int32),
+        ("ratio", C.c_float), ("n_cells", C.c_int32), ("w_size", C.c_int32), ("h_size", C.c_int32),
+        ("sym_mode", C.c_int32),
+        ("ransac_prob", C.c_double), ("ransac_threshold", C.c_double),
+        ("ransac_max_iters", C.c_int32), ("ransac_adaptive", C.c_int32), ("ransac_seed", C.c_uint64),
+        ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+        ("f2f_iters", C.c_int32), ("f2f_threshold", C.c_double),
+    ]
+
+    def copy(self):
+        p = Params()
+        C.memmove(C.byref(p), C.byref(self), C.sizeof(Params))
+        return p
+
+
+class Timings(C.Structure):
+    _fields_ = [("ms_total", C.c_float), ("ms_pyramid", C.c_float), ("ms_fast", C.c_float),
+                ("ms_select", C.c_float), ("ms_describe", C.c_float), ("ms_knn", C.c_float),
+                ("ms_filter", C.c_float), ("ms_pose", C.c_float),
+                ("launches_fast", C.c_int32), ("launches_total", C.c_int32)]
+
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+DMATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
+assert KEYPOINT_DTYPE.itemsize == 28 and DMATCH_DTYPE.itemsize == 16
+
+SYM_REFERENCE_EFFECTIVE, SYM_INTENDED = 0, 1
+STAGE_DETECT, STAGE_MATCH, STAGE_POSE, STAGE_ALL = 1, 2, 4, 7
+
+# every symbol include/vislam_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "vis_version", "vis_strerror", "vis_device_count", "vis_create", "vis_destroy", "vis_last_error",
+    "vis_default_params", "vis_set_params", "vis_get_params", "vis_set_stream", "vis_last_timings",
+    "vis_level_geometry", "vis_camera_update", "vis_orb_detect_compute", "vis_bf_knn2_hamming",
+    "vis_bf_knn2_hamming_host", "vis_good_matches", "vis_good_matches_host", "vis_essential_ransac",
+    "vis_recover_pose", "vis_f2f_ransac", "vis_batch_plan", "vis_batch_reset", "vis_batch_run",
+    "vis_batch_sync", "vis_batch_get_keypoints", "vis_batch_get_knn", "vis_batch_get_matches",
+    "vis_batch_get_pose", "vis_batch_status", "vis_synth_canvas", "vis_synth_frame",
+]
+
+
+def _load():
+    path = os.path.abspath(LIB_PATH)
+    if not os.path.exists(path):
+        raise ImportError(f"libvislam_hip.so not built at {path}: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)")
+    lib = C.CDLL(path)
+    lib.vis_version.restype = C.c_char_p
+    lib.vis_strerror.restype = C.c_char_p
+    lib.vis_strerror.argtypes = [C.c_int]
+    lib.vis_last_error.restype = C.c_char_p
+    lib.vis_last_error.argtypes = [C.c_void_p]
+    lib.vis_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.vis_destroy.argtypes = [C.c_void_p]
+    lib.vis_destroy.restype = None
+    lib.vis_default_params.argtypes = [C.POINTER(Params)]
+    lib.vis_default_params.restype = None
+    lib.vis_set_params.argtypes = [C.c_void_p, C.POINTER(Params)]
+    lib.vis_get_params.argtypes = [C.c_void_p, C.POINTER(Params)]
+    lib.vis_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.vis_last_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
+    vp, ci, ip = C.c_void_p, C.c_int, C.POINTER(C.c_int)
+    lib.vis_level_geometry.argtypes = [vp, ci, ci, vp, vp, vp, vp]
+    lib.vis_camera_update.argtypes = [vp, vp, ci, ci, ci, C.POINTER(C.c_void_p)]
+    lib.vis_orb_detect_compute.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, ci, ip]
+    lib.vis_bf_knn2_hamming.argtypes = [vp, ci, ci, vp, vp]
+    lib.vis_bf_knn2_hamming_host.argtypes = [vp, vp, ci, vp, ci, vp, vp]
+    lib.vis_good_matches.argtypes = [vp, ci, ci, vp, ci, ip, vp, ci, ip]
+    lib.vis_good_matches_host.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp, ci, ip, vp, ci, ip]
+    lib.vis_essential_ransac.argtypes = [vp, vp, vp, ci, vp, vp, ip, ip]
+    lib.vis_recover_pose.argtypes = [vp, vp, vp, vp, ci, vp, vp, ip]
+    lib.vis_f2f_ransac.argtypes = [vp, vp, vp, ci, vp, vp, ci, C.c_float, vp, ip]
+    lib.vis_batch_plan.argtypes = [vp, ci, ci, ci, ci]
+    lib.vis_batch_reset.argtypes = [vp]
+    lib.vis_batch_run.argtypes = [vp, vp, ci, ci]
+    lib.vis_batch_sync.argtypes = [vp]
+    lib.vis_batch_get_keypoints.argtypes = [vp, ci, vp, vp, ci, ip]
+    lib.vis_batch_get_knn.argtypes = [vp, ci, vp, ci, ip, vp, ci, ip]
+    lib.vis_batch_get_matches.argtypes = [vp, ci, vp, ci, ip, ip]
+    lib.vis_batch_get_pose.argtypes = [vp, ci, vp, vp, vp, ip, ip, ip]
+    lib.vis_batch_status.argtypes = [vp, ip]
+    lib.vis_synth_canvas.argtypes = [vp, ci, C.c_uint64]
+    lib.vis_synth_frame.argtypes = [vp, ci, C.c_uint64, ci, ci, ci, vp, ci]
+    return lib
+
+
+lib = _load()
+
+
+def _strerror(code):
+    return lib.vis_strerror(int(code)).decode()
+
+
+def version():
+    return lib.vis_version().decode()
+
+
+def device_count():
+    return int(lib.vis_device_count())
+
+
+def default_params():
+    p = Params()
+    lib.vis_default_params(C.byref(p))
+    return p
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ---- synthetic stream (host-side utility of the library; integer-only, bit-reproducible) ----------
+def synth_canvas(dim=4096, seed=0xE0C00001):
+    cv = np.empty((dim, dim), np.uint8)
+    rc = lib.vis_synth_canvas(_ptr(cv), dim, C.c_uint64(seed))
+    if rc:
+        raise VisError(rc, "vis_synth_canvas")
+    return cv
+
+
+def synth_frame(canvas, t, w=752, h=480, seed=0xE0C00001, out=None):
+    if out is None:
+        out = np.empty((h, w), np.uint8)
+    rc = lib.vis_synth_frame(_ptr(canvas), canvas.shape[0], C.c_uint64(seed), int(t), w, h, _ptr(out), out.strides[0])
+    if rc:
+        raise VisError(rc, "vis_synth_frame")
+    return out
+
+
+class Context:
+    """One device context (not thread-safe), like one CameraGPU + MatcherGPU pair."""
+
+    def __init__(self, device=0, params=None):
+        self._h = C.c_void_p()
+        rc = lib.vis_create(int(device), C.byref(self._h))
+        if rc:
+            self._h = None
+            raise VisError(rc, "vis_create")
+        self.params = default_params()
+        if params is not None:
+            self.set_params(params)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.vis_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, where):
+        if rc:
+            raise VisError(rc, where, lib.vis_last_error(self._h).decode())
+
+    def set_params(self, p):
+        self._chk(lib.vis_set_params(self._h, C.byref(p)), "vis_set_params")
+        self.params = p.copy()
+
+    def set_stream(self, raw_stream):
+        self._chk(lib.vis_set_stream(self._h, C.c_void_p(raw_stream)), "vis_set_stream")
+
+    def timings(self):
+        t = Timings()
+        self._chk(lib.vis_last_timings(self._h, C.byref(t)), "vis_last_timings")
+        return t
+
+    def level_geometry(self, w, h):
+        L = self.params.nlevels
+        ws, hs, q = (np.zeros(L, np.int32) for _ in range(3))
+        sc = np.zeros(L, np.float32)
+        self._chk(lib.vis_level_geometry(self._h, w, h, _ptr(ws), _ptr(hs), _ptr(sc), _ptr(q)), "vis_level_geometry")
+        return ws, hs, sc, q
+
+    # -- Camera::Update --------------------------------------------------------------------------------
+    def camera_update(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        levels = [np.empty((h >> l, w >> l), np.uint8) for l in range(5)]
+        arr = (C.c_void_p * 5)(*[l.ctypes.data for l in levels])
+        self._chk(lib.vis_camera_update(self._h, _ptr(img), w, h, img.strides[0], arr), "vis_camera_update")
+        return levels
+
+    # -- CameraGPU::detectAndComputeGPUFeatures ---------------------------------------------------------
+    def orb_detect_compute(self, img, slot=0, cap=None):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        if cap is None:
+            cap = 2 * self.params.nfeatures + 1024
+        kps = np.zeros(cap, KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        self._chk(lib.vis_orb_detect_compute(self._h, _ptr(img), w, h, img.strides[0], slot, _ptr(kps), _ptr(desc), cap,
+                                             C.byref(n)), "vis_orb_detect_compute")
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    # -- MatcherGPU::computeGPUMatches ---------------------------------------------------------------------
+    def bf_knn2_hamming(self, slot_q, slot_t, nq, nt):
+        o12 = np.zeros((nq, 2), DMATCH_DTYPE)
+        o21 = np.zeros((nt, 2), DMATCH_DTYPE)
+        self._chk(lib.vis_bf_knn2_hamming(self._h, slot_q, slot_t, _ptr(o12), _ptr(o21)), "vis_bf_knn2_hamming")
+        return o12, o21
+
+    def bf_knn2_hamming_host(self, d1, d2):
+        d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 32)
+        o12 = np.zeros((len(d1), 2), DMATCH_DTYPE)
+        o21 = np.zeros((len(d2), 2), DMATCH_DTYPE)
+        self._chk(lib.vis_bf_knn2_hamming_host(self._h, _ptr(d1), len(d1), _ptr(d2), len(d2), _ptr(o12), _ptr(o21)),
+                  "vis_bf_knn2_hamming_host")
+        return o12, o21
+
+    # -- Matcher::computeBestMatches ----------------------------------------------------------------------
+    def good_matches(self, slot_prev, slot_cur, sym_cap=65536):
+        root2 = 1024
+        good = np.zeros(root2, DMATCH_DTYPE)
+        sym = np.zeros(sym_cap, DMATCH_DTYPE)
+        ng, ns = C.c_int(0), C.c_int(0)
+        self._chk(lib.vis_good_matches(self._h, slot_prev, slot_cur, _ptr(good), root2, C.byref(ng), _ptr(sym), sym_cap,
+                                       C.byref(ns)), "vis_good_matches")
+        return good[:ng.value].copy(), sym[:ns.value].copy()
+
+    def good_matches_host(self, kps1, kps2, knn12, knn21):
+        kps1 = np.ascontiguousarray(kps1, KEYPOINT_DTYPE)
+        kps2 = np.ascontiguousarray(kps2, KEYPOINT_DTYPE)
+        knn12 = np.ascontiguousarray(knn12, DMATCH_DTYPE)
+        knn21 = np.ascontiguousarray(knn21, DMATCH_DTYPE)
+        good = np.zeros(1024, DMATCH_DTYPE)
+        sym = np.zeros(max(len(kps1), 1), DMATCH_DTYPE)
+        ng, ns = C.c_int(0), C.c_int(0)
+        self._chk(lib.vis_good_matches_host(self._h, _ptr(kps1), len(kps1), _ptr(kps2), len(kps2), _ptr(knn12), _ptr(knn21),
+                                            _ptr(good), 1024, C.byref(ng), _ptr(sym), len(sym), C.byref(ns)),
+                  "vis_good_matches_host")
+        return good[:ng.value].copy(), sym[:ns.value].copy()
+
+    # -- findEssentialMat / recoverPose --------------------------------------------------------------------
+    def essential_ransac(self, p1, p2):
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+        p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+        E = np.zeros(9, np.float64)
+        mask = np.zeros(max(len(p1), 1), np.uint8)
+        ni, it = C.c_int(0), C.c_int(0)
+        self._chk(lib.vis_essential_ransac(self._h, _ptr(p1), _ptr(p2), len(p1), _ptr(E), _ptr(mask), C.byref(ni), C.byref(it)),
+                  "vis_essential_ransac")
+        return E.reshape(3, 3), mask[:len(p1)], ni.value, it.value
+
+    def recover_pose(self, E, p1, p2):
+        E = np.ascontiguousarray(E, np.float64).reshape(9)
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+        p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+        R = np.zeros(9, np.float64)
+        t = np.zeros(3, np.float64)
+        ng = C.c_int(0)
+        self._chk(lib.vis_recover_pose(self._h, _ptr(E), _ptr(p1), _ptr(p2), len(p1), _ptr(R), _ptr(t), C.byref(ng)),
+                  "vis_recover_pose")
+        return R.reshape(3, 3), t, ng.value
+
+    def f2f_ransac(self, pts1, pts2, rot, sample_idx, scale):
+        pts1 = np.ascontiguousarray(pts1, KEYPOINT_DTYPE)
+        pts2 = np.ascontiguousarray(pts2, KEYPOINT_DTYPE)
+        rot = np.ascontiguousarray(rot, np.float32).reshape(9)
+        idx = np.ascontiguousarray(sample_idx, np.int32).reshape(-1)
+        out = np.zeros(3, np.float32)
+        cm = C.c_int(0)
+        self._chk(lib.vis_f2f_ransac(self._h, _ptr(pts1), _ptr(pts2), len(pts1), _ptr(rot), _ptr(idx), len(idx) // 2,
+                                     C.c_float(scale), _ptr(out), C.byref(cm)), "vis_f2f_ransac")
+        return out, cm.value
+
+    # -- batched stream path ----------------------------------------------------------------------------------
+    def batch_plan(self, w, h, stride, max_frames):
+        self._chk(lib.vis_batch_plan(self._h, w, h, stride, max_frames), "vis_batch_plan")
+
+    def batch_reset(self):
+        self._chk(lib.vis_batch_reset(self._h), "vis_batch_reset")
+
+    def batch_run(self, dev_ptr, n_frames, stages=STAGE_ALL):
+        self._chk(lib.vis_batch_run(self._h, C.c_void_p(dev_ptr), n_frames, stages), "vis_batch_run")
+
+    def batch_sync(self):
+        self._chk(lib.vis_batch_sync(self._h), "vis_batch_sync")
+
+    def batch_status(self):
+        f = C.c_int(0)
+        self._chk(lib.vis_batch_status(self._h, C.byref(f)), "vis_batch_status")
+        return f.value
+
+    def batch_keypoints(self, frame, cap=None):
+        if cap is None:
+            cap = 2 * self.params.nfeatures + 1024
+        kps = np.zeros(cap, KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        self._chk(lib.vis_batch_get_keypoints(self._h, frame, _ptr(kps), _ptr(desc), cap, C.byref(n)), "vis_batch_get_keypoints")
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def batch_knn(self, frame, cap=None):
+        if cap is None:
+            cap = 2 * self.params.nfeatures + 1024
+        o12 = np.zeros((cap, 2), DMATCH_DTYPE)
+        o21 = np.zeros((cap, 2), DMATCH_DTYPE)
+        n12, n21 = C.c_int(0), C.c_int(0)
+        self._chk(lib.vis_batch_get_knn(self._h, frame, _ptr(o12), 2 * cap, C.byref(n12), _ptr(o21), 2 * cap, C.byref(n21)),
+                  "vis_batch_get_knn")
+        return o12[:n12.value].copy(), o21[:n21.value].copy()
+
+    def batch_matches(self, frame):
+        good = np.zeros(1024, DMATCH_DTYPE)
+        ng, ns = C.c_int(0), C.c_int(0)
+        self._chk(lib.vis_batch_get_matches(self._h, frame, _ptr(good), 1024, C.byref(ng), C.byref(ns)), "vis_batch_get_matches")
+        return good[:ng.value].copy(), ns.value
+
+    def batch_pose(self, frame):
+        E, R, t = np.zeros(9), np.zeros(9), np.zeros(3)
+        ni, ng, it = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._chk(lib.vis_batch_get_pose(self._h, frame, _ptr(E), _ptr(R), _ptr(t), C.byref(ni), C.byref(ng), C.byref(it)),
+                  "vis_batch_get_pose")
+        return dict(E=E.reshape(3, 3), R=R.reshape(3, 3), t=t, n_inliers=ni.value, n_pose_good=ng.value, iters_run=it.value)
