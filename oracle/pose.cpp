@@ -11,7 +11,7 @@
 // epipolar system, 10 cubic constraints, Gauss-Jordan to a 3x3 polynomial matrix B(z), det B = 0 as a
 // degree-10 polynomial, back-substitution) with a documented, deterministic realisation:
 //   null space  : Householder QR of Q^T (orthonormal basis X,Y,Z,W)
-//   real roots  : Sturm-sequence isolation + bisection, roots taken in ascending order
+//   real roots  : derivative-interlacing bisection (Rolle), roots taken in ascending order
 //   (x,y) from z: largest-norm row cross product of B(z)
 // RANSAC (cv::RANSACPointSetRegistrator::run semantics, cv::RNG sample stream, adaptive iteration
 // count, float Sampson error vs float threshold) and recoverPose (4 candidates, DLT triangulation,
@@ -106,48 +106,16 @@ static double poly_eval(const double* c, int deg, double x) {
     return r;
 }
 
-// Sturm chain of p (degree deg, c[deg] != 0).  chain[k] has degree cdeg[k].
-struct Sturm { double c[12][11]; int deg[12]; int n; };
-static void sturm_build(const double* p, int deg, Sturm& S) {
-    S.n = 0;
-    for (int i = 0; i <= deg; i++) S.c[0][i] = p[i];
-    S.deg[0] = deg; S.n = 1;
-    if (deg == 0) return;
-    for (int i = 1; i <= deg; i++) S.c[1][i - 1] = p[i] * i;
-    S.deg[1] = deg - 1; S.n = 2;
-    while (S.deg[S.n - 1] > 0) {
-        const double* a = S.c[S.n - 2]; int da = S.deg[S.n - 2];
-        const double* b = S.c[S.n - 1]; int db = S.deg[S.n - 1];
-        double r[11];
-        for (int i = 0; i <= da; i++) r[i] = a[i];
-        for (int k = da - db; k >= 0; k--) {             // polynomial long division
-            double f = r[db + k] / b[db];
-            for (int i = 0; i <= db; i++) r[i + k] -= f * b[i];
-            r[db + k] = 0.0;
-        }
-        int dr = db - 1;
-        double mx = 0; for (int i = 0; i <= dr; i++) mx = std::max(mx, std::fabs(r[i]));
-        double ma = 0; for (int i = 0; i <= da; i++) ma = std::max(ma, std::fabs(a[i]));
-        if (mx <= 1e-14 * ma) break;                     // remainder vanished: repeated roots
-        while (dr > 0 && std::fabs(r[dr]) <= 1e-14 * mx) dr--;
-        for (int i = 0; i <= dr; i++) S.c[S.n][i] = -r[i];
-        S.deg[S.n] = dr; S.n++;
-        if (S.n >= 12) break;
-    }
-}
-static int sturm_count(const Sturm& S, double x) {
-    int changes = 0, last = 0;
-    for (int k = 0; k < S.n; k++) {
-        double v = poly_eval(S.c[k], S.deg[k], x);
-        int s = v > 0 ? 1 : (v < 0 ? -1 : 0);
-        if (s == 0) continue;
-        if (last != 0 && s != last) changes++;
-        last = s;
-    }
-    return changes;
-}
+// Real roots of c[0..deg] in ascending order (returns count <= deg).
+// Method ("derivative interlacing"): by Rolle's theorem the roots of q' separate the roots of q, so the
+// real roots of the k-th derivative tower p^(deg-1), p^(deg-2), ..., p are found level by level: at each
+// level the previous level's roots (plus the Cauchy bound +-B) cut the line into intervals that hold at
+// most one root each; an interval with a sign change is bisected.  Inner levels only need to separate
+// (40 halvings); the last level bisects until the interval cannot shrink in double precision.
+// Control flow is data-independent apart from the sign tests -- the HIP kernel runs the same steps on 64
+// hypotheses in lock step.  Even-multiplicity roots (no sign change) are not reported.
+static const int BISECT_INNER = 40, BISECT_FINAL = 200;
 
-// real roots of c[0..deg] in ascending order; returns count (<= deg)
 static int real_roots(const double* cin, int deg, double* roots) {
     double c[11]; double mx = 0;
     for (int i = 0; i <= deg; i++) mx = std::max(mx, std::fabs(cin[i]));
@@ -155,53 +123,38 @@ static int real_roots(const double* cin, int deg, double* roots) {
     for (int i = 0; i <= deg; i++) c[i] = cin[i] / mx;
     while (deg > 0 && std::fabs(c[deg]) < 1e-15) deg--;
     if (deg == 0) return 0;
-    Sturm S; sturm_build(c, deg, S);
     double B = 0;
     for (int i = 0; i < deg; i++) B = std::max(B, std::fabs(c[i] / c[deg]));
     B += 1.0;
-    struct Iv { double lo, hi; int nlo, nhi; };
-    Iv stack[96]; int sp = 0;
-    int nlo = sturm_count(S, -B), nhi = sturm_count(S, B);
-    int nroots = 0;
-    if (nlo - nhi <= 0) return 0;
-    stack[sp++] = Iv{-B, B, nlo, nhi};
-    // depth-first, always expanding the LEFT child last-pushed-first so roots come out ascending
-    while (sp > 0 && nroots < deg) {
-        Iv iv = stack[--sp];
-        int cnt = iv.nlo - iv.nhi;
-        if (cnt <= 0) continue;
-        double mid = 0.5 * (iv.lo + iv.hi);
-        bool tiny = (iv.hi - iv.lo) <= 1e-13 * B || mid <= iv.lo || mid >= iv.hi;
-        if (cnt == 1 || tiny) {
-            double lo = iv.lo, hi = iv.hi;
-            double flo = poly_eval(c, deg, lo), fhi = poly_eval(c, deg, hi);
-            if (!tiny && ((flo < 0) != (fhi < 0))) {
-                for (int it = 0; it < 200; it++) {       // plain bisection on the sign of p
-                    double m = 0.5 * (lo + hi);
-                    if (m <= lo || m >= hi) break;
-                    double fm = poly_eval(c, deg, m);
-                    if ((fm < 0) == (flo < 0)) { lo = m; flo = fm; } else { hi = m; fhi = fm; }
-                }
-                roots[nroots++] = 0.5 * (lo + hi);
-            } else if (!tiny) {
-                // exactly one distinct root but no sign change at the ends (even multiplicity or a
-                // root sitting on an end point): keep halving with Sturm counts
-                if (sp + 2 <= 96) {
-                    int nm = sturm_count(S, mid);
-                    stack[sp++] = Iv{mid, iv.hi, nm, iv.nhi};
-                    stack[sp++] = Iv{iv.lo, mid, iv.nlo, nm};
-                }
-            } else {
-                roots[nroots++] = mid;                    // cluster narrower than resolution
-            }
-            continue;
+    double prev[11]; int nprev = 0;
+    for (int d = 1; d <= deg; d++) {
+        const int k = deg - d;                       // q = k-th derivative of p, degree d
+        double q[11];
+        for (int i = 0; i <= d; i++) {
+            double f = 1.0;
+            for (int j = 0; j < k; j++) f *= (double)(i + k - j);
+            q[i] = c[i + k] * f;
         }
-        if (sp + 2 > 96) { roots[nroots++] = mid; continue; }
-        int nm = sturm_count(S, mid);
-        stack[sp++] = Iv{mid, iv.hi, nm, iv.nhi};
-        stack[sp++] = Iv{iv.lo, mid, iv.nlo, nm};
+        double cur[11]; int ncur = 0;
+        for (int j = 0; j <= nprev; j++) {
+            double lo = j == 0 ? -B : prev[j - 1];
+            double hi = j == nprev ? B : prev[j];
+            double flo = poly_eval(q, d, lo), fhi = poly_eval(q, d, hi);
+            if ((flo < 0) == (fhi < 0)) continue;    // no sign change: no (odd) root here
+            const int nit = d == deg ? BISECT_FINAL : BISECT_INNER;
+            for (int it = 0; it < nit; it++) {
+                const double m = 0.5 * (lo + hi);
+                if (m <= lo || m >= hi) break;
+                const double fm = poly_eval(q, d, m);
+                if ((fm < 0) == (flo < 0)) lo = m; else hi = m;
+            }
+            cur[ncur++] = 0.5 * (lo + hi);
+        }
+        nprev = ncur;
+        for (int j = 0; j < ncur; j++) prev[j] = cur[j];
     }
-    return nroots;
+    for (int j = 0; j < nprev; j++) roots[j] = prev[j];
+    return nprev;
 }
 
 // ---------------------------------------------------------------------------- five-point solver

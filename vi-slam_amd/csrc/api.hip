@@ -83,6 +83,7 @@ extern "C" void vis_destroy(vis_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     plan_destroy(ctx->single); plan_destroy(ctx->batch);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_sample_table) (void)hipFree(ctx->d_sample_table);
     for (int i = 0; i < 10; i++) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -225,7 +226,39 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
     DALLOC(pl->d_rstate, (size_t)npairs * VIS_RSTATE_WORDS);
     DALLOC(pl->d_pose, npairs);
     HIPCHK(ctx, hipMemset(pl->d_pose, 0, (size_t)npairs * sizeof(PoseOut)));
+    { int rc2 = vis_build_sample_table(ctx, ncell); if (rc2) { plan_destroy(pl); return rc2; } }
     *out = pl;
+    return VIS_OK;
+}
+
+// cv::RNG((uint64)seed) + getSubset replayed on the host for every M in [6, max_m]: the RANSAC sample
+// stream depends only on (seed, M), so the per-pair sequential RNG walk is replaced by a table row.
+int vis_build_sample_table(vis_ctx* ctx, int max_m) {
+    const int iters = ctx->p.ransac_max_iters;
+    if (ctx->d_sample_table && ctx->sample_max_m >= max_m && ctx->sample_iters == iters && ctx->sample_seed == ctx->p.ransac_seed) return VIS_OK;
+    if (ctx->d_sample_table) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->d_sample_table); ctx->d_sample_table = nullptr; ctx->sample_max_m = 0; }
+    if (max_m < 6 || (size_t)(max_m - 5) * iters * 5 * 4 > ((size_t)256 << 20)) return VIS_OK;     // no table: device replay
+    std::vector<int32_t> tab((size_t)(max_m - 5) * iters * 5);
+    for (int M = 6; M <= max_m; M++) {
+        unsigned long long state = ctx->p.ransac_seed ? ctx->p.ransac_seed : 0xffffffffULL;
+        int32_t* dst = tab.data() + (size_t)(M - 6) * iters * 5;
+        for (int it = 0; it < iters; it++) {
+            int idx[5];
+            for (int i = 0; i < 5; i++) {
+                for (;;) {
+                    state = (unsigned long long)(unsigned)state * 4164903690ULL + (unsigned)(state >> 32);   // RNG::next
+                    const int v = idx[i] = (int)((unsigned)state % (unsigned)M);                               // uniform(0, M)
+                    int j = 0;
+                    for (; j < i; j++) if (v == idx[j]) break;
+                    if (j == i) break;
+                }
+            }
+            for (int k = 0; k < 5; k++) dst[5 * it + k] = idx[k];
+        }
+    }
+    HIPCHK(ctx, hipMalloc((void**)&ctx->d_sample_table, tab.size() * 4));
+    HIPCHK(ctx, hipMemcpy(ctx->d_sample_table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    ctx->sample_max_m = max_m; ctx->sample_iters = iters; ctx->sample_seed = ctx->p.ransac_seed;
     return VIS_OK;
 }
 
@@ -514,6 +547,8 @@ static int pose_host(vis_ctx* ctx, const float* p1xy, const float* p2xy, int m, 
     const int32_t mm = m;
     HIPCHK(ctx, hipMemcpy(d_npts, &mm, 4, hipMemcpyHostToDevice));
     if (E_in) HIPCHK(ctx, hipMemcpy(d_E, E_in, 72, hipMemcpyHostToDevice));
+    rc = vis_build_sample_table(ctx, std::min(m, 64));
+    if (rc) return rc;
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[6], ctx->stream);
     rc = pose_run(ctx, 1, mcap, iters, d_p1, d_p2, d_npts, d_n1, d_n2, d_samples, d_models, d_counts, d_rstate,
                   E_in ? d_E : nullptr, d_mask, d_pose, do_ransac, do_pose);

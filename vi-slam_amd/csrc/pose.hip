@@ -91,99 +91,97 @@ DEV double poly_eval(const double* c, int deg, double x) {
     return r;
 }
 
-struct Sturm { double c[12][11]; int deg[12]; int n; };
+#define BISECT_INNER 40
+#define BISECT_FINAL 200
 
-__device__ void sturm_build(const double* p, int deg, Sturm& S) {
-    for (int i = 0; i <= deg; i++) S.c[0][i] = p[i];
-    S.deg[0] = deg; S.n = 1;
-    if (deg == 0) return;
-    for (int i = 1; i <= deg; i++) S.c[1][i - 1] = p[i] * i;
-    S.deg[1] = deg - 1; S.n = 2;
-    while (S.deg[S.n - 1] > 0) {
-        const double* a = S.c[S.n - 2]; const int da = S.deg[S.n - 2];
-        const double* b = S.c[S.n - 1]; const int db = S.deg[S.n - 1];
-        double r[11];
-        for (int i = 0; i <= da; i++) r[i] = a[i];
-        for (int k = da - db; k >= 0; k--) {
-            const double f = r[db + k] / b[db];
-            for (int i = 0; i <= db; i++) r[i + k] -= f * b[i];
-            r[db + k] = 0.0;
+// generic (rolled) derivative-interlacing root finder: identical steps to oracle/pose.cpp real_roots.
+// Only used when the degree-10 coefficient vanished (deg < 10) -- the unrolled fast path handles deg == 10.
+__device__ int real_roots_generic(const double* c, int deg, double B, double* roots) {
+    double prev[11]; int nprev = 0;
+    for (int d = 1; d <= deg; d++) {
+        const int k = deg - d;
+        double q[11];
+        for (int i = 0; i <= d; i++) {
+            double f = 1.0;
+            for (int j = 0; j < k; j++) f *= (double)(i + k - j);
+            q[i] = c[i + k] * f;
         }
-        int dr = db - 1;
-        double mx = 0; for (int i = 0; i <= dr; i++) mx = fmax(mx, fabs(r[i]));
-        double ma = 0; for (int i = 0; i <= da; i++) ma = fmax(ma, fabs(a[i]));
-        if (mx <= 1e-14 * ma) break;
-        while (dr > 0 && fabs(r[dr]) <= 1e-14 * mx) dr--;
-        for (int i = 0; i <= dr; i++) S.c[S.n][i] = -r[i];
-        S.deg[S.n] = dr; S.n++;
-        if (S.n >= 12) break;
-    }
-}
-__device__ int sturm_count(const Sturm& S, double x) {
-    int changes = 0, last = 0;
-    for (int k = 0; k < S.n; k++) {
-        const double v = poly_eval(S.c[k], S.deg[k], x);
-        const int s = v > 0 ? 1 : (v < 0 ? -1 : 0);
-        if (s == 0) continue;
-        if (last != 0 && s != last) changes++;
-        last = s;
-    }
-    return changes;
-}
-
-struct Iv { double lo, hi; int nlo, nhi; };
-#define IV_STACK 96
-
-__device__ int real_roots(const double* cin, int deg, double* roots) {
-    double c[11]; double mx = 0;
-    for (int i = 0; i <= deg; i++) mx = fmax(mx, fabs(cin[i]));
-    if (mx == 0) return 0;
-    for (int i = 0; i <= deg; i++) c[i] = cin[i] / mx;
-    while (deg > 0 && fabs(c[deg]) < 1e-15) deg--;
-    if (deg == 0) return 0;
-    Sturm S; sturm_build(c, deg, S);
-    double B = 0;
-    for (int i = 0; i < deg; i++) B = fmax(B, fabs(c[i] / c[deg]));
-    B += 1.0;
-    Iv stack[IV_STACK]; int sp = 0;
-    const int nlo = sturm_count(S, -B), nhi = sturm_count(S, B);
-    int nroots = 0;
-    if (nlo - nhi <= 0) return 0;
-    stack[sp++] = Iv{-B, B, nlo, nhi};
-    while (sp > 0 && nroots < deg) {
-        const Iv iv = stack[--sp];
-        const int cnt = iv.nlo - iv.nhi;
-        if (cnt <= 0) continue;
-        const double mid = 0.5 * (iv.lo + iv.hi);
-        const bool tiny = (iv.hi - iv.lo) <= 1e-13 * B || mid <= iv.lo || mid >= iv.hi;
-        if (cnt == 1 || tiny) {
-            double lo = iv.lo, hi = iv.hi;
-            double flo = poly_eval(c, deg, lo), fhi = poly_eval(c, deg, hi);
-            if (!tiny && ((flo < 0) != (fhi < 0))) {
-                for (int it = 0; it < 200; it++) {
-                    const double m = 0.5 * (lo + hi);
-                    if (m <= lo || m >= hi) break;
-                    const double fm = poly_eval(c, deg, m);
-                    if ((fm < 0) == (flo < 0)) { lo = m; flo = fm; } else { hi = m; fhi = fm; }
-                }
-                roots[nroots++] = 0.5 * (lo + hi);
-            } else if (!tiny) {
-                if (sp + 2 <= IV_STACK) {
-                    const int nm = sturm_count(S, mid);
-                    stack[sp++] = Iv{mid, iv.hi, nm, iv.nhi};
-                    stack[sp++] = Iv{iv.lo, mid, iv.nlo, nm};
-                }
-            } else {
-                roots[nroots++] = mid;
+        double cur[11]; int ncur = 0;
+        for (int j = 0; j <= nprev; j++) {
+            double lo = j == 0 ? -B : prev[j - 1];
+            double hi = j == nprev ? B : prev[j];
+            const double flo = poly_eval(q, d, lo), fhi = poly_eval(q, d, hi);
+            if ((flo < 0) == (fhi < 0)) continue;
+            const int nit = d == deg ? BISECT_FINAL : BISECT_INNER;
+            for (int it = 0; it < nit; it++) {
+                const double m = 0.5 * (lo + hi);
+                if (m <= lo || m >= hi) break;
+                const double fm = poly_eval(q, d, m);
+                if ((fm < 0) == (flo < 0)) lo = m; else hi = m;
             }
-            continue;
+            cur[ncur++] = 0.5 * (lo + hi);
         }
-        if (sp + 2 > IV_STACK) { roots[nroots++] = mid; continue; }
-        const int nm = sturm_count(S, mid);
-        stack[sp++] = Iv{mid, iv.hi, nm, iv.nhi};
-        stack[sp++] = Iv{iv.lo, mid, iv.nlo, nm};
+        nprev = ncur;
+        for (int j = 0; j < ncur; j++) prev[j] = cur[j];
     }
-    return nroots;
+    for (int j = 0; j < nprev; j++) roots[j] = prev[j];
+    return nprev;
+}
+
+// unrolled level of the same algorithm for deg == 10: q = (10-D)-th derivative (degree D), all D candidate
+// intervals bisected in lock step (independent Horner chains -> ILP), everything in registers.
+template <int D>
+DEV void interlace_level(const double (&c)[11], double B, double (&prev)[10], int& nprev) {
+    constexpr int K = 10 - D;
+    double q[D + 1];
+#pragma unroll
+    for (int i = 0; i <= D; i++) {
+        double f = 1.0;
+#pragma unroll
+        for (int j = 0; j < K; j++) f *= (double)(i + K - j);
+        q[i] = c[i + K] * f;
+    }
+    double lo[D], hi[D]; bool act[D], neg[D];
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        lo[j] = (j == 0) ? -B : prev[j > 0 ? j - 1 : 0];
+        hi[j] = (j == nprev) ? B : prev[j < 10 ? j : 9];
+        double flo = q[D], fhi = q[D];
+#pragma unroll
+        for (int i = D - 1; i >= 0; i--) { flo = flo * lo[j] + q[i]; fhi = fhi * hi[j] + q[i]; }
+        neg[j] = flo < 0;
+        act[j] = (j <= nprev) && ((flo < 0) != (fhi < 0));
+    }
+    constexpr int NIT = (D == 10) ? BISECT_FINAL : BISECT_INNER;
+    for (int it = 0; it < NIT; it++) {
+        bool progress = false;
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            const double m = 0.5 * (lo[j] + hi[j]);
+            double fm = q[D];
+#pragma unroll
+            for (int i = D - 1; i >= 0; i--) fm = fm * m + q[i];
+            const bool go = act[j] && (m > lo[j]) && (m < hi[j]);       // "break" of the reference loop == no-op from here on
+            const bool left = (fm < 0) == neg[j];
+            if (go && left) lo[j] = m;
+            if (go && !left) hi[j] = m;
+            progress |= go;
+        }
+        if (D == 10 && !__any(progress)) break;
+    }
+    double cur[10]; int ncur = 0;
+#pragma unroll
+    for (int t = 0; t < 10; t++) cur[t] = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        const double r = 0.5 * (lo[j] + hi[j]);
+#pragma unroll
+        for (int t = 0; t < D; t++) if (act[j] && t == ncur) cur[t] = r;
+        ncur += act[j] ? 1 : 0;
+    }
+#pragma unroll
+    for (int t = 0; t < 10; t++) prev[t] = cur[t];
+    nprev = ncur;
 }
 
 DEV void pmul(const double* a, int da, const double* b, int db, double* o) {
@@ -191,143 +189,33 @@ DEV void pmul(const double* a, int da, const double* b, int db, double* o) {
     for (int i = 0; i <= da; i++) for (int j = 0; j <= db; j++) o[i + j] += a[i] * b[j];
 }
 
-// 5-point minimal solver; Es: up to 10 row-major E with x2^T E x1 = 0, ascending root order
-__device__ int five_point(const double* q1, const double* q2, double* Es) {
-    double A[9][5];
-    for (int i = 0; i < 5; i++) {
-        const double x1 = q1[2 * i], y1 = q1[2 * i + 1], x2 = q2[2 * i], y2 = q2[2 * i + 1];
-        A[0][i] = x2 * x1; A[1][i] = x2 * y1; A[2][i] = x2;
-        A[3][i] = y2 * x1; A[4][i] = y2 * y1; A[5][i] = y2;
-        A[6][i] = x1; A[7][i] = y1; A[8][i] = 1.0;
-    }
-    double vs[5][9]; double betas[5];
-    for (int k = 0; k < 5; k++) {
-        double nrm = 0;
-        for (int i = k; i < 9; i++) nrm += A[i][k] * A[i][k];
-        nrm = sqrt(nrm);
-        for (int i = 0; i < 9; i++) vs[k][i] = 0;
-        if (nrm < 1e-300) { betas[k] = 0; continue; }
-        const double alpha = A[k][k] >= 0 ? -nrm : nrm;
-        for (int i = k; i < 9; i++) vs[k][i] = A[i][k];
-        vs[k][k] -= alpha;
-        double vn = 0; for (int i = k; i < 9; i++) vn += vs[k][i] * vs[k][i];
-        if (vn < 1e-300) { betas[k] = 0; continue; }
-        betas[k] = 2.0 / vn;
-        for (int j = k; j < 5; j++) {
-            double d = 0; for (int i = k; i < 9; i++) d += vs[k][i] * A[i][j];
-            d *= betas[k];
-            for (int i = k; i < 9; i++) A[i][j] -= d * vs[k][i];
-        }
-    }
-    double Bs[4][9];
-    for (int j = 0; j < 4; j++) {
-        double e[9];
-        for (int i = 0; i < 9; i++) e[i] = 0;
-        e[5 + j] = 1.0;
-        for (int k = 4; k >= 0; k--) {
-            double d = 0; for (int i = k; i < 9; i++) d += vs[k][i] * e[i];
-            d *= betas[k];
-            for (int i = k; i < 9; i++) e[i] -= d * vs[k][i];
-        }
-        for (int i = 0; i < 9; i++) Bs[j][i] = e[i];
-    }
-    double El[3][3][4];
-    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) for (int v = 0; v < 4; v++) El[r][c][v] = Bs[v][3 * r + c];
-    double M[10][20];
-    for (int r = 0; r < 10; r++) for (int c = 0; c < 20; c++) M[r][c] = 0;
-    {
-        const int ta[3] = {0, 1, 2}, tb[3] = {1, 0, 0}, tc[3] = {2, 2, 1}, td[3] = {2, 2, 1}, te[3] = {1, 0, 0};
-        const double sg[3] = {1.0, -1.0, 1.0};
-        for (int k = 0; k < 3; k++) {
-            double q[10], q2[10];
-            for (int i = 0; i < 10; i++) { q[i] = 0; q2[i] = 0; }
-            mul_ll(El[1][tb[k]], El[2][tc[k]], q);
-            mul_ll(El[1][td[k]], El[2][te[k]], q2);
-            for (int i = 0; i < 10; i++) q[i] -= q2[i];
-            mul_ql(q, El[0][ta[k]], M[0], sg[k]);
-        }
-    }
-    {
-        double EEt[3][3][10];
-        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
-            for (int m = 0; m < 10; m++) EEt[i][j][m] = 0;
-            for (int k = 0; k < 3; k++) mul_ll(El[i][k], El[j][k], EEt[i][j]);
-        }
-        double tr[10];
-        for (int m = 0; m < 10; m++) tr[m] = 0.5 * ((EEt[0][0][m] + EEt[1][1][m]) + EEt[2][2][m]);
-        for (int i = 0; i < 3; i++) for (int m = 0; m < 10; m++) EEt[i][i][m] -= tr[m];
-        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
-            for (int k = 0; k < 3; k++) mul_ql(EEt[i][k], El[k][j], M[1 + 3 * i + j], 1.0);
-    }
-    for (int col = 0; col < 10; col++) {
-        int piv = col; double best = fabs(M[col][col]);
-        for (int r = col + 1; r < 10; r++) if (fabs(M[r][col]) > best) { best = fabs(M[r][col]); piv = r; }
-        if (best < 1e-300) return 0;
-        if (piv != col) for (int c = 0; c < 20; c++) { const double t = M[piv][c]; M[piv][c] = M[col][c]; M[col][c] = t; }
-        const double inv = 1.0 / M[col][col];
-        for (int c = col; c < 20; c++) M[col][c] *= inv;
-        for (int r = 0; r < 10; r++) {
-            if (r == col) continue;
-            const double f = M[r][col];
-            if (f == 0.0) continue;
-            for (int c = col; c < 20; c++) M[r][c] -= f * M[col][c];
-        }
-    }
-    double Bx[3][4], By[3][4], B1[3][5];
-    for (int i = 0; i < 3; i++) {
-        const double* a = &M[4 + 2 * i][10];
-        const double* b = &M[5 + 2 * i][10];
-        Bx[i][0] = a[2]; Bx[i][1] = a[1] - b[2]; Bx[i][2] = a[0] - b[1]; Bx[i][3] = -b[0];
-        By[i][0] = a[5]; By[i][1] = a[4] - b[5]; By[i][2] = a[3] - b[4]; By[i][3] = -b[3];
-        B1[i][0] = a[9]; B1[i][1] = a[8] - b[9]; B1[i][2] = a[7] - b[8]; B1[i][3] = a[6] - b[7]; B1[i][4] = -b[6];
-    }
-    double c10[11]; for (int i = 0; i <= 10; i++) c10[i] = 0;
-    {
-        double t1[8], t2[8], m[8], o[11];
-        pmul(By[1], 3, B1[2], 4, t1); pmul(B1[1], 4, By[2], 3, t2);
-        for (int i = 0; i <= 7; i++) m[i] = t1[i] - t2[i];
-        pmul(Bx[0], 3, m, 7, o); for (int i = 0; i <= 10; i++) c10[i] += o[i];
-        pmul(Bx[1], 3, B1[2], 4, t1); pmul(B1[1], 4, Bx[2], 3, t2);
-        for (int i = 0; i <= 7; i++) m[i] = t1[i] - t2[i];
-        pmul(By[0], 3, m, 7, o); for (int i = 0; i <= 10; i++) c10[i] -= o[i];
-        double u1[7], u2[7], mm[7];
-        pmul(Bx[1], 3, By[2], 3, u1); pmul(By[1], 3, Bx[2], 3, u2);
-        for (int i = 0; i <= 6; i++) mm[i] = u1[i] - u2[i];
-        pmul(B1[0], 4, mm, 6, o); for (int i = 0; i <= 10; i++) c10[i] += o[i];
-    }
-    double roots[10];
-    const int nr = real_roots(c10, 10, roots);
-    int count = 0;
-    for (int ri = 0; ri < nr && count < 10; ri++) {
-        const double z = roots[ri];
-        double Bz[3][3];
-        for (int i = 0; i < 3; i++) {
-            Bz[i][0] = poly_eval(Bx[i], 3, z);
-            Bz[i][1] = poly_eval(By[i], 3, z);
-            Bz[i][2] = poly_eval(B1[i], 4, z);
-        }
-        double c01[3], c02[3], c12[3];
-        cross3(Bz[0], Bz[1], c01); cross3(Bz[0], Bz[2], c02); cross3(Bz[1], Bz[2], c12);
-        const double n01 = dot3(c01, c01), n02 = dot3(c02, c02), n12 = dot3(c12, c12);
-        double nv[3] = {c01[0], c01[1], c01[2]}; double nn = n01;
-        if (n02 > nn) { nv[0] = c02[0]; nv[1] = c02[1]; nv[2] = c02[2]; nn = n02; }
-        if (n12 > nn) { nv[0] = c12[0]; nv[1] = c12[1]; nv[2] = c12[2]; nn = n12; }
-        if (!(nn > 0)) continue;
-        const double inv = 1.0 / sqrt(nn);
-        const double w = nv[2] * inv;
-        if (fabs(w) < 1e-10) continue;
-        const double x = (nv[0] * inv) / w, y = (nv[1] * inv) / w;
-        double E[9]; double fn = 0;
-        for (int i = 0; i < 9; i++) {
-            E[i] = ((x * Bs[0][i] + y * Bs[1][i]) + z * Bs[2][i]) + Bs[3][i];
-            fn += E[i] * E[i];
-        }
-        fn = sqrt(fn);
-        if (!(fn > 0)) continue;
-        for (int i = 0; i < 9; i++) Es[9 * count + i] = E[i] / fn;
-        count++;
-    }
-    return count;
+// ---- compile-time monomial tables for the unrolled solver (same tables as g_tb)
+struct CT {
+    static constexpr PoseTables T = make_tables();
+};
+
+// lin*lin -> quad, quad*lin -> cubic with compile-time slots (register arrays)
+DEV void mul_ll_u(const double (&a)[4], const double (&b)[4], double (&q)[10]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) q[CT::T.q_of[i][j]] += a[i] * b[j];
+}
+DEV void mul_ql_u(const double (&q)[10], const double (&l)[4], double (&c)[20], double sgn) {
+#pragma unroll
+    for (int m = 0; m < 10; m++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) c[CT::T.c_of[m][v]] += sgn * (q[m] * l[v]);
+}
+
+// LDS layout (one wave per block): element-major, lane-minor -> every access is conflict free
+#define LM(r, c) ldsM[((r) * 20 + (c)) * 64 + lane]
+#define LB(j, i) ldsB[((j) * 9 + (i)) * 64 + lane]
+#define HYP_LDS_BYTES ((200 + 36) * 64 * 8)
+
+DEV void load_El(const double* ldsB, int lane, int r, int c, double (&l)[4]) {
+#pragma unroll
+    for (int v = 0; v < 4; v++) l[v] = LB(v, 3 * r + c);
 }
 
 DEV int sampson_inlier(const double* E, double x1, double y1, double x2, double y2, float t) {
@@ -353,11 +241,25 @@ struct PoseParams {
     double fx_inv, cx, cy, thr, prob;
     unsigned long long seed;
     int max_iters, adaptive, mcap;
+    const int32_t* sample_table;     // host-built cv::RNG sample tables for M in [6, table_max_m] (may be null)
+    int table_max_m;
 };
 
 // rstate: [0] niters, [1] maxGood, [2] best hypothesis index (-1 none), [3] best model, [4] next iteration to scan,
 //         [5] special (1 = M==5 shortcut, 2 = M<5), [6] M, [7] iterations run
 #define RS 8
+
+// getSubset (ptsetreg.cpp): 5 distinct indices in [0,M), redraw on duplicates, from the running cv::RNG
+DEV void draw_subset(CvRng& rng, int M, int* idx) {
+    for (int i = 0; i < 5; i++) {
+        for (;;) {
+            const int v = idx[i] = rng.uniform(0, M);
+            int j = 0;
+            for (; j < i; j++) if (v == idx[j]) break;
+            if (j == i) break;
+        }
+    }
+}
 
 __global__ __launch_bounds__(256) void k_pose_prep(PoseParams P, const float* __restrict__ p1, const float* __restrict__ p2,
                                                    const int32_t* __restrict__ npts, double* __restrict__ n1, double* __restrict__ n2,
@@ -372,68 +274,330 @@ __global__ __launch_bounds__(256) void k_pose_prep(PoseParams P, const float* __
         o1[2 * i] = ((double)a[2 * i] - P.cx) * P.fx_inv; o1[2 * i + 1] = ((double)a[2 * i + 1] - P.cy) * P.fx_inv;
         o2[2 * i] = ((double)b[2 * i] - P.cx) * P.fx_inv; o2[2 * i + 1] = ((double)b[2 * i + 1] - P.cy) * P.fx_inv;
     }
+    int32_t* rs = rstate + (size_t)pair * RS;
+    int32_t* sm = samples + (size_t)pair * P.max_iters * 5;
     if (tid == 0) {
-        int32_t* rs = rstate + (size_t)pair * RS;
-        int32_t* sm = samples + (size_t)pair * P.max_iters * 5;
         rs[1] = 0; rs[2] = -1; rs[3] = 0; rs[4] = 0; rs[6] = M; rs[7] = 0;
         if (M < 5) { rs[0] = 0; rs[5] = 2; }
         else if (M == 5) { rs[0] = 1; rs[5] = 1; for (int k = 0; k < 5; k++) sm[k] = k; }
-        else {
-            rs[0] = max(P.max_iters, 1); rs[5] = 0;
+        else { rs[0] = max(P.max_iters, 1); rs[5] = 0; }
+    }
+    if (M > 5) {
+        if (P.sample_table && M <= P.table_max_m) {              // table lookup: parallel copy
+            const int32_t* src = P.sample_table + (size_t)(M - 6) * P.max_iters * 5;
+            for (int i = tid; i < P.max_iters * 5; i += 256) sm[i] = src[i];
+        } else if (tid == 0) {                                   // sequential replay of the RNG stream
             CvRng rng; rng.state = P.seed ? P.seed : 0xffffffffULL;
-            for (int it = 0; it < P.max_iters; it++) {          // getSubset: 5 distinct, redraw on duplicates
-                int idx[5];
-                for (int i = 0; i < 5; i++) {
-                    for (;;) {
-                        const int v = idx[i] = rng.uniform(0, M);
-                        int j = 0;
-                        for (; j < i; j++) if (v == idx[j]) break;
-                        if (j == i) break;
-                    }
-                }
+            for (int it = 0; it < P.max_iters; it++) {
+                int idx[5]; draw_subset(rng, M, idx);
                 for (int k = 0; k < 5; k++) sm[5 * it + k] = idx[k];
             }
         }
     }
 }
 
+// One wave per block, one lane per hypothesis.  hbest[pair][h] = (best inlier count << 4) | first model with that
+// count, or -1 when the sample produced no model.  models[pair][h][m][9] receives every E (row-major).
 __global__ __launch_bounds__(64) void k_ransac_hyp(PoseParams P, int h0, const double* __restrict__ n1, const double* __restrict__ n2,
                                                    const int32_t* __restrict__ samples, const int32_t* __restrict__ rstate,
-                                                   double* __restrict__ models, int32_t* __restrict__ counts) {
-    const int pair = blockIdx.y;
-    const int h = h0 + blockIdx.x * 64 + threadIdx.x;
+                                                   double* __restrict__ models, int32_t* __restrict__ hbest) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* ldsM = reinterpret_cast<double*>(smem);
+    double* ldsB = ldsM + 200 * 64;
+    const int pair = blockIdx.y, lane = threadIdx.x;
+    const int h = h0 + blockIdx.x * 64 + lane;
     const int32_t* rs = rstate + (size_t)pair * RS;
     const int niters = rs[0], M = rs[6];
     if (h0 + (int)blockIdx.x * 64 >= niters) return;               // adaptive stop already below this block
     const bool active = h < niters && h < max(P.max_iters, 1);
-    const double* a = n1 + (size_t)pair * P.mcap * 2;
-    const double* b = n2 + (size_t)pair * P.mcap * 2;
-    double Es[90];
-    int nm = 0;
-    if (active) {
-        const int32_t* sm = samples + ((size_t)pair * P.max_iters + h) * 5;
-        double s1[10], s2[10];
-        for (int k = 0; k < 5; k++) {
-            const int id = sm[k];
-            s1[2 * k] = a[2 * id]; s1[2 * k + 1] = a[2 * id + 1];
-            s2[2 * k] = b[2 * id]; s2[2 * k + 1] = b[2 * id + 1];
-        }
-        nm = five_point(s1, s2, Es);
+    const double* pa = n1 + (size_t)pair * P.mcap * 2;
+    const double* pb = n2 + (size_t)pair * P.mcap * 2;
+    const int hh = active ? h : 0;                                 // inactive lanes redo hypothesis 0 (results dropped)
+    const int32_t* sm = samples + ((size_t)pair * P.max_iters + hh) * 5;
+    // ---- epipolar system A = Q^T (9 x 5)
+    double A[9][5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const int id = sm[i];
+        const double x1 = pa[2 * id], y1 = pa[2 * id + 1], x2 = pb[2 * id], y2 = pb[2 * id + 1];
+        A[0][i] = x2 * x1; A[1][i] = x2 * y1; A[2][i] = x2;
+        A[3][i] = y2 * x1; A[4][i] = y2 * y1; A[5][i] = y2;
+        A[6][i] = x1; A[7][i] = y1; A[8][i] = 1.0;
     }
-    if (!active) return;
-    const float t = (float)(P.thr * P.thr);
-    double* mo = models + ((size_t)pair * P.max_iters + h) * 90;
-    int32_t* co = counts + ((size_t)pair * P.max_iters + h) * 10;
-    for (int m = 0; m < 10; m++) {
-        int good = -1;
-        if (m < nm) {
-            good = 0;
-            const double* E = Es + 9 * m;
-            for (int i = 0; i < M; i++) good += sampson_inlier(E, a[2 * i], a[2 * i + 1], b[2 * i], b[2 * i + 1], t);
-            for (int k = 0; k < 9; k++) mo[9 * m + k] = E[k];
+    // ---- Householder QR, reflectors kept (vs[k][i] for i >= k)
+    double vs[5][9]; double betas[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        double nrm = 0;
+#pragma unroll
+        for (int i = k; i < 9; i++) nrm += A[i][k] * A[i][k];
+        nrm = sqrt(nrm);
+#pragma unroll
+        for (int i = 0; i < 9; i++) vs[k][i] = 0;
+        double beta = 0;
+        if (!(nrm < 1e-300)) {
+            const double alpha = A[k][k] >= 0 ? -nrm : nrm;
+#pragma unroll
+            for (int i = k; i < 9; i++) vs[k][i] = A[i][k];
+            vs[k][k] -= alpha;
+            double vn = 0;
+#pragma unroll
+            for (int i = k; i < 9; i++) vn += vs[k][i] * vs[k][i];
+            if (!(vn < 1e-300)) {
+                beta = 2.0 / vn;
+#pragma unroll
+                for (int j = k; j < 5; j++) {
+                    double d = 0;
+#pragma unroll
+                    for (int i = k; i < 9; i++) d += vs[k][i] * A[i][j];
+                    d *= beta;
+#pragma unroll
+                    for (int i = k; i < 9; i++) A[i][j] -= d * vs[k][i];
+                }
+            }
         }
-        co[m] = good;
+        betas[k] = beta;
     }
+    // ---- null-space basis X,Y,Z,W = columns 5..8 of H0..H4 -> LDS
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        double e[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) e[i] = 0;
+        e[5 + j] = 1.0;
+#pragma unroll
+        for (int k = 4; k >= 0; k--) {
+            double d = 0;
+#pragma unroll
+            for (int i = k; i < 9; i++) d += vs[k][i] * e[i];
+            d *= betas[k];
+#pragma unroll
+            for (int i = k; i < 9; i++) e[i] -= d * vs[k][i];
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) LB(j, i) = e[i];
+    }
+    // ---- constraint rows -> LDS.  row 0: det(E)
+    {
+        double row[20];
+#pragma unroll
+        for (int c = 0; c < 20; c++) row[c] = 0;
+        constexpr int ta[3] = {0, 1, 2}, tb[3] = {1, 0, 0}, tc[3] = {2, 2, 1}, td[3] = {2, 2, 1}, te[3] = {1, 0, 0};
+        constexpr double sg[3] = {1.0, -1.0, 1.0};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double q[10], q2[10], l1[4], l2[4];
+#pragma unroll
+            for (int i = 0; i < 10; i++) { q[i] = 0; q2[i] = 0; }
+            load_El(ldsB, lane, 1, tb[k], l1); load_El(ldsB, lane, 2, tc[k], l2); mul_ll_u(l1, l2, q);
+            load_El(ldsB, lane, 1, td[k], l1); load_El(ldsB, lane, 2, te[k], l2); mul_ll_u(l1, l2, q2);
+#pragma unroll
+            for (int i = 0; i < 10; i++) q[i] -= q2[i];
+            load_El(ldsB, lane, 0, ta[k], l1);
+            mul_ql_u(q, l1, row, sg[k]);
+        }
+#pragma unroll
+        for (int c = 0; c < 20; c++) LM(0, c) = row[c];
+    }
+    // rows 1..9: (E E^T - 0.5 tr(E E^T) I) E
+    {
+        double tr[10];
+        {
+            double dg[3][10];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+#pragma unroll
+                for (int m = 0; m < 10; m++) dg[i][m] = 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { double l1[4]; load_El(ldsB, lane, i, k, l1); mul_ll_u(l1, l1, dg[i]); }
+            }
+#pragma unroll
+            for (int m = 0; m < 10; m++) tr[m] = 0.5 * ((dg[0][m] + dg[1][m]) + dg[2][m]);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            double EEt[3][10];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+#pragma unroll
+                for (int m = 0; m < 10; m++) EEt[j][m] = 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { double l1[4], l2[4]; load_El(ldsB, lane, i, k, l1); load_El(ldsB, lane, j, k, l2); mul_ll_u(l1, l2, EEt[j]); }
+            }
+#pragma unroll
+            for (int m = 0; m < 10; m++) EEt[i][m] -= tr[m];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                double row[20];
+#pragma unroll
+                for (int c = 0; c < 20; c++) row[c] = 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { double l1[4]; load_El(ldsB, lane, k, j, l1); mul_ql_u(EEt[k], l1, row, 1.0); }
+#pragma unroll
+                for (int c = 0; c < 20; c++) LM(1 + 3 * i + j, c) = row[c];
+            }
+        }
+    }
+    // ---- Gauss-Jordan with partial pivoting on the left 10 x 10 block (rows live in LDS, pivot row in registers)
+    bool ok = true;
+#pragma unroll
+    for (int col = 0; col < 10; col++) {
+        int piv = col; double best = fabs(LM(col, col));
+        for (int r = col + 1; r < 10; r++) { const double v = fabs(LM(r, col)); if (v > best) { best = v; piv = r; } }
+        if (best < 1e-300) ok = false;
+        double prow[20];
+#pragma unroll
+        for (int c = col; c < 20; c++) { prow[c] = LM(piv, c); const double t = LM(col, c); LM(piv, c) = t; }
+        const double inv = 1.0 / prow[col];
+#pragma unroll
+        for (int c = col; c < 20; c++) { prow[c] *= inv; LM(col, c) = prow[c]; }
+        for (int r = 0; r < 10; r++) {
+            if (r == col) continue;
+            const double f = LM(r, col);
+            if (f == 0.0) continue;
+#pragma unroll
+            for (int c = col; c < 20; c++) LM(r, c) -= f * prow[c];
+        }
+    }
+    // ---- B(z) from rows (4,5),(6,7),(8,9)
+    double Bx[3][4], By[3][4], B1[3][5];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double a[10], b[10];
+#pragma unroll
+        for (int c = 0; c < 10; c++) { a[c] = LM(4 + 2 * i, 10 + c); b[c] = LM(5 + 2 * i, 10 + c); }
+        Bx[i][0] = a[2]; Bx[i][1] = a[1] - b[2]; Bx[i][2] = a[0] - b[1]; Bx[i][3] = -b[0];
+        By[i][0] = a[5]; By[i][1] = a[4] - b[5]; By[i][2] = a[3] - b[4]; By[i][3] = -b[3];
+        B1[i][0] = a[9]; B1[i][1] = a[8] - b[9]; B1[i][2] = a[7] - b[8]; B1[i][3] = a[6] - b[7]; B1[i][4] = -b[6];
+    }
+    // ---- det B(z): degree-10 polynomial (same product/summation order as the oracle)
+    double c10[11];
+#pragma unroll
+    for (int i = 0; i <= 10; i++) c10[i] = 0;
+    {
+        double t1[8], t2[8], m[8], o[11];
+#define PMUL(a, da, b, db, o_) do { _Pragma("unroll") for (int i_ = 0; i_ <= (da) + (db); i_++) (o_)[i_] = 0; \
+            _Pragma("unroll") for (int i_ = 0; i_ <= (da); i_++) _Pragma("unroll") for (int j_ = 0; j_ <= (db); j_++) (o_)[i_ + j_] += (a)[i_] * (b)[j_]; } while (0)
+        PMUL(By[1], 3, B1[2], 4, t1); PMUL(B1[1], 4, By[2], 3, t2);
+#pragma unroll
+        for (int i = 0; i <= 7; i++) m[i] = t1[i] - t2[i];
+        PMUL(Bx[0], 3, m, 7, o);
+#pragma unroll
+        for (int i = 0; i <= 10; i++) c10[i] += o[i];
+        PMUL(Bx[1], 3, B1[2], 4, t1); PMUL(B1[1], 4, Bx[2], 3, t2);
+#pragma unroll
+        for (int i = 0; i <= 7; i++) m[i] = t1[i] - t2[i];
+        PMUL(By[0], 3, m, 7, o);
+#pragma unroll
+        for (int i = 0; i <= 10; i++) c10[i] -= o[i];
+        double u1[7], u2[7], mm[7];
+        PMUL(Bx[1], 3, By[2], 3, u1); PMUL(By[1], 3, Bx[2], 3, u2);
+#pragma unroll
+        for (int i = 0; i <= 6; i++) mm[i] = u1[i] - u2[i];
+        PMUL(B1[0], 4, mm, 6, o);
+#pragma unroll
+        for (int i = 0; i <= 10; i++) c10[i] += o[i];
+#undef PMUL
+    }
+    // ---- real roots (ascending) -> LDS slots reusing the M region (M is dead from here on)
+    int nr = 0;
+    {
+        double c[11]; double mx = 0;
+#pragma unroll
+        for (int i = 0; i <= 10; i++) mx = fmax(mx, fabs(c10[i]));
+        if (mx == 0 || !ok) nr = 0;
+        else {
+#pragma unroll
+            for (int i = 0; i <= 10; i++) c[i] = c10[i] / mx;
+            const bool full = !(fabs(c[10]) < 1e-15);
+            if (__all(full || !active)) {                          // fast path: every lane has degree 10
+                double B = 0;
+#pragma unroll
+                for (int i = 0; i < 10; i++) B = fmax(B, fabs(c[i] / c[10]));
+                B += 1.0;
+                double prev[10]; int np = 0;
+#pragma unroll
+                for (int t = 0; t < 10; t++) prev[t] = 0.0;
+                interlace_level<1>(c, B, prev, np); interlace_level<2>(c, B, prev, np);
+                interlace_level<3>(c, B, prev, np); interlace_level<4>(c, B, prev, np);
+                interlace_level<5>(c, B, prev, np); interlace_level<6>(c, B, prev, np);
+                interlace_level<7>(c, B, prev, np); interlace_level<8>(c, B, prev, np);
+                interlace_level<9>(c, B, prev, np); interlace_level<10>(c, B, prev, np);
+                nr = full ? np : 0;
+#pragma unroll
+                for (int t = 0; t < 10; t++) LM(0, t) = prev[t];
+            } else {                                               // rare: some lane lost the leading coefficient
+                int deg = 10;
+                while (deg > 0 && fabs(c[deg]) < 1e-15) deg--;
+                double rr[10];
+                for (int t = 0; t < 10; t++) rr[t] = 0;
+                if (deg > 0) {
+                    double B = 0;
+                    for (int i = 0; i < deg; i++) B = fmax(B, fabs(c[i] / c[deg]));
+                    B += 1.0;
+                    nr = real_roots_generic(c, deg, B, rr);
+                }
+                for (int t = 0; t < 10; t++) LM(0, t) = rr[t];
+            }
+        }
+    }
+    // ---- back-substitute each root, write the model, count inliers
+    const float thr2 = (float)(P.thr * P.thr);
+    double* mo = models + ((size_t)pair * P.max_iters + hh) * 90;
+    int count = 0, bestc = -1, bestm = 0;
+    int nr_max = nr;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nr_max = max(nr_max, __shfl_xor(nr_max, o));
+    for (int ri = 0; ri < nr_max; ri++) {
+        if (ri >= nr) continue;
+        const double z = LM(0, ri);
+        double Bz[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            double v = Bx[i][3];
+#pragma unroll
+            for (int k = 2; k >= 0; k--) v = v * z + Bx[i][k];
+            Bz[i][0] = v;
+            v = By[i][3];
+#pragma unroll
+            for (int k = 2; k >= 0; k--) v = v * z + By[i][k];
+            Bz[i][1] = v;
+            v = B1[i][4];
+#pragma unroll
+            for (int k = 3; k >= 0; k--) v = v * z + B1[i][k];
+            Bz[i][2] = v;
+        }
+        double c01[3], c02[3], c12[3];
+        cross3(Bz[0], Bz[1], c01); cross3(Bz[0], Bz[2], c02); cross3(Bz[1], Bz[2], c12);
+        const double n01 = dot3(c01, c01), n02 = dot3(c02, c02), n12 = dot3(c12, c12);
+        double nv0 = c01[0], nv1 = c01[1], nv2 = c01[2], nn = n01;
+        if (n02 > nn) { nv0 = c02[0]; nv1 = c02[1]; nv2 = c02[2]; nn = n02; }
+        if (n12 > nn) { nv0 = c12[0]; nv1 = c12[1]; nv2 = c12[2]; nn = n12; }
+        if (!(nn > 0)) continue;
+        const double inv = 1.0 / sqrt(nn);
+        const double w = nv2 * inv;
+        if (fabs(w) < 1e-10) continue;
+        const double x = (nv0 * inv) / w, y = (nv1 * inv) / w;
+        double E[9]; double fn = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            E[i] = ((x * LB(0, i) + y * LB(1, i)) + z * LB(2, i)) + LB(3, i);
+            fn += E[i] * E[i];
+        }
+        fn = sqrt(fn);
+        if (!(fn > 0)) continue;
+#pragma unroll
+        for (int i = 0; i < 9; i++) E[i] = E[i] / fn;
+        int good = 0;
+        for (int i = 0; i < M; i++) good += sampson_inlier(E, pa[2 * i], pa[2 * i + 1], pb[2 * i], pb[2 * i + 1], thr2);
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) mo[9 * count + k] = E[k];
+        }
+        if (good > bestc) { bestc = good; bestm = count; }
+        count++;
+    }
+    if (active) hbest[(size_t)pair * P.max_iters + h] = count ? ((bestc << 4) | bestm) : -1;
 }
 
 DEV int update_num_iters(double p, double ep, int modelPoints, int maxIters) {
@@ -446,26 +610,33 @@ DEV int update_num_iters(double p, double ep, int modelPoints, int maxIters) {
     return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)rint(num / denom);
 }
 
-// replay RANSACPointSetRegistrator::run's loop over hypotheses [rs[4], min(hi, niters))
-__global__ void k_ransac_scan(PoseParams P, int hi, int npairs, const int32_t* __restrict__ counts, int32_t* __restrict__ rstate) {
-    const int pair = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pair >= npairs) return;
+// replay RANSACPointSetRegistrator::run's accept/update rule over hypotheses [rs[4], min(hi, niters)).
+// One wave per pair: 64 per-iteration results are fetched in parallel, then walked in order (all lanes
+// carry the same scalar state).  Within one iteration only its best count matters: counts are accepted
+// in model order when strictly greater, so the survivor is the first model reaching the iteration's
+// maximum, and the iteration bound only ever shrinks with larger counts.
+__global__ __launch_bounds__(64) void k_ransac_scan(PoseParams P, int hi, const int32_t* __restrict__ hbest, int32_t* __restrict__ rstate) {
+    const int pair = blockIdx.x, lane = threadIdx.x;
     int32_t* rs = rstate + (size_t)pair * RS;
-    if (rs[5] != 0) { if (rs[5] == 1) { rs[2] = 0; rs[3] = 0; rs[1] = 5; rs[7] = 1; rs[4] = 1; } return; }
-    int niters = rs[0], maxGood = rs[1], iter = rs[4];
+    if (rs[5] != 0) { if (rs[5] == 1 && lane == 0) { rs[2] = 0; rs[3] = 0; rs[1] = 5; rs[7] = 1; rs[4] = 1; } return; }
+    int niters = rs[0], maxGood = rs[1], iter = rs[4], bi = rs[2], bm = rs[3];
     const int M = rs[6];
-    for (; iter < niters && iter < hi; iter++) {
-        const int32_t* co = counts + ((size_t)pair * P.max_iters + iter) * 10;
-        for (int i = 0; i < 10; i++) {
-            const int good = co[i];
-            if (good < 0) break;
+    const int32_t* hb = hbest + (size_t)pair * P.max_iters;
+    while (iter < niters && iter < hi) {
+        const int base = iter;
+        const int idx = base + lane;
+        const int v = (idx < hi && idx < P.max_iters) ? hb[idx] : -1;
+        for (int k = 0; k < 64 && iter < niters && iter < hi; k++, iter++) {
+            const int e = __shfl(v, k);
+            if (e < 0) continue;
+            const int good = e >> 4;
             if (good > max(maxGood, 4)) {
-                rs[2] = iter; rs[3] = i; maxGood = good;
+                bi = iter; bm = e & 15; maxGood = good;
                 if (P.adaptive) niters = update_num_iters(P.prob, (double)(M - good) / M, 5, niters);
             }
         }
     }
-    rs[0] = niters; rs[1] = maxGood; rs[4] = iter; rs[7] = iter;
+    if (lane == 0) { rs[0] = niters; rs[1] = maxGood; rs[2] = bi; rs[3] = bm; rs[4] = iter; rs[7] = iter; }
 }
 
 __device__ void svd3_decompose(const double* E, double* U, double* Vt) {
@@ -635,6 +806,8 @@ static PoseParams make_pose_params(const vis_ctx* ctx, int max_iters, int mcap) 
     P.thr = ctx->p.ransac_threshold / ctx->p.fx;        // findEssentialMat: threshold /= focal
     P.prob = ctx->p.ransac_prob; P.seed = ctx->p.ransac_seed;
     P.max_iters = max_iters; P.adaptive = ctx->p.ransac_adaptive; P.mcap = mcap;
+    P.sample_table = (max_iters == ctx->sample_iters && ctx->sample_seed == ctx->p.ransac_seed) ? ctx->d_sample_table : nullptr;
+    P.table_max_m = ctx->sample_max_m;
     return P;
 }
 
@@ -644,16 +817,21 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
              double* d_n1, double* d_n2, int32_t* d_samples, double* d_models, int32_t* d_counts, int32_t* d_rstate,
              const double* d_E_in, uint8_t* d_mask, PoseOut* d_pose, int do_ransac, int do_pose) {
     hipStream_t st = ctx->stream;
-    const PoseParams P = make_pose_params(ctx, max_iters, mcap);
+    PoseParams P = make_pose_params(ctx, max_iters, mcap);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)k_ransac_hyp, hipFuncAttributeMaxDynamicSharedMemorySize, HYP_LDS_BYTES));
+        attr_set = true;
+    }
     hipLaunchKernelGGL(k_pose_prep, dim3(npairs), dim3(256), 0, st, P, d_p1, d_p2, d_npts, d_n1, d_n2, d_samples, d_rstate);
     if (do_ransac) {
         const int first = std::min(64, std::max(max_iters, 1));
-        hipLaunchKernelGGL(k_ransac_hyp, dim3(1, npairs), dim3(64), 0, st, P, 0, d_n1, d_n2, d_samples, d_rstate, d_models, d_counts);
-        hipLaunchKernelGGL(k_ransac_scan, dim3((npairs + 63) / 64), dim3(64), 0, st, P, first, npairs, d_counts, d_rstate);
+        hipLaunchKernelGGL(k_ransac_hyp, dim3(1, npairs), dim3(64), HYP_LDS_BYTES, st, P, 0, d_n1, d_n2, d_samples, d_rstate, d_models, d_counts);
+        hipLaunchKernelGGL(k_ransac_scan, dim3(npairs), dim3(64), 0, st, P, first, d_counts, d_rstate);
         if (max_iters > first) {
-            hipLaunchKernelGGL(k_ransac_hyp, dim3((max_iters - first + 63) / 64, npairs), dim3(64), 0, st, P, first, d_n1, d_n2,
+            hipLaunchKernelGGL(k_ransac_hyp, dim3((max_iters - first + 63) / 64, npairs), dim3(64), HYP_LDS_BYTES, st, P, first, d_n1, d_n2,
                                d_samples, d_rstate, d_models, d_counts);
-            hipLaunchKernelGGL(k_ransac_scan, dim3((npairs + 63) / 64), dim3(64), 0, st, P, max_iters, npairs, d_counts, d_rstate);
+            hipLaunchKernelGGL(k_ransac_scan, dim3(npairs), dim3(64), 0, st, P, max_iters, d_counts, d_rstate);
         }
     }
     hipLaunchKernelGGL(k_pose_final, dim3(npairs), dim3(256), 0, st, P, d_n1, d_n2, d_models, d_rstate, d_E_in, d_mask, d_pose, do_pose);

@@ -98,6 +98,8 @@ struct vis_ctx {
     // grow-only scratch for the *_host entry points
     void* d_scratch = nullptr; size_t scratch_bytes = 0;
     int slot_valid[VIS_NSLOTS];
+    // cv::RNG sample tables for M in [6, sample_max_m], built on the host for (seed, max_iters)
+    int32_t* d_sample_table = nullptr; int sample_max_m = 0; int sample_iters = 0; unsigned long long sample_seed = 0;
 };
 
 #define HIPCHK(ctx, call)                                                          \
@@ -125,6 +127,7 @@ int launch_half_pyramid(vis_ctx* ctx, const uint8_t* d_img, int w, int h, int st
 int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p1, const float* d_p2, const int32_t* d_npts,
              double* d_n1, double* d_n2, int32_t* d_samples, double* d_models, int32_t* d_counts, int32_t* d_rstate,
              const double* d_E_in, uint8_t* d_mask, PoseOut* d_pose, int do_ransac, int do_pose);
+int  vis_build_sample_table(vis_ctx* ctx, int max_m);
 int f2f_run(vis_ctx* ctx, const vis_keypoint* d_pts1, const vis_keypoint* d_pts2, int m, const float* d_rot,
             const int32_t* d_idx, int iters, double* d_nv, float* d_counts);
 #define VIS_RSTATE_WORDS 8
