@@ -25,6 +25,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402  (device memory + torch.distributed plumbing; imported before the HIP library)
 import vislam  # noqa: E402
+from vislam import dist as vdist  # noqa: E402
 
 W, H, NFEAT, LEVELS = 752, 480, 1000, 8
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy)
@@ -102,20 +103,14 @@ def main():
 
     # ---- parameters: rank 0 owns them; one RCCL broadcast of the POD struct ("intrinsics only")
     p = vislam.default_params()
-    p.nfeatures, p.nlevels, p.w_size, p.h_size = NFEAT, LEVELS, W, H
-    p.fy = p.fx
-    buf = torch.zeros(C.sizeof(vislam.Params), dtype=torch.uint8)
     if rank == 0:
-        buf = torch.frombuffer(bytearray(bytes(p)), dtype=torch.uint8).clone()
-    if dist is not None:
-        dbuf = buf.to(dev)
-        dist.broadcast(dbuf, src=0)
-        buf = dbuf.cpu()
-    C.memmove(C.byref(p), bytes(buf.numpy().tobytes()), C.sizeof(vislam.Params))
+        p.nfeatures, p.nlevels, p.w_size, p.h_size = NFEAT, LEVELS, W, H
+        p.fy = p.fx
+    p = vdist.broadcast_params(p, dist, dev, rank)
 
     ctx = vislam.Context(local_rank if world > 1 else 0, p)
     B, R = a.batch, a.ring
-    frames = make_frames(0xE0C00010 + rank if world > 1 else 0xE0C00001, B * R)
+    frames = make_frames(vdist.stream_seed(rank, world), B * R)
     dframes = torch.from_numpy(frames).to(dev)
     ctx.batch_plan(W, H, W, B)
     fbytes = W * H
@@ -141,10 +136,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = vdist.max_over_ranks(dt, dist, dev)
     if ctx.batch_status() != 0:
         raise RuntimeError("device capacity flag set during the timed region")
 
@@ -177,7 +169,7 @@ def main():
                 traffic = json.load(open(pmc)).get(kname, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        fps = world * a.steps * B / dt
+        fps = vdist.aggregate_fps(world, a.steps, B, dt)
         out = {
             "metric": "frames/sec detect+match+pose, 752x480 mono8", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,

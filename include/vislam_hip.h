@@ -134,7 +134,8 @@ int  vis_level_geometry(vis_ctx* ctx, int w, int h, int32_t* widths, int32_t* he
 
 /* ---- single-frame API: one call per OpenCV(-CUDA) call site --------------- */
 /* Camera::Update, src/Camera.cpp:63-72: copy + 4x half-resolution levels.
- * out_levels[l] (l=1..4) receives (w>>l)*(h>>l) bytes, tightly packed; out_levels[0] may be NULL. */
+ * out_levels[l] (l=1..4) receives (w>>l)*(h>>l) bytes, tightly packed; out_levels[0] may be NULL.
+ * w and h must be multiples of 16 (all four levels halve exactly, as 752x480 does). */
 int  vis_camera_update(vis_ctx* ctx, const uint8_t* img, int w, int h, int stride,
                        uint8_t* const out_levels[5]);
 /* replaces frameGPU.upload + cuda::ORB::detectAndCompute + descriptorsGPU.download,

@@ -9,6 +9,9 @@ struct LevelGeom { int w, h, quota; float scale; };
 struct RawKp { int x, y; float response; };
 
 void sincos_det(double x, double* s, double* c);
+float fast_atan2(float y, float x);
+void compute_umax(int halfPatch, std::vector<int>& umax);
+void gaussian_kernel7_q8(int k[7]);
 void level_geometry(const vis_params& p, int w, int h, std::vector<LevelGeom>& g);
 int orb_detect_compute(const vis_params& p, const uint8_t* img, int w, int h, int stride,
                        std::vector<vis_keypoint>& kps, std::vector<uint8_t>& desc);

@@ -430,26 +430,23 @@ extern "C" int orc_resize_linear(const uint8_t* src, int sw, int sh, int sstride
 }
 
 // Camera::Update, src/Camera.cpp:68-70: resize(prev, next, Size(), 0.5, 0.5) -> INTER_LINEAR with an
-// exact 2x decimation takes OpenCV's area-fast path: (a+b+c+d+2)>>2; dst size = cvRound(src*0.5).
+// exact 2x decimation takes OpenCV's area-fast path: (a+b+c+d+2)>>2.  SPEC: w and h must be multiples
+// of 16 so that all four levels halve exactly (752x480 -> 47x30); OpenCV's odd-size edge handling
+// (cvRound'ed dsize + partial boxes) is outside the reference's use and not restated.
 extern "C" int orc_half_pyramid(const uint8_t* img, int w, int h, int stride, uint8_t* const out_levels[5]) {
-    if (!img || !out_levels) return VIS_E_INVALID;
+    if (!img || !out_levels || w < 16 || h < 16 || (w & 15) || (h & 15)) return VIS_E_INVALID;
     std::vector<uint8_t> prev((size_t)w * h);
     for (int y = 0; y < h; y++) std::memcpy(&prev[(size_t)y * w], img + (size_t)y * stride, w);
     if (out_levels[0]) std::memcpy(out_levels[0], prev.data(), prev.size());
     int pw = w, ph = h;
     for (int l = 1; l < 5; l++) {
-        int nw = cv_round(pw * 0.5), nh = cv_round(ph * 0.5);
-        if (nw < 1 || nh < 1) return VIS_E_INVALID;
+        const int nw = pw / 2, nh = ph / 2;
         std::vector<uint8_t> cur((size_t)nw * nh);
-        if (nw * 2 == pw && nh * 2 == ph) {
-            for (int y = 0; y < nh; y++)
-                for (int x = 0; x < nw; x++) {
-                    const uint8_t* s = &prev[(size_t)(2 * y) * pw + 2 * x];
-                    cur[(size_t)y * nw + x] = (uint8_t)((s[0] + s[1] + s[pw] + s[pw + 1] + 2) >> 2);
-                }
-        } else {
-            resize_linear(prev.data(), pw, ph, pw, cur.data(), nw, nh, nw);   // odd sizes: generic path
-        }
+        for (int y = 0; y < nh; y++)
+            for (int x = 0; x < nw; x++) {
+                const uint8_t* s = &prev[(size_t)(2 * y) * pw + 2 * x];
+                cur[(size_t)y * nw + x] = (uint8_t)((s[0] + s[1] + s[pw] + s[pw + 1] + 2) >> 2);
+            }
         if (out_levels[l]) std::memcpy(out_levels[l], cur.data(), cur.size());
         prev.swap(cur); pw = nw; ph = nh;
     }
@@ -489,3 +486,9 @@ extern "C" int orc_orb_detect_compute(const vis_params* p, const uint8_t* img, i
     if (desc) std::memcpy(desc, d.data(), d.size());
     return VIS_OK;
 }
+
+// ---- small exports for the unit tests ----
+extern "C" void orc_sincos_det(double x, double* s, double* c) { orc::sincos_det(x, s, c); }
+extern "C" float orc_fast_atan2(float y, float x) { return orc::fast_atan2(y, x); }
+extern "C" void orc_umax(int half_patch, int* out) { std::vector<int> u; orc::compute_umax(half_patch, u); for (int i = 0; i <= half_patch; i++) out[i] = u[i]; }
+extern "C" void orc_gaussian_kernel7_q8(int* k) { orc::gaussian_kernel7_q8(k); }

@@ -72,6 +72,12 @@ int orc_f2f_ransac(const vis_params* p, const vis_keypoint* pts1, const vis_keyp
 /* the sample sequence cv::RNG((uint64)-1) + getSubset would draw: idx5[iters*5] */
 int orc_ransac_samples(uint64_t seed, int count, int iters, int32_t* idx5);
 
+/* unit-test hooks */
+void orc_sincos_det(double x, double* s, double* c);
+float orc_fast_atan2(float y, float x);
+void orc_umax(int half_patch, int* out);
+void orc_gaussian_kernel7_q8(int* k);
+
 /* whole per-frame CPU pipeline for the cpu_baseline leg: detect cur, match against prev
  * (knn both directions as the reference does), filters, essential RANSAC, recoverPose. */
 typedef struct orc_frame_result {

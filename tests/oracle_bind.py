@@ -61,7 +61,8 @@ def half_pyramid(img):
     h, w = img.shape
     levels = [np.empty((h >> l, w >> l), np.uint8) for l in range(5)]
     arr = (vp * 5)(*[l.ctypes.data for l in levels])
-    assert lib.orc_half_pyramid(_p(img), w, h, img.strides[0], arr) == 0
+    rc = lib.orc_half_pyramid(_p(img), w, h, img.strides[0], arr)
+    assert rc == 0, rc
     return levels
 
 
@@ -175,3 +176,35 @@ def pipeline_frame(p, img, prev=None, cap=None):
     rc = lib.orc_pipeline_frame(C.byref(p), _p(img), w, h, img.strides[0], _p(pk), _p(pd), pn, _p(kps), _p(desc), cap, C.byref(res))
     assert rc == 0, rc
     return kps[:res.n_kp].copy(), desc[:res.n_kp].copy(), res
+
+
+lib.orc_sincos_det.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+lib.orc_sincos_det.restype = None
+lib.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+lib.orc_fast_atan2.restype = C.c_float
+lib.orc_umax.argtypes = [ci, vp]
+lib.orc_umax.restype = None
+lib.orc_gaussian_kernel7_q8.argtypes = [vp]
+lib.orc_gaussian_kernel7_q8.restype = None
+
+
+def sincos_det(x):
+    s, c = C.c_double(), C.c_double()
+    lib.orc_sincos_det(x, C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def fast_atan2(y, x):
+    return float(lib.orc_fast_atan2(y, x))
+
+
+def umax(half=15):
+    out = np.zeros(half + 1, np.int32)
+    lib.orc_umax(half, _p(out))
+    return out
+
+
+def gaussian_kernel7_q8():
+    k = np.zeros(7, np.int32)
+    lib.orc_gaussian_kernel7_q8(_p(k))
+    return k

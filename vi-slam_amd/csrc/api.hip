@@ -307,7 +307,7 @@ static int check_flags(vis_ctx* ctx, Plan* pl) {
 
 // ------------------------------------------------------------------------------------------------ single-frame API
 extern "C" int vis_camera_update(vis_ctx* ctx, const uint8_t* img, int w, int h, int stride, uint8_t* const out_levels[5]) {
-    if (!ctx || !img || !out_levels || w < 16 || h < 16 || stride < w) return VIS_E_INVALID;
+    if (!ctx || !img || !out_levels || w < 16 || h < 16 || (w & 15) || (h & 15) || stride < w) return VIS_E_INVALID;
     (void)hipSetDevice(ctx->device);
     size_t lvl_bytes[5]; size_t total = (size_t)w * h;
     lvl_bytes[0] = (size_t)w * h;
