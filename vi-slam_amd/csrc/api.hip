@@ -45,7 +45,7 @@ extern "C" void vis_default_params(vis_params* p) {
 
 static int validate_params(const vis_params& p) {
     if (p.nfeatures < 1 || p.nlevels < 1 || p.nlevels > VIS_MAX_LEVELS) return VIS_E_INVALID;
-    if (!(p.scale_factor > 1.0f)) return VIS_E_INVALID;
+    if (!(p.scale_factor > 1.0f) || p.scale_factor > 3.0f) return VIS_E_INVALID;   // k_resize fetches a 12-byte source window per 4 outputs
     if (p.patch_size != 31) return VIS_E_INVALID;                 // the rBRIEF pattern is learned for 31x31
     if (p.edge_threshold < 22 || p.edge_threshold > 255) return VIS_E_INVALID;   // 43x43 raw patch must stay inside
     if (p.fast_threshold < 1 || p.fast_threshold > 254) return VIS_E_INVALID;

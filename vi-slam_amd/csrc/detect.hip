@@ -22,7 +22,17 @@
 #include <cmath>
 
 // ------------------------------------------------------------------------------------------------
-// k_resize: one thread = 4 horizontally adjacent destination pixels (one 32-bit store).
+// k_resize: one thread = 4 horizontally adjacent destination pixels (one 32-bit store).  The two source
+// rows are fetched as (unaligned) dwords covering the <= 12 source bytes the four outputs touch, the
+// coefficient tables as one 16-byte vector each; bytes are picked with v_alignbyte.
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+
+__device__ __forceinline__ uint32_t pick_byte(uint32_t w0, uint32_t w1, uint32_t w2, int off) {
+    // byte `off` (0..11) of the 12-byte little-endian string w0|w1|w2
+    const uint32_t lo = off < 4 ? w0 : (off < 8 ? w1 : w2);
+    return (lo >> ((off & 3) * 8)) & 0xFFu;
+}
+
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, int sw, int sstride, size_t sframe,
                                                 uint8_t* __restrict__ dst, int dw, int dh, int dstride, size_t dframe,
                                                 const int32_t* __restrict__ xofs, const int16_t* __restrict__ ialpha,
@@ -31,21 +41,49 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
     const int dy = blockIdx.y * 4 + threadIdx.y;
     const int f = blockIdx.z;
     if (dx4 >= dw || dy >= dh) return;
-    const uint8_t* S0 = src + (size_t)f * sframe + (size_t)yofs[2 * dy] * sstride;
-    const uint8_t* S1 = src + (size_t)f * sframe + (size_t)yofs[2 * dy + 1] * sstride;
-    const int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
+    const int2 ys = *reinterpret_cast<const int2*>(yofs + 2 * dy);
+    const uint32_t bb = *reinterpret_cast<const uint32_t*>(ibeta + 2 * dy);
+    const int b0 = (int)(short)(bb & 0xFFFF), b1 = (int)(short)(bb >> 16);
+    const uint8_t* S0 = src + (size_t)f * sframe + (size_t)ys.x * sstride;
+    const uint8_t* S1 = src + (size_t)f * sframe + (size_t)ys.y * sstride;
     uint32_t out = 0;
+    if (dx4 + 3 < dw) {
+        const int4 xo = *reinterpret_cast<const int4*>(xofs + dx4);           // tables are padded to a multiple of 4
+        const uint4 al = *reinterpret_cast<const uint4*>(ialpha + 2 * dx4);
+        const int base = xo.x;
+        // the 4 outputs read source bytes base .. xo.w+1 (span <= 12 for any down-scale factor < 3.6);
+        // clamp the window start so the 12-byte fetch stays inside the row (rows are >= 12 bytes)
+        const int wb = min(base, sstride - 12);
+        const uint32_t a0w = *reinterpret_cast<const u32_unaligned*>(S0 + wb);
+        const uint32_t a1w = *reinterpret_cast<const u32_unaligned*>(S0 + wb + 4);
+        const uint32_t a2w = *reinterpret_cast<const u32_unaligned*>(S0 + wb + 8);
+        const uint32_t c0w = *reinterpret_cast<const u32_unaligned*>(S1 + wb);
+        const uint32_t c1w = *reinterpret_cast<const u32_unaligned*>(S1 + wb + 4);
+        const uint32_t c2w = *reinterpret_cast<const u32_unaligned*>(S1 + wb + 8);
+        const int sxs[4] = {xo.x, xo.y, xo.z, xo.w};
+        const uint32_t als[4] = {al.x, al.y, al.z, al.w};
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int dx = dx4 + k;
-        if (dx < dw) {
-            const int sx = xofs[dx];
-            const int sx1 = min(sx + 1, sw - 1);
-            const int a0 = ialpha[2 * dx], a1 = ialpha[2 * dx + 1];
-            const int r0 = S0[sx] * a0 + S0[sx1] * a1;
-            const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+        for (int k = 0; k < 4; k++) {
+            const int o0 = sxs[k] - wb, o1 = min(sxs[k] + 1, sw - 1) - wb;
+            const int a0 = (int)(short)(als[k] & 0xFFFF), a1 = (int)(short)(als[k] >> 16);
+            const int r0 = (int)pick_byte(a0w, a1w, a2w, o0) * a0 + (int)pick_byte(a0w, a1w, a2w, o1) * a1;
+            const int r1 = (int)pick_byte(c0w, c1w, c2w, o0) * a0 + (int)pick_byte(c0w, c1w, c2w, o1) * a1;
             const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
             out |= (uint32_t)(v & 255) << (8 * k);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int dx = dx4 + k;
+            if (dx < dw) {
+                const int sx = xofs[dx];
+                const int sx1 = min(sx + 1, sw - 1);
+                const int a0 = ialpha[2 * dx], a1 = ialpha[2 * dx + 1];
+                const int r0 = S0[sx] * a0 + S0[sx1] * a1;
+                const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+                const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                out |= (uint32_t)(v & 255) << (8 * k);
+            }
         }
     }
     *reinterpret_cast<uint32_t*>(dst + (size_t)f * dframe + (size_t)dy * dstride + dx4) = out;
@@ -61,7 +99,8 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
 #define SC_H (FT_H + 2)
 #define SC_S 68              // LDS score row stride
 
-__device__ __forceinline__ int fast_score16(const uint8_t* c, int t) {
+// full cornerScore<16> without the early exit (callers have already thinned the candidates)
+__device__ __forceinline__ int fast_score16_full(const uint8_t* c, int t) {
     const int S = PX_W;
     const int v = c[0];
     int d[16];
@@ -69,15 +108,6 @@ __device__ __forceinline__ int fast_score16(const uint8_t* c, int t) {
     d[4] = v - c[3];           d[5] = v - c[-S + 3];      d[6] = v - c[-2 * S + 2];  d[7] = v - c[-3 * S + 1];
     d[8] = v - c[-3 * S];      d[9] = v - c[-3 * S - 1];  d[10] = v - c[-2 * S - 2]; d[11] = v - c[-S - 3];
     d[12] = v - c[-3];         d[13] = v - c[S - 3];      d[14] = v - c[2 * S - 2];  d[15] = v - c[3 * S - 1];
-    // necessary condition for a 9-arc: every opposite pair has a member in the arc
-    int mn = 255, mx = -255;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        mn = min(mn, max(d[k], d[k + 8]));
-        mx = max(mx, min(d[k], d[k + 8]));
-    }
-    if (mn <= t && mx >= -t) return 0;
-    // A = max over the 16 arcs of min(d), Bv = max over arcs of min(-d) = -(min over arcs of max(d))
     int lo2[16], hi2[16], lo4[16], hi4[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
@@ -91,25 +121,51 @@ __device__ __forceinline__ int fast_score16(const uint8_t* c, int t) {
         A = max(A, lo9);
         Bm = min(Bm, hi9);
     }
-    const int s = max(A, -Bm) - 1;      // cornerScore<16>: largest threshold that still passes
+    const int s = max(A, -Bm) - 1;
     return s >= t ? s : 0;
 }
 
-__global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ img, int w, int h, int stride, size_t frame_bytes,
-                                              int threshold, int edge, uint32_t* __restrict__ cand, int cand_cap,
-                                              int32_t* __restrict__ cand_cnt, int32_t* __restrict__ hist, int level, int L) {
+// cheap necessary condition on 4 of the 8 opposite ring pairs (N/S, E/W and the two diagonals): a
+// 9-arc contains at least one pixel of every opposite pair, so all four pairs must show a pixel
+// darker than v-t (or all four a pixel brighter than v+t).  9 LDS byte reads, ~25 VALU ops.
+__device__ __forceinline__ bool fast_pretest(const uint8_t* c, int t) {
+    const int S = PX_W;
+    const int v = c[0];
+    const int n = v - c[3 * S], so = v - c[-3 * S], e = v - c[3], w = v - c[-3];
+    const int ne = v - c[2 * S + 2], sw = v - c[-2 * S - 2], se = v - c[-2 * S + 2], nw = v - c[2 * S - 2];
+    const int mn = min(min(max(n, so), max(e, w)), min(max(ne, sw), max(se, nw)));
+    const int mx = max(max(min(n, so), min(e, w)), max(min(ne, sw), min(se, nw)));
+    return mn > t || mx < -t;
+}
+
+struct FastLevel { const uint8_t* img; uint32_t* cand; size_t frame_bytes; int w, h, stride, cand_cap, tiles_x, tile_base; };
+struct FastArgs { FastLevel lv[VIS_MAX_LEVELS]; int L, total_tiles; };
+
+// ONE launch for all pyramid levels of all frames: blockIdx.x enumerates the 64x32 tiles of every level,
+// blockIdx.y the frame.  Phases: (A) pixel tile + halo -> LDS with dword loads, (B) pretest on every
+// score position, survivors are compacted into an LDS queue, (C) dense full cornerScore on the queue,
+// (D) 3x3 NMS + border cull on the scored survivors, packed candidates + score histogram.
+__global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edge, int32_t* __restrict__ cand_cnt,
+                                              int32_t* __restrict__ hist) {
     __shared__ __attribute__((aligned(16))) uint32_t px[PX_H * PX_W / 4];
     __shared__ uint8_t sc[SC_H * SC_S];
+    __shared__ uint16_t queue[SC_H * SC_W];
     __shared__ uint32_t lhist[256];
     __shared__ uint32_t lcand[FT_W * FT_H / 4];
-    __shared__ int lcount, gbase;
+    __shared__ int lcount, gbase, qn;
     const int tid = threadIdx.x;
-    const int ox = blockIdx.x * FT_W, oy = blockIdx.y * FT_H, f = blockIdx.z;
+    int level = 0;
+#pragma unroll 1
+    for (int l = 1; l < F.L; l++) if ((int)blockIdx.x >= F.lv[l].tile_base) level = l;
+    const FastLevel V = F.lv[level];
+    const int tile = blockIdx.x - V.tile_base;
+    const int ox = (tile % V.tiles_x) * FT_W, oy = (tile / V.tiles_x) * FT_H, f = blockIdx.y;
+    const int w = V.w, h = V.h, stride = V.stride;
     // tiles that cannot emit (entirely inside the culled border) do nothing
     if (ox + FT_W <= edge || ox >= w - edge || oy + FT_H <= edge || oy >= h - edge) return;
-    const uint8_t* base = img + (size_t)f * frame_bytes;
+    const uint8_t* base = V.img + (size_t)f * V.frame_bytes;
     lhist[tid] = 0;
-    if (tid == 0) lcount = 0;
+    if (tid == 0) { lcount = 0; qn = 0; }
     for (int wv = tid; wv < PX_H * (PX_W / 4); wv += 256) {
         const int r = wv / (PX_W / 4), cw = wv % (PX_W / 4);
         const int gx = ox - 4 + cw * 4, gy = oy - 4 + r;
@@ -118,23 +174,44 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ img, i
             v = *reinterpret_cast<const uint32_t*>(base + (size_t)gy * stride + gx);
         px[wv] = v;
     }
+    for (int i = tid; i < SC_H * SC_S / 4; i += 256) reinterpret_cast<uint32_t*>(sc)[i] = 0;
     __syncthreads();
     const uint8_t* pxb = reinterpret_cast<const uint8_t*>(px);
     // real scores are needed one pixel beyond the emit region (NMS neighbours), nowhere else
     const int lox = max(3, edge - 1), hix = min(w - 3, w - edge + 1);
     const int loy = max(3, edge - 1), hiy = min(h - 3, h - edge + 1);
-    for (int i = tid; i < SC_H * SC_W; i += 256) {
-        const int sy = i / SC_W, sx = i % SC_W;
-        const int gx = ox - 1 + sx, gy = oy - 1 + sy;
-        int s = 0;
-        if (gx >= lox && gx < hix && gy >= loy && gy < hiy) s = fast_score16(pxb + (sy + 3) * PX_W + (sx + 3), threshold);
+    {
+        const int tx = tid & 63, ty = tid >> 6;
+        for (int sy = ty; sy < SC_H; sy += 4) {
+            const int gy = oy - 1 + sy;
+            const bool rowok = gy >= loy && gy < hiy;
+            {
+                const int sx = tx, gx = ox - 1 + sx;
+                if (rowok && gx >= lox && gx < hix && fast_pretest(pxb + (sy + 3) * PX_W + (sx + 3), threshold))
+                    queue[atomicAdd(&qn, 1)] = (uint16_t)(sy * SC_W + sx);
+            }
+            if (tx < 2) {                                          // score columns 64, 65
+                const int sx = 64 + tx, gx = ox - 1 + sx;
+                if (rowok && gx >= lox && gx < hix && fast_pretest(pxb + (sy + 3) * PX_W + (sx + 3), threshold))
+                    queue[atomicAdd(&qn, 1)] = (uint16_t)(sy * SC_W + sx);
+            }
+        }
+    }
+    __syncthreads();
+    const int nq = qn;
+    for (int i = tid; i < nq; i += 256) {
+        const int pos = queue[i];
+        const int sy = pos / SC_W, sx = pos - sy * SC_W;
+        const int s = fast_score16_full(pxb + (sy + 3) * PX_W + (sx + 3), threshold);
         sc[sy * SC_S + sx] = (uint8_t)s;
     }
     __syncthreads();
-    for (int i = tid; i < FT_W * FT_H; i += 256) {
-        const int ty = i / FT_W, tx = i % FT_W;
-        const int gx = ox + tx, gy = oy + ty;
-        const uint8_t* p = sc + (ty + 1) * SC_S + (tx + 1);
+    for (int i = tid; i < nq; i += 256) {
+        const int pos = queue[i];
+        const int sy = pos / SC_W, sx = pos - sy * SC_W;
+        const int gx = ox - 1 + sx, gy = oy - 1 + sy;
+        if (sx < 1 || sx > FT_W || sy < 1 || sy > FT_H) continue;     // halo positions belong to neighbour tiles
+        const uint8_t* p = sc + sy * SC_S + sx;
         const int s = p[0];
         if (s && gx >= edge && gx < w - edge && gy >= edge && gy < h - edge &&
             s > p[-1] && s > p[1] && s > p[-SC_S - 1] && s > p[-SC_S] && s > p[-SC_S + 1] &&
@@ -147,12 +224,12 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ img, i
     __syncthreads();
     const int n = lcount;
     if (n == 0) return;
-    const int seg = f * L + level;
+    const int seg = f * F.L + level;
     if (tid == 0) gbase = atomicAdd(&cand_cnt[seg], n);
     __syncthreads();
     const int gb = gbase;
     for (int i = tid; i < n; i += 256)
-        if (gb + i < cand_cap) cand[(size_t)f * cand_cap + gb + i] = lcand[i];
+        if (gb + i < V.cand_cap) V.cand[(size_t)f * V.cand_cap + gb + i] = lcand[i];
     if (lhist[tid]) atomicAdd(&hist[(size_t)seg * 256 + tid], (int)lhist[tid]);
 }
 
@@ -382,9 +459,22 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
     uint8_t* raw = lds + wv * WAVE_LDS;
     uint16_t* hb = reinterpret_cast<uint16_t*>(raw + PW * PS);
     const uint8_t* img = A.img + (size_t)f * A.frame_bytes + (size_t)(y0 - PR) * A.stride + (x0 - PR);
-    for (int i = lane; i < PW * PW; i += 64) {
-        const int r = i / PW, c = i - r * PW;
-        raw[r * PS + c] = img[(size_t)r * A.stride + c];
+    // 43 rows x 44 bytes as 11 unaligned dwords per row: 473 dwords = 8 wave-wide loads, all in flight
+    // before the first LDS write (the patch of a kept keypoint is >= 9 px inside the image)
+    {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = lane + 64 * k;
+            const int r = i / 11, c = i - r * 11;
+            v[k] = (i < PW * 11) ? *reinterpret_cast<const u32_unaligned*>(img + (size_t)r * A.stride + 4 * c) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = lane + 64 * k;
+            const int r = i / 11, c = i - r * 11;
+            if (i < PW * 11) *reinterpret_cast<uint32_t*>(raw + r * PS + 4 * c) = v[k];
+        }
     }
     WAVE_SYNC();
     // IC angle over the radius-15 disc
@@ -400,14 +490,38 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
-    // horizontal 7-tap pass over all 43 rows, patch columns 3..39
-    for (int i = lane; i < PW * HW; i += 64) {
-        const int r = i / HW, c = i - r * HW;
-        const uint8_t* p = raw + r * PS + c;
-        int s = 0;
+    // horizontal 7-tap pass over all 43 rows, patch columns 3..39: one task = (row, 13-wide segment) with a
+    // sliding window over 19 source bytes (5 dword reads); 43*3 = 129 tasks
+    for (int task = lane; task < PW * 3; task += 64) {
+        const int r = task / 3, sg = task - r * 3;
+        const int c0 = sg * 13;                                   // outputs c0 .. c0+12 (segment 2: 26..36 -> 11)
+        const uint8_t* p = raw + r * PS + c0;                     // needs bytes p[0 .. 18]
+        const int al = c0 & 3;
+        const uint32_t* pw = reinterpret_cast<const uint32_t*>(p - al);
+        uint32_t w[6];
 #pragma unroll
-        for (int k = 0; k < 7; k++) s += G.kq[k] * p[k];
-        hb[r * HS + c] = (uint16_t)s;                 // <= 255*257 = 65535
+        for (int k = 0; k < 6; k++) w[k] = (al + 19 > 4 * k) ? pw[k] : 0u;
+        int b[19];
+#pragma unroll
+        for (int k = 0; k < 19; k++) {
+            const int o = al + k;
+            // al is 0,1,2 (c0 = 0,13,26): resolve the dynamic byte offset with a funnel shift
+            const uint32_t lo = w[k >> 2], mid = w[(k >> 2) + 1];
+            const int sh = (o & 3);
+            const int wi = o >> 2;
+            const uint32_t word = (wi == (k >> 2)) ? lo : mid;
+            b[k] = (int)((word >> (sh * 8)) & 0xFFu);
+        }
+        const int nout = sg == 2 ? HW - 26 : 13;
+#pragma unroll
+        for (int j = 0; j < 13; j++) {
+            if (j < nout) {
+                int sacc = 0;
+#pragma unroll
+                for (int k = 0; k < 7; k++) sacc += G.kq[k] * b[j + k];
+                hb[r * HS + c0 + j] = (uint16_t)sacc;             // <= 255*257 = 65535
+            }
+        }
     }
     WAVE_SYNC();
     float ang = angle;
@@ -509,13 +623,20 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
                            pl->d_xofs[l], pl->d_ialpha[l], pl->d_yofs[l], pl->d_ibeta[l]);
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[1], st);
-    for (int l = 0; l < L; l++) {
-        const LevelInfo& V = pl->lv[l];
-        dim3 grid(V.tiles_x, V.tiles_y, n);
-        hipLaunchKernelGGL(k_fast, grid, dim3(256), 0, st, D.lv[l].img, V.w, V.h, V.stride, V.frame_bytes,
-                           ctx->p.fast_threshold, ctx->p.edge_threshold, pl->d_cand[l], V.cand_cap,
-                           pl->d_cand_cnt, pl->d_hist, l, L);
-        nfast++;
+    {
+        FastArgs FA; FA.L = L;
+        int tb = 0;
+        for (int l = 0; l < L; l++) {
+            const LevelInfo& V = pl->lv[l];
+            FA.lv[l].img = D.lv[l].img; FA.lv[l].cand = pl->d_cand[l]; FA.lv[l].frame_bytes = V.frame_bytes;
+            FA.lv[l].w = V.w; FA.lv[l].h = V.h; FA.lv[l].stride = V.stride; FA.lv[l].cand_cap = V.cand_cap;
+            FA.lv[l].tiles_x = V.tiles_x; FA.lv[l].tile_base = tb;
+            tb += V.tiles_x * V.tiles_y;
+        }
+        FA.total_tiles = tb;
+        hipLaunchKernelGGL(k_fast, dim3(tb, n), dim3(256), 0, st, FA, ctx->p.fast_threshold, ctx->p.edge_threshold,
+                           pl->d_cand_cnt, pl->d_hist);
+        nfast = 1;
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[2], st);
     int max_surv = 0; for (int l = 0; l < L; l++) max_surv = std::max(max_surv, pl->lv[l].surv_cap);
@@ -526,7 +647,7 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
                        pl->d_kps, pl->d_desc, pl->d_nkp, pl->kcap, rec0, pl->d_flags);
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[4], st);
     ctx->tm.launches_fast = nfast;
-    ctx->tm.launches_total = 2 * L - 1 + 2;
+    ctx->tm.launches_total = (L - 1) + 1 + 2;
     HIPCHK(ctx, hipGetLastError());
     return VIS_OK;
 }

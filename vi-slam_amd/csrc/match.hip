@@ -28,15 +28,31 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ desc, 
     const uint4 qa = Q[0], qb = Q[1];
     const uint4* T = reinterpret_cast<const uint4*>(desc + (size_t)rt * kcap * 32);
     uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
-    for (int t = 0; t < nt; t++) {
-        const uint4 ta = T[2 * t], tb = T[2 * t + 1];
-        uint32_t d = __popc(qa.x ^ ta.x);
-        d += __popc(qa.y ^ ta.y); d += __popc(qa.z ^ ta.z); d += __popc(qa.w ^ ta.w);
-        d += __popc(qb.x ^ tb.x); d += __popc(qb.y ^ tb.y); d += __popc(qb.z ^ tb.z); d += __popc(qb.w ^ tb.w);
-        const uint32_t key = (d << 16) | (uint32_t)t;
-        k1 = min(k1, max(k0, key));
-        k0 = min(k0, key);
+#define KNN_STEP(ta, tb, tt) do {                                                                   \
+        uint32_t d_ = __popc(qa.x ^ (ta).x);                                                        \
+        d_ += __popc(qa.y ^ (ta).y); d_ += __popc(qa.z ^ (ta).z); d_ += __popc(qa.w ^ (ta).w);      \
+        d_ += __popc(qb.x ^ (tb).x); d_ += __popc(qb.y ^ (tb).y); d_ += __popc(qb.z ^ (tb).z);      \
+        d_ += __popc(qb.w ^ (tb).w);                                                                \
+        const uint32_t key_ = (d_ << 16) | (uint32_t)(tt);                                          \
+        k1 = min(k1, max(k0, key_));                                                                \
+        k0 = min(k0, key_); } while (0)
+    // the train descriptors are wave-uniform (SGPRs): groups of KNN_U rows are fetched with back-to-back
+    // scalar loads (s_load_dwordx16) so one load latency is paid per group, not per row; the other waves
+    // of the SIMD cover it with their xor/popcount work
+    constexpr int KNN_U = 8;
+    const int ntU = nt & ~(KNN_U - 1);
+    for (int t = 0; t < ntU; t += KNN_U) {
+        uint4 cur[2 * KNN_U];
+#pragma unroll
+        for (int j = 0; j < 2 * KNN_U; j++) cur[j] = T[2 * t + j];
+#pragma unroll
+        for (int u = 0; u < KNN_U; u++) KNN_STEP(cur[2 * u], cur[2 * u + 1], t + u);
     }
+    for (int t = ntU; t < nt; t++) {
+        const uint4 ta = T[2 * t], tb = T[2 * t + 1];
+        KNN_STEP(ta, tb, t);
+    }
+#undef KNN_STEP
     if (q < nq) {
         uint32_t* out = (dir == 0 ? knn12 : knn21) + ((size_t)pair * kcap + q) * 2;
         out[0] = k0; out[1] = k1;
