@@ -82,8 +82,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="frames per step (per GPU)")
-    ap.add_argument("--ring", type=int, default=4, help="distinct batches resident in HBM")
+    ap.add_argument("--batch", type=int, default=256, help="frames per step (per GPU)")
+    ap.add_argument("--ring", type=int, default=2, help="distinct batches resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 

@@ -71,6 +71,10 @@ extern "C" int vis_create(int device, vis_ctx** out) {
     for (int i = 0; i < VIS_NSLOTS; i++) ctx->slot_valid[i] = 0;
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return VIS_E_HIP; }
     ctx->stream = ctx->own_stream;
+    if (hipStreamCreateWithFlags(&ctx->pose_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_filter_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_pose_done, hipEventDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_pose_start, hipEventDefault) != hipSuccess) { delete ctx; return VIS_E_HIP; }
     ctx->ev_ok = true;
     for (int i = 0; i < 10; i++) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) ctx->ev_ok = false;
     *out = ctx;
@@ -81,12 +85,23 @@ extern "C" void vis_destroy(vis_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->pose_stream) (void)hipStreamSynchronize(ctx->pose_stream);
     plan_destroy(ctx->single); plan_destroy(ctx->batch);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_sample_table) (void)hipFree(ctx->d_sample_table);
     for (int i = 0; i < 10; i++) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->pose_stream) { (void)hipStreamSynchronize(ctx->pose_stream); (void)hipStreamDestroy(ctx->pose_stream); }
+    if (ctx->ev_filter_done) (void)hipEventDestroy(ctx->ev_filter_done);
+    if (ctx->ev_pose_done) (void)hipEventDestroy(ctx->ev_pose_done);
+    if (ctx->ev_pose_start) (void)hipEventDestroy(ctx->ev_pose_start);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
+}
+
+static void sync_all(vis_ctx* ctx) {
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->pose_stream) (void)hipStreamSynchronize(ctx->pose_stream);
+    ctx->pose_pending = false;
 }
 
 extern "C" const char* vis_last_error(vis_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -95,7 +110,7 @@ extern "C" int vis_set_params(vis_ctx* ctx, const vis_params* p) {
     if (!ctx || !p) return VIS_E_INVALID;
     int rc = validate_params(*p);
     if (rc) return rc;
-    (void)hipStreamSynchronize(ctx->stream);
+    sync_all(ctx);
     ctx->p = *p;
     // geometry depends on the params: drop plans (re-created lazily / by vis_batch_plan)
     plan_destroy(ctx->single); ctx->single = nullptr;
@@ -112,7 +127,7 @@ extern "C" int vis_get_params(vis_ctx* ctx, vis_params* p) {
 
 extern "C" int vis_set_stream(vis_ctx* ctx, void* s) {
     if (!ctx) return VIS_E_INVALID;
-    (void)hipStreamSynchronize(ctx->stream);
+    sync_all(ctx);
     ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
     return VIS_OK;
 }
@@ -620,7 +635,7 @@ extern "C" int vis_f2f_ransac(vis_ctx* ctx, const vis_keypoint* pts1, const vis_
 extern "C" int vis_batch_plan(vis_ctx* ctx, int w, int h, int stride, int max_frames) {
     if (!ctx || max_frames < 1 || max_frames > 4096) return VIS_E_INVALID;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    sync_all(ctx);
     plan_destroy(ctx->batch); ctx->batch = nullptr;
     return plan_create(ctx, w, h, stride, max_frames, max_frames + 1, max_frames, &ctx->batch);
 }
@@ -658,10 +673,27 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
     rc = VIS_OK;
     if (stages & VIS_STAGE_MATCH) {
         rc = launch_match(ctx, pl, n);
-        if (!rc) { if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[5], st); rc = launch_filter(ctx, pl, n); }
+        if (!rc) {
+            if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[5], st);
+            // the filter rewrites the pose inputs of the previous batch: wait until its pose work is done
+            if (ctx->pose_pending) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_pose_done, 0));
+            rc = launch_filter(ctx, pl, n);
+        }
         if (!rc && ctx->ev_ok) (void)hipEventRecord(ctx->ev[6], st);
     } else if (ctx->ev_ok) { (void)hipEventRecord(ctx->ev[5], st); (void)hipEventRecord(ctx->ev[6], st); }
-    if (!rc && (stages & VIS_STAGE_POSE)) rc = launch_pose(ctx, pl, n);
+    if (!rc && (stages & VIS_STAGE_POSE)) {
+        // RANSAC + recoverPose run on a second stream: 1 wave per frame pair is latency- not
+        // throughput-bound, so it overlaps the next batch's detect/describe/knn on the main stream
+        HIPCHK(ctx, hipEventRecord(ctx->ev_filter_done, st));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->pose_stream, ctx->ev_filter_done, 0));
+        hipStream_t saved = ctx->stream;
+        ctx->stream = ctx->pose_stream;
+        (void)hipEventRecord(ctx->ev_pose_start, ctx->pose_stream);
+        rc = launch_pose(ctx, pl, n);
+        (void)hipEventRecord(ctx->ev_pose_done, ctx->pose_stream);
+        ctx->stream = saved;
+        ctx->pose_pending = true;
+    }
     pl->d_pair_q = saved_q;
     if (rc) return rc;
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[7], st);
@@ -674,20 +706,25 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
 extern "C" int vis_batch_sync(vis_ctx* ctx) {
     if (!ctx) return VIS_E_INVALID;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const bool had_pose = ctx->pose_pending;
+    if (ctx->pose_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->pose_stream));
+    ctx->pose_pending = false;
     if (ctx->ev_ok) {
         collect_detect_timings(ctx);
         float a = 0;
         if (hipEventElapsedTime(&a, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->tm.ms_knn = a;
         if (hipEventElapsedTime(&a, ctx->ev[5], ctx->ev[6]) == hipSuccess) ctx->tm.ms_filter = a;
-        if (hipEventElapsedTime(&a, ctx->ev[6], ctx->ev[7]) == hipSuccess) ctx->tm.ms_pose = a;
+        ctx->tm.ms_pose = 0;
+        if (had_pose && hipEventElapsedTime(&a, ctx->ev_pose_start, ctx->ev_pose_done) == hipSuccess) ctx->tm.ms_pose = a;
         if (hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[8]) == hipSuccess) ctx->tm.ms_total = a;
+        if (had_pose && hipEventElapsedTime(&a, ctx->ev[0], ctx->ev_pose_done) == hipSuccess && a > ctx->tm.ms_total) ctx->tm.ms_total = a;
     }
     return VIS_OK;
 }
 
 extern "C" int vis_batch_status(vis_ctx* ctx, int* flags) {
     if (!ctx || !ctx->batch || !flags) return VIS_E_STATE;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    sync_all(ctx);
     int32_t fl = 0;
     HIPCHK(ctx, hipMemcpy(&fl, ctx->batch->d_flags, 4, hipMemcpyDeviceToHost));
     *flags = fl;
@@ -698,7 +735,7 @@ extern "C" int vis_batch_get_keypoints(vis_ctx* ctx, int frame, vis_keypoint* kp
     if (!ctx || !ctx->batch) return VIS_E_STATE;
     Plan* pl = ctx->batch;
     if (frame < 0 || frame >= pl->last_n) return VIS_E_INVALID;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    sync_all(ctx);
     int32_t n = 0;
     HIPCHK(ctx, hipMemcpy(&n, pl->d_nkp + frame + 1, 4, hipMemcpyDeviceToHost));
     if (n_out) *n_out = n;
@@ -713,7 +750,7 @@ extern "C" int vis_batch_get_knn(vis_ctx* ctx, int frame, vis_dmatch* out12, int
     if (!ctx || !ctx->batch) return VIS_E_STATE;
     Plan* pl = ctx->batch;
     if (frame < 0 || frame >= pl->last_n) return VIS_E_INVALID;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    sync_all(ctx);
     int32_t nq = 0, nt = 0;
     HIPCHK(ctx, hipMemcpy(&nq, pl->d_nkp + frame, 4, hipMemcpyDeviceToHost));
     HIPCHK(ctx, hipMemcpy(&nt, pl->d_nkp + frame + 1, 4, hipMemcpyDeviceToHost));
@@ -729,7 +766,7 @@ extern "C" int vis_batch_get_matches(vis_ctx* ctx, int frame, vis_dmatch* good, 
     if (!ctx || !ctx->batch) return VIS_E_STATE;
     Plan* pl = ctx->batch;
     if (frame < 0 || frame >= pl->last_n) return VIS_E_INVALID;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    sync_all(ctx);
     return download_matches(ctx, pl, frame, good, cap, n_good, nullptr, 0, n_sym);
 }
 
@@ -738,7 +775,7 @@ extern "C" int vis_batch_get_pose(vis_ctx* ctx, int frame, double E[9], double R
     if (!ctx || !ctx->batch) return VIS_E_STATE;
     Plan* pl = ctx->batch;
     if (frame < 0 || frame >= pl->last_n) return VIS_E_INVALID;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    sync_all(ctx);
     PoseOut o;
     HIPCHK(ctx, hipMemcpy(&o, pl->d_pose + frame, sizeof(PoseOut), hipMemcpyDeviceToHost));
     if (E) std::memcpy(E, o.E, 72);

@@ -88,6 +88,9 @@ struct vis_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t pose_stream = nullptr;       // RANSAC/pose of batch i overlaps detect/match of batch i+1
+    hipEvent_t ev_filter_done = nullptr, ev_pose_done = nullptr, ev_pose_start = nullptr;
+    bool pose_pending = false;
     vis_params p;
     std::string err;
     Plan* single = nullptr;
