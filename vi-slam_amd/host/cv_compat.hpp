@@ -1,0 +1,45 @@
+// cv_compat.hpp -- the handful of OpenCV value types the reference's Camera/Matcher/VISystem surface
+// uses, so the adapter classes build where OpenCV is absent (this image, the GPU box).  Field order
+// and sizes match OpenCV's (cv::KeyPoint 28 B == vis_keypoint, cv::DMatch 16 B == vis_dmatch); on a
+// machine with OpenCV, define VISLAM_USE_OPENCV and the real headers are used instead.
+#ifndef VISLAM_CV_COMPAT_HPP_
+#define VISLAM_CV_COMPAT_HPP_
+#ifdef VISLAM_USE_OPENCV
+#include <opencv2/core.hpp>
+#else
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+namespace cv {
+typedef std::string String;
+template <class T> struct Point_ { T x, y; Point_() : x(0), y(0) {} Point_(T a, T b) : x(a), y(b) {} };
+typedef Point_<float> Point2f; typedef Point_<double> Point2d;
+template <class T> struct Point3_ { T x, y, z; Point3_() : x(0), y(0), z(0) {} Point3_(T a, T b, T c) : x(a), y(b), z(c) {} };
+typedef Point3_<float> Point3f; typedef Point3_<double> Point3d;
+struct KeyPoint { Point2f pt; float size, angle, response; int octave, class_id;
+                  KeyPoint() : size(0), angle(-1), response(0), octave(0), class_id(-1) {} };
+struct DMatch { int queryIdx, trainIdx, imgIdx; float distance;
+                DMatch() : queryIdx(-1), trainIdx(-1), imgIdx(-1), distance(3.402823466e+38f) {}
+                DMatch(int q, int t, float d) : queryIdx(q), trainIdx(t), imgIdx(-1), distance(d) {}
+                bool operator<(const DMatch& m) const { return distance < m.distance; } };
+static_assert(sizeof(KeyPoint) == 28 && sizeof(DMatch) == 16, "layout must match the C ABI");
+enum { CV_8U = 0 };
+// minimal 8-bit single-channel matrix with shared storage (enough for grayImage / descriptors)
+struct Mat {
+    int rows = 0, cols = 0; size_t step = 0; uint8_t* data = nullptr;
+    std::shared_ptr<std::vector<uint8_t>> store;
+    Mat() {}
+    Mat(int r, int c, int /*type*/) { create(r, c, CV_8U); }
+    void create(int r, int c, int /*type*/) { rows = r; cols = c; step = (size_t)c; store = std::make_shared<std::vector<uint8_t>>((size_t)r * c); data = store->data(); }
+    bool empty() const { return rows == 0 || cols == 0; }
+    void release() { rows = cols = 0; step = 0; data = nullptr; store.reset(); }
+    Mat clone() const { Mat m; if (!empty()) { m.create(rows, cols, CV_8U); for (int y = 0; y < rows; y++) std::memcpy(m.data + (size_t)y * m.step, data + (size_t)y * step, (size_t)cols); } return m; }
+    void copyTo(Mat& m) const { m = clone(); }
+    Mat rowRange(int a, int b) const { Mat m = *this; m.data = data + (size_t)a * step; m.rows = b - a; return m; }
+};
+template <class T> using Ptr = std::shared_ptr<T>;
+}  // namespace cv
+#endif
+#endif
