@@ -640,6 +640,9 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[2], st);
     int max_surv = 0; for (int l = 0; l < L; l++) max_surv = std::max(max_surv, pl->lv[l].surv_cap);
+    if ((size_t)max_surv * 8 + 16 > 65536) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (160 KiB per CU on gfx950)
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)max_surv * 8 + 16)));
+    }
     hipLaunchKernelGGL(k_select, dim3(L, n), dim3(256), (size_t)max_surv * 8 + 16, st, D, pl->d_cand_cnt, pl->d_hist,
                        pl->d_seg_cnt, pl->d_flags, max_surv);
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[3], st);

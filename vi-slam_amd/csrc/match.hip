@@ -203,6 +203,8 @@ int launch_filter(vis_ctx* ctx, Plan* pl, int npairs) {
     if (npairs <= 0) return VIS_OK;
     int keys_cap = 2; while (keys_cap < pl->kcap) keys_cap <<= 1;
     const size_t lds = (size_t)keys_cap * 8 + (size_t)pl->root * pl->root * 4 + 256 * 4 + 16;
+    if (lds > 160 * 1024) return VIS_E_CAPACITY;
+    if (lds > 65536) HIPCHK(ctx, hipFuncSetAttribute((const void*)k_filter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_filter, dim3(npairs), dim3(256), lds, ctx->stream, pl->d_kps, pl->d_nkp, pl->kcap,
                        pl->d_pair_q, pl->d_pair_t, pl->d_knn12, pl->d_knn21, (double)ctx->p.ratio, ctx->p.sym_mode,
                        pl->root, pl->d_hf, pl->d_wf, pl->d_sym, pl->d_nsym, pl->d_good, pl->d_ngood,
