@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc CSVs (one directory per counter pass) into profiles/pmc_traffic.json.
+usage: pmc_summarize.py OUTDIR B  where OUTDIR holds pass_*/**/*counter_collection.csv"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out_dir, B = sys.argv[1], int(sys.argv[2])
+acc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0]
+        acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+summary = {}
+for k, cs in acc.items():
+    summary[k] = {c: {"calls": len(v), "mean": sum(v) / len(v)} for c, v in cs.items()}
+# calibration: the 256 MiB device-to-device copy = the largest copyBuffer dispatch of each pass
+known = 256 << 20
+cal = {}
+for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "copyBuffer" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            cal[r["Counter_Name"]] = max(cal.get(r["Counter_Name"], 0.0), float(r["Counter_Value"]))
+res = {"batch_frames": B, "raw": summary,
+       "calibration": {"known_bytes_each_way": known, "FETCH_SIZE_units": cal.get("FETCH_SIZE"), "WRITE_SIZE_units": cal.get("WRITE_SIZE"),
+                       "fetch_bytes_per_unit": known / cal["FETCH_SIZE"] if cal.get("FETCH_SIZE") else None,
+                       "write_bytes_per_unit": known / cal["WRITE_SIZE"] if cal.get("WRITE_SIZE") else None,
+                       "note": "MI355X_MICROARCH.md 'HBM': on gfx950 FETCH_SIZE (KB) reports half of a coalesced streaming read, "
+                               "WRITE_SIZE (KB) is exact; the factors here are measured on a 256 MiB copy in the same run"}}
+fb = res["calibration"]["fetch_bytes_per_unit"] or 2048.0
+wb = res["calibration"]["write_bytes_per_unit"] or 1024.0
+for k in ("k_fast", "k_resize", "k_describe", "k_knn2", "k_select", "k_filter", "k_ransac_hyp"):
+    if k in summary and "FETCH_SIZE" in summary[k]:
+        f = summary[k]["FETCH_SIZE"]["mean"]
+        w = summary[k].get("WRITE_SIZE", {}).get("mean", 0.0)
+        res[k] = {"hbm_bytes_per_launch": f * fb + w * wb, "fetch_units": f, "write_units": w}
+        sq = summary[k]
+        if "SQ_INSTS_VALU" in sq:
+            res[k]["valu_wave_insts_per_launch"] = sq["SQ_INSTS_VALU"]["mean"]
+            res[k]["lds_wave_insts_per_launch"] = sq.get("SQ_INSTS_LDS", {}).get("mean")
+            res[k]["lds_bank_conflict_cycles"] = sq.get("SQ_LDS_BANK_CONFLICT", {}).get("mean")
+json.dump(res, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in res.items() if k != "raw"}, indent=1))

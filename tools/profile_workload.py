@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Workload for rocprofv3 PMC passes: a few batched steps of the bench configuration (B frames of S-752)
+plus one device-to-device copy of known size that calibrates FETCH_SIZE/WRITE_SIZE on this box
+(MI355X_MICROARCH.md 'HBM': gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x; other access
+widths must be calibrated on a known byte count).  Run as:
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d OUT -- python3 tools/profile_workload.py
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "vi-slam_amd"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import vislam  # noqa: E402
+
+B = int(os.environ.get("VIS_PROFILE_BATCH", "256"))
+STEPS = int(os.environ.get("VIS_PROFILE_STEPS", "3"))
+W, H = 752, 480
+p = vislam.default_params()
+p.fy = p.fx
+ctx = vislam.Context(0, p)
+cv = vislam.synth_canvas(4096, 0xE0C00001)
+fr = np.empty((B, H, W), np.uint8)
+for t in range(B):
+    vislam.synth_frame(cv, t, W, H, 0xE0C00001, out=fr[t])
+d = torch.from_numpy(fr).cuda()
+ctx.batch_plan(W, H, W, B)
+# flush the 256 MiB Infinity Cache between steps with a 1 GiB fill so every step reads its frames from HBM
+junk = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+cal_src = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+cal_dst = torch.empty_like(cal_src)
+for i in range(STEPS):
+    junk.fill_(i)
+    torch.cuda.synchronize()
+    ctx.batch_run(d.data_ptr(), B)
+    ctx.batch_sync()
+junk.fill_(7)
+torch.cuda.synchronize()
+cal_dst.copy_(cal_src)          # calibration: 256 MiB read + 256 MiB written
+torch.cuda.synchronize()
+print("status", ctx.batch_status(), "B", B)
+ctx.close()

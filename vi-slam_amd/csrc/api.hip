@@ -170,7 +170,7 @@ void plan_destroy(Plan* pl) {
         F(pl->d_pyr[l]); F(pl->d_xofs[l]); F(pl->d_ialpha[l]); F(pl->d_yofs[l]); F(pl->d_ibeta[l]);
         F(pl->d_cand[l]); F(pl->d_seg_kp[l]);
     }
-    F(pl->d_cand_cnt); F(pl->d_hist); F(pl->d_seg_cnt); F(pl->d_flags);
+    F(pl->d_cand_cnt); F(pl->d_hist); F(pl->d_seg_cnt); F(pl->d_flags); F(pl->d_angle_tab);
     F(pl->d_kps); F(pl->d_desc); F(pl->d_nkp);
     F(pl->d_pair_q); F(pl->d_pair_t); F(pl->d_pair_q_noprev); F(pl->d_knn12); F(pl->d_knn21);
     F(pl->d_sym); F(pl->d_nsym); F(pl->d_good); F(pl->d_ngood); F(pl->d_p1); F(pl->d_p2); F(pl->d_hf); F(pl->d_wf);

@@ -27,6 +27,19 @@
 // coefficient tables as one 16-byte vector each; bytes are picked with v_alignbyte.
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 
+// XCD-aware work mapping.  Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8), each
+// with a private 4 MiB L2.  All work of one frame is given to ONE XCD so that halo rows, overlapping
+// keypoint patches and resize source rows that neighbouring workgroups share are L2 hits instead of 8
+// separate fabric fetches (rocprofv3 FETCH_SIZE was 4.1x the algorithmic bytes for k_fast before this).
+// Speed only: results do not depend on the placement.  Grid = 8 * ceil(n/8) * per_frame blocks.
+__device__ __forceinline__ bool xcd_frame_map(int b, int per_frame, int n, int& frame, int& inner) {
+    const int xcd = b & 7, j = b >> 3;
+    frame = (j / per_frame) * 8 + xcd;
+    inner = j - (j / per_frame) * per_frame;
+    return frame < n;
+}
+static inline int xcd_grid(int n, int per_frame) { return 8 * ((n + 7) / 8) * per_frame; }
+
 __device__ __forceinline__ uint32_t pick_byte(uint32_t w0, uint32_t w1, uint32_t w2, int off) {
     // byte `off` (0..11) of the 12-byte little-endian string w0|w1|w2
     const uint32_t lo = off < 4 ? w0 : (off < 8 ? w1 : w2);
@@ -36,10 +49,12 @@ __device__ __forceinline__ uint32_t pick_byte(uint32_t w0, uint32_t w1, uint32_t
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, int sw, int sstride, size_t sframe,
                                                 uint8_t* __restrict__ dst, int dw, int dh, int dstride, size_t dframe,
                                                 const int32_t* __restrict__ xofs, const int16_t* __restrict__ ialpha,
-                                                const int32_t* __restrict__ yofs, const int16_t* __restrict__ ibeta) {
-    const int dx4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int dy = blockIdx.y * 4 + threadIdx.y;
-    const int f = blockIdx.z;
+                                                const int32_t* __restrict__ yofs, const int16_t* __restrict__ ibeta,
+                                                int bx_count, int per_frame, int nframes) {
+    int f, inner;
+    if (!xcd_frame_map(blockIdx.x, per_frame, nframes, f, inner)) return;
+    const int dx4 = ((inner % bx_count) * 64 + threadIdx.x) * 4;
+    const int dy = (inner / bx_count) * 4 + threadIdx.y;
     if (dx4 >= dw || dy >= dh) return;
     const int2 ys = *reinterpret_cast<const int2*>(yofs + 2 * dy);
     const uint32_t bb = *reinterpret_cast<const uint32_t*>(ibeta + 2 * dy);
@@ -146,7 +161,7 @@ struct FastArgs { FastLevel lv[VIS_MAX_LEVELS]; int L, total_tiles; };
 // score position, survivors are compacted into an LDS queue, (C) dense full cornerScore on the queue,
 // (D) 3x3 NMS + border cull on the scored survivors, packed candidates + score histogram.
 __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edge, int32_t* __restrict__ cand_cnt,
-                                              int32_t* __restrict__ hist) {
+                                              int32_t* __restrict__ hist, int nframes) {
     __shared__ __attribute__((aligned(16))) uint32_t px[PX_H * PX_W / 4];
     __shared__ uint8_t sc[SC_H * SC_S];
     __shared__ uint16_t queue[SC_H * SC_W];
@@ -154,12 +169,14 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edg
     __shared__ uint32_t lcand[FT_W * FT_H / 4];
     __shared__ int lcount, gbase, qn;
     const int tid = threadIdx.x;
+    int f, gtile;
+    if (!xcd_frame_map(blockIdx.x, F.total_tiles, nframes, f, gtile)) return;
     int level = 0;
 #pragma unroll 1
-    for (int l = 1; l < F.L; l++) if ((int)blockIdx.x >= F.lv[l].tile_base) level = l;
+    for (int l = 1; l < F.L; l++) if (gtile >= F.lv[l].tile_base) level = l;
     const FastLevel V = F.lv[level];
-    const int tile = blockIdx.x - V.tile_base;
-    const int ox = (tile % V.tiles_x) * FT_W, oy = (tile / V.tiles_x) * FT_H, f = blockIdx.y;
+    const int tile = gtile - V.tile_base;
+    const int ox = (tile % V.tiles_x) * FT_W, oy = (tile / V.tiles_x) * FT_H;
     const int w = V.w, h = V.h, stride = V.stride;
     // tiles that cannot emit (entirely inside the culled border) do nothing
     if (ox + FT_W <= edge || ox >= w - edge || oy + FT_H <= edge || oy >= h - edge) return;
@@ -281,11 +298,12 @@ __device__ float harris7(const uint8_t* __restrict__ img, int stride, int x, int
 
 __global__ __launch_bounds__(256) void k_select(DetLevels D, const int32_t* __restrict__ cand_cnt,
                                                 const int32_t* __restrict__ hist, int32_t* __restrict__ seg_cnt,
-                                                int32_t* __restrict__ flags, int max_surv) {
+                                                int32_t* __restrict__ flags, int max_surv, int nframes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
     const int tid = threadIdx.x;
-    const int l = blockIdx.x, f = blockIdx.y;
+    int l, f;
+    if (!xcd_frame_map(blockIdx.x, D.L, nframes, f, l)) return;
     const LevelArgs A = D.lv[l];
     int* sv = reinterpret_cast<int*>(smem + (size_t)max_surv * 8);   // all LDS in the dynamic region (16-B aligned base)
     int& s_cut = sv[0]; int& s_n = sv[1]; int& s_keep = sv[2];
@@ -383,6 +401,8 @@ __device__ const int8_t g_pattern[256 * 4] = {
 struct DescArgs {
     int umax[16];
     int kq[7];                // 7-tap Gaussian, Q8
+    uint32_t k0, k1;          // the same taps packed as bytes for v_dot4_u32_u8: (k0..k3), (k4..k6, 0)
+    const uint32_t* angle_tab; // [31 rows][9 dwords][2]: byte weights (u+16 inside the disc, else 0) and byte mask (1/0)
     float rad_per_deg;        // (float)(CV_PI/180.f)
     int patch_size;
 };
@@ -438,11 +458,12 @@ __device__ __forceinline__ void sincos_det(double x, double* s, double* c) {
 __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const int32_t* __restrict__ seg_cnt,
                                                   vis_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                   int32_t* __restrict__ nkp, int kcap, int rec0,
-                                                  int32_t* __restrict__ flags) {
+                                                  int32_t* __restrict__ flags, int nframes) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[4 * WAVE_LDS];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int f = blockIdx.y;
-    const int g = blockIdx.x * 4 + wv;
+    int f, kb;
+    if (!xcd_frame_map(blockIdx.x, (kcap + 3) / 4, nframes, f, kb)) return;
+    const int g = kb * 4 + wv;
     // locate (level, index) of packed keypoint g: level-major, canonical order inside a level
     int total = 0, lev = -1, idx = 0;
     for (int l = 0; l < D.L; l++) {
@@ -477,51 +498,41 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
         }
     }
     WAVE_SYNC();
-    // IC angle over the radius-15 disc
-    int m01 = 0, m10 = 0;
-    for (int i = lane; i < 31 * 31; i += 64) {
-        const int vv = i / 31 - 15, uu = i % 31 - 15;
-        const int av = vv < 0 ? -vv : vv, au = uu < 0 ? -uu : uu;
-        if (au <= G.umax[av]) {
-            const int I = raw[(PR + vv) * PS + (PR + uu)];
-            m10 += uu * I; m01 += vv * I;
+    // IC angle over the radius-15 disc: each (row, dword) item is two byte dot products against a
+    // precomputed weight/mask table: m10 = sum (u+16) I - 16 sum I,  m01 = sum v I   (all exact integers)
+    int sA = 0, sB = 0, sC = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int item = lane + 64 * k;
+        if (item < 31 * 9) {
+            const int rv = item / 9, dw = item - rv * 9;
+            const uint32_t pixw = *reinterpret_cast<const uint32_t*>(raw + (PR - 15 + rv) * PS + 4 + 4 * dw);
+            const uint2 wm = *reinterpret_cast<const uint2*>(G.angle_tab + 2 * item);
+            const int a = (int)__builtin_amdgcn_udot4(pixw, wm.x, 0u, false);
+            const int b = (int)__builtin_amdgcn_udot4(pixw, wm.y, 0u, false);
+            sA += a; sB += b; sC += (rv - 15) * b;
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    for (int o = 32; o > 0; o >>= 1) { sA += __shfl_xor(sA, o); sB += __shfl_xor(sB, o); sC += __shfl_xor(sC, o); }
+    const int m10 = sA - 16 * sB, m01 = sC;
     const float angle = fast_atan2_deg((float)m01, (float)m10);
-    // horizontal 7-tap pass over all 43 rows, patch columns 3..39: one task = (row, 13-wide segment) with a
-    // sliding window over 19 source bytes (5 dword reads); 43*3 = 129 tasks
-    for (int task = lane; task < PW * 3; task += 64) {
-        const int r = task / 3, sg = task - r * 3;
-        const int c0 = sg * 13;                                   // outputs c0 .. c0+12 (segment 2: 26..36 -> 11)
-        const uint8_t* p = raw + r * PS + c0;                     // needs bytes p[0 .. 18]
-        const int al = c0 & 3;
-        const uint32_t* pw = reinterpret_cast<const uint32_t*>(p - al);
-        uint32_t w[6];
+    // horizontal 7-tap pass over all 43 rows, patch columns 3..39.  One task = (row, group of 4 outputs):
+    // 3 aligned dword reads, byte windows by v_alignbyte, 2 x v_dot4_u32_u8 per output, 2 dword stores.
+    for (int task = lane; task < PW * 10; task += 64) {
+        const int r = task / 10, g4 = task - r * 10;
+        const uint32_t* rw = reinterpret_cast<const uint32_t*>(raw + r * PS) + g4;
+        const uint32_t w0 = rw[0], w1 = rw[1], w2 = rw[2];
+        uint32_t o[4];
+        o[0] = __builtin_amdgcn_udot4(w0, G.k0, __builtin_amdgcn_udot4(w1, G.k1, 0u, false), false);
 #pragma unroll
-        for (int k = 0; k < 6; k++) w[k] = (al + 19 > 4 * k) ? pw[k] : 0u;
-        int b[19];
-#pragma unroll
-        for (int k = 0; k < 19; k++) {
-            const int o = al + k;
-            // al is 0,1,2 (c0 = 0,13,26): resolve the dynamic byte offset with a funnel shift
-            const uint32_t lo = w[k >> 2], mid = w[(k >> 2) + 1];
-            const int sh = (o & 3);
-            const int wi = o >> 2;
-            const uint32_t word = (wi == (k >> 2)) ? lo : mid;
-            b[k] = (int)((word >> (sh * 8)) & 0xFFu);
+        for (int j = 1; j < 4; j++) {
+            const uint32_t a = __builtin_amdgcn_alignbyte(w1, w0, j), b = __builtin_amdgcn_alignbyte(w2, w1, j);
+            o[j] = __builtin_amdgcn_udot4(a, G.k0, __builtin_amdgcn_udot4(b, G.k1, 0u, false), false);
         }
-        const int nout = sg == 2 ? HW - 26 : 13;
-#pragma unroll
-        for (int j = 0; j < 13; j++) {
-            if (j < nout) {
-                int sacc = 0;
-#pragma unroll
-                for (int k = 0; k < 7; k++) sacc += G.kq[k] * b[j + k];
-                hb[r * HS + c0 + j] = (uint16_t)sacc;             // <= 255*257 = 65535
-            }
-        }
+        uint32_t* hw = reinterpret_cast<uint32_t*>(hb + r * HS + 4 * g4);      // <= 255*257 = 65535 per output
+        hw[0] = o[0] | (o[1] << 16);
+        if (g4 < 9) hw[1] = o[2] | (o[3] << 16);                             // group 9 holds only output 36
     }
     WAVE_SYNC();
     float ang = angle;
@@ -586,7 +597,7 @@ static void fill_det_levels(const Plan* pl, const uint8_t* d_frames, DetLevels& 
     }
 }
 
-static void fill_desc_args(const vis_params& p, DescArgs& G) {
+static void fill_desc_args(const vis_params& p, DescArgs& G, std::vector<uint32_t>* tab_out) {
     // ORB umax table for halfPatchSize = 15 (computed exactly as ORB_Impl does)
     const int hp = p.patch_size / 2;
     int umax[17] = {0};
@@ -601,8 +612,25 @@ static void fill_desc_args(const vis_params& p, DescArgs& G) {
     for (int i = 0; i < n; i++) { double x = i - (n - 1) * 0.5; cf[i] = (float)std::exp(scale2X * x * x); sum += cf[i]; }
     sum = 1. / sum;
     for (int i = 0; i < n; i++) { cf[i] = (float)(cf[i] * sum); G.kq[i] = (int)std::lrint((double)cf[i] * 256.0); }
+    G.k0 = (uint32_t)G.kq[0] | ((uint32_t)G.kq[1] << 8) | ((uint32_t)G.kq[2] << 16) | ((uint32_t)G.kq[3] << 24);
+    G.k1 = (uint32_t)G.kq[4] | ((uint32_t)G.kq[5] << 8) | ((uint32_t)G.kq[6] << 16);
     G.rad_per_deg = (float)(M_PI / 180.f);
     G.patch_size = p.patch_size;
+    G.angle_tab = nullptr;
+    if (tab_out) {
+        // row rv (v = rv-15), dword dw covers patch columns 4+4dw .. 7+4dw, i.e. u = pc - 21
+        tab_out->assign(31 * 9 * 2, 0u);
+        for (int rv = 0; rv < 31; rv++)
+            for (int dw = 0; dw < 9; dw++) {
+                uint32_t wv = 0, mv = 0;
+                for (int b = 0; b < 4; b++) {
+                    const int u = 4 + 4 * dw + b - 21, v = rv - 15;
+                    const int au = u < 0 ? -u : u, av = v < 0 ? -v : v;
+                    if (au <= 15 && au <= umax[av]) { wv |= (uint32_t)(u + 16) << (8 * b); mv |= 1u << (8 * b); }
+                }
+                (*tab_out)[2 * (rv * 9 + dw)] = wv; (*tab_out)[2 * (rv * 9 + dw) + 1] = mv;
+            }
+    }
 }
 
 int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int rec0) {
@@ -612,15 +640,21 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
     HIPCHK(ctx, hipMemsetAsync(pl->d_hist, 0, sizeof(int32_t) * (size_t)pl->B * L * 256, st));
     HIPCHK(ctx, hipMemsetAsync(pl->d_seg_cnt, 0, sizeof(int32_t) * (size_t)pl->B * L, st));
     DetLevels D; fill_det_levels(pl, d_frames, D);
-    DescArgs G; fill_desc_args(ctx->p, G);
+    DescArgs G;
+    if (!pl->d_angle_tab) {
+        std::vector<uint32_t> tab; fill_desc_args(ctx->p, G, &tab);
+        HIPCHK(ctx, hipMalloc((void**)&pl->d_angle_tab, tab.size() * 4));
+        HIPCHK(ctx, hipMemcpy(pl->d_angle_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    } else fill_desc_args(ctx->p, G, nullptr);
+    G.angle_tab = pl->d_angle_tab;
     int nfast = 0;
     for (int l = 1; l < L; l++) {
         const LevelInfo& V = pl->lv[l];
         const LevelInfo& U = pl->lv[l - 1];
-        dim3 grid((V.w + 255) / 256, (V.h + 3) / 4, n), block(64, 4);
-        hipLaunchKernelGGL(k_resize, grid, block, 0, st, D.lv[l - 1].img, U.w, U.stride, U.frame_bytes,
+        const int bxc = (V.w + 255) / 256, per_frame = bxc * ((V.h + 3) / 4);
+        hipLaunchKernelGGL(k_resize, dim3(xcd_grid(n, per_frame)), dim3(64, 4), 0, st, D.lv[l - 1].img, U.w, U.stride, U.frame_bytes,
                            pl->d_pyr[l], V.w, V.h, V.stride, V.frame_bytes,
-                           pl->d_xofs[l], pl->d_ialpha[l], pl->d_yofs[l], pl->d_ibeta[l]);
+                           pl->d_xofs[l], pl->d_ialpha[l], pl->d_yofs[l], pl->d_ibeta[l], bxc, per_frame, n);
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[1], st);
     {
@@ -634,8 +668,8 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
             tb += V.tiles_x * V.tiles_y;
         }
         FA.total_tiles = tb;
-        hipLaunchKernelGGL(k_fast, dim3(tb, n), dim3(256), 0, st, FA, ctx->p.fast_threshold, ctx->p.edge_threshold,
-                           pl->d_cand_cnt, pl->d_hist);
+        hipLaunchKernelGGL(k_fast, dim3(xcd_grid(n, tb)), dim3(256), 0, st, FA, ctx->p.fast_threshold, ctx->p.edge_threshold,
+                           pl->d_cand_cnt, pl->d_hist, n);
         nfast = 1;
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[2], st);
@@ -643,11 +677,11 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
     if ((size_t)max_surv * 8 + 16 > 65536) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (160 KiB per CU on gfx950)
         HIPCHK(ctx, hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)max_surv * 8 + 16)));
     }
-    hipLaunchKernelGGL(k_select, dim3(L, n), dim3(256), (size_t)max_surv * 8 + 16, st, D, pl->d_cand_cnt, pl->d_hist,
-                       pl->d_seg_cnt, pl->d_flags, max_surv);
+    hipLaunchKernelGGL(k_select, dim3(xcd_grid(n, L)), dim3(256), (size_t)max_surv * 8 + 16, st, D, pl->d_cand_cnt, pl->d_hist,
+                       pl->d_seg_cnt, pl->d_flags, max_surv, n);
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[3], st);
-    hipLaunchKernelGGL(k_describe, dim3((pl->kcap + 3) / 4, n), dim3(256), 0, st, D, G, pl->d_seg_cnt,
-                       pl->d_kps, pl->d_desc, pl->d_nkp, pl->kcap, rec0, pl->d_flags);
+    hipLaunchKernelGGL(k_describe, dim3(xcd_grid(n, (pl->kcap + 3) / 4)), dim3(256), 0, st, D, G, pl->d_seg_cnt,
+                       pl->d_kps, pl->d_desc, pl->d_nkp, pl->kcap, rec0, pl->d_flags, n);
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[4], st);
     ctx->tm.launches_fast = nfast;
     ctx->tm.launches_total = (L - 1) + 1 + 2;

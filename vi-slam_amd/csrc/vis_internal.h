@@ -50,6 +50,7 @@ struct Plan {
     int32_t* d_seg_cnt = nullptr;            // B x L kept counts
     float4*  d_seg_kp[VIS_MAX_LEVELS] = {};  // B x keep_cap (x, y, response, unused)
     int32_t* d_flags = nullptr;              // device error flags (1 word)
+    uint32_t* d_angle_tab = nullptr;         // IC-angle byte weight/mask table for k_describe
     // records
     vis_keypoint* d_kps = nullptr;           // nrec x kcap
     uint8_t* d_desc = nullptr;               // nrec x kcap x 32
