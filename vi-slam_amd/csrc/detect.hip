@@ -153,6 +153,30 @@ __device__ __forceinline__ bool fast_pretest(const uint8_t* c, int t) {
     return mn > t || mx < -t;
 }
 
+// ---- packed (2 x 16 bit) pretest on 4 horizontally adjacent pixels held as the 4 bytes of a dword
+typedef short pk16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk16 as_pk(uint32_t v) { return __builtin_bit_cast(pk16, v); }
+__device__ __forceinline__ pk16 unpack_lo(uint32_t w) { return as_pk(__builtin_amdgcn_perm(0u, w, 0x0c010c00u)); }   // bytes 0,1 -> 2 x u16
+__device__ __forceinline__ pk16 unpack_hi(uint32_t w) { return as_pk(__builtin_amdgcn_perm(0u, w, 0x0c030c02u)); }   // bytes 2,3 -> 2 x u16
+__device__ __forceinline__ pk16 pmin(pk16 a, pk16 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ pk16 pmax(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
+
+// the 4-pair necessary condition of fast_pretest() on two pixels at once: > 0 in a half <=> that pixel passes
+template <bool HI>
+__device__ __forceinline__ pk16 pretest_pk(uint32_t C, uint32_t N, uint32_t S, uint32_t E, uint32_t W,
+                                           uint32_t NE, uint32_t SW, uint32_t SE, uint32_t NW, pk16 T) {
+    const pk16 c = HI ? unpack_hi(C) : unpack_lo(C);
+    const pk16 n = HI ? unpack_hi(N) : unpack_lo(N), so = HI ? unpack_hi(S) : unpack_lo(S);
+    const pk16 e = HI ? unpack_hi(E) : unpack_lo(E), w = HI ? unpack_hi(W) : unpack_lo(W);
+    const pk16 ne = HI ? unpack_hi(NE) : unpack_lo(NE), sw = HI ? unpack_hi(SW) : unpack_lo(SW);
+    const pk16 se = HI ? unpack_hi(SE) : unpack_lo(SE), nw = HI ? unpack_hi(NW) : unpack_lo(NW);
+    // dark arc: every pair has a ring pixel < c - t   <=>  max over pairs of min(pair) < c - t
+    const pk16 mx = pmax(pmax(pmin(n, so), pmin(e, w)), pmax(pmin(ne, sw), pmin(se, nw)));
+    // bright arc: min over pairs of max(pair) > c + t
+    const pk16 mn = pmin(pmin(pmax(n, so), pmax(e, w)), pmin(pmax(ne, sw), pmax(se, nw)));
+    return pmax((c - T) - mx, (mn - c) - T);
+}
+
 struct FastLevel { const uint8_t* img; uint32_t* cand; size_t frame_bytes; int w, h, stride, cand_cap, tiles_x, tile_base; };
 struct FastArgs { FastLevel lv[VIS_MAX_LEVELS]; int L, total_tiles; };
 
@@ -198,20 +222,52 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edg
     const int lox = max(3, edge - 1), hix = min(w - 3, w - edge + 1);
     const int loy = max(3, edge - 1), hiy = min(h - 3, h - edge + 1);
     {
-        const int tx = tid & 63, ty = tid >> 6;
-        for (int sy = ty; sy < SC_H; sy += 4) {
+        // score columns 1..64 (the tile's own 64 columns): unit = 4 adjacent positions whose centre pixels
+        // are one aligned LDS dword; 11 dword reads + 4 v_alignbyte give centre and the 8 tested ring
+        // pixels for all four; 34 rows x 16 units
+        const pk16 T = {(short)threshold, (short)threshold};
+        for (int u = tid; u < SC_H * 16; u += 256) {
+            const int sy = u >> 4, q = u & 15;
             const int gy = oy - 1 + sy;
+            const uint32_t* r0 = px + (sy + 3) * (PX_W / 4) + q;          // centre row, dword q
+            const uint32_t* rp2 = r0 + 2 * (PX_W / 4), * rm2 = r0 - 2 * (PX_W / 4);
+            const uint32_t c0 = r0[0], C = r0[1], c2 = r0[2];
+            const uint32_t N = r0[3 * (PX_W / 4) + 1], S = r0[-3 * (PX_W / 4) + 1];
+            const uint32_t a0 = rp2[0], a1 = rp2[1], a2 = rp2[2];
+            const uint32_t b0 = rm2[0], b1 = rm2[1], b2 = rm2[2];
+            const uint32_t E = __builtin_amdgcn_alignbyte(c2, C, 3), W = __builtin_amdgcn_alignbyte(C, c0, 1);
+            const uint32_t NE = __builtin_amdgcn_alignbyte(a2, a1, 2), NW = __builtin_amdgcn_alignbyte(a1, a0, 2);
+            const uint32_t SE = __builtin_amdgcn_alignbyte(b2, b1, 2), SW = __builtin_amdgcn_alignbyte(b1, b0, 2);
+            const pk16 plo = pretest_pk<false>(C, N, S, E, W, NE, SW, SE, NW, T);
+            const pk16 phi = pretest_pk<true>(C, N, S, E, W, NE, SW, SE, NW, T);
             const bool rowok = gy >= loy && gy < hiy;
-            {
-                const int sx = tx, gx = ox - 1 + sx;
-                if (rowok && gx >= lox && gx < hix && fast_pretest(pxb + (sy + 3) * PX_W + (sx + 3), threshold))
-                    queue[atomicAdd(&qn, 1)] = (uint16_t)(sy * SC_W + sx);
+            const int gx0 = ox + 4 * q;                                  // image x of position sx = 4q+1
+            const bool p0 = rowok && plo.x > 0 && gx0 >= lox && gx0 < hix;
+            const bool p1 = rowok && plo.y > 0 && gx0 + 1 >= lox && gx0 + 1 < hix;
+            const bool p2 = rowok && phi.x > 0 && gx0 + 2 >= lox && gx0 + 2 < hix;
+            const bool p3 = rowok && phi.y > 0 && gx0 + 3 >= lox && gx0 + 3 < hix;
+            // wave-aggregated queue append (queue order is irrelevant: k_select sorts)
+            const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1), m2 = __ballot(p2), m3 = __ballot(p3);
+            const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+            const int tot = n0 + n1 + n2 + n3;
+            if (tot) {
+                int base = 0;
+                if ((tid & 63) == 0) base = atomicAdd(&qn, tot);
+                base = __shfl(base, 0);
+                const unsigned long long lt = (1ull << (tid & 63)) - 1ull;
+                const int pos = sy * SC_W + 4 * q + 1;
+                if (p0) queue[base + __popcll(m0 & lt)] = (uint16_t)pos;
+                if (p1) queue[base + n0 + __popcll(m1 & lt)] = (uint16_t)(pos + 1);
+                if (p2) queue[base + n0 + n1 + __popcll(m2 & lt)] = (uint16_t)(pos + 2);
+                if (p3) queue[base + n0 + n1 + n2 + __popcll(m3 & lt)] = (uint16_t)(pos + 3);
             }
-            if (tx < 2) {                                          // score columns 64, 65
-                const int sx = 64 + tx, gx = ox - 1 + sx;
-                if (rowok && gx >= lox && gx < hix && fast_pretest(pxb + (sy + 3) * PX_W + (sx + 3), threshold))
-                    queue[atomicAdd(&qn, 1)] = (uint16_t)(sy * SC_W + sx);
-            }
+        }
+        // halo score columns 0 and 65 (NMS neighbours of the first/last tile column): byte-wise test
+        if (tid < 2 * SC_H) {
+            const int sy = tid >> 1, sx = (tid & 1) ? SC_W - 1 : 0;
+            const int gx = ox - 1 + sx, gy = oy - 1 + sy;
+            if (gy >= loy && gy < hiy && gx >= lox && gx < hix && fast_pretest(pxb + (sy + 3) * PX_W + (sx + 3), threshold))
+                queue[atomicAdd(&qn, 1)] = (uint16_t)(sy * SC_W + sx);
         }
     }
     __syncthreads();
