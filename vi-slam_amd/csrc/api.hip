@@ -170,7 +170,7 @@ void plan_destroy(Plan* pl) {
         F(pl->d_pyr[l]); F(pl->d_xofs[l]); F(pl->d_ialpha[l]); F(pl->d_yofs[l]); F(pl->d_ibeta[l]);
         F(pl->d_cand[l]); F(pl->d_seg_kp[l]);
     }
-    F(pl->d_cand_cnt); F(pl->d_hist); F(pl->d_seg_cnt); F(pl->d_flags); F(pl->d_angle_tab);
+    F(pl->d_tile_cnt); F(pl->d_seg_cnt); F(pl->d_flags); F(pl->d_angle_tab);
     F(pl->d_kps); F(pl->d_desc); F(pl->d_nkp);
     F(pl->d_pair_q); F(pl->d_pair_t); F(pl->d_pair_q_noprev); F(pl->d_knn12); F(pl->d_knn21);
     F(pl->d_sym); F(pl->d_nsym); F(pl->d_good); F(pl->d_ngood); F(pl->d_p1); F(pl->d_p2); F(pl->d_hf); F(pl->d_wf);
@@ -210,7 +210,8 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
         DALLOC(pl->d_cand[l], (size_t)pl->lv[l].cand_cap * B);
         DALLOC(pl->d_seg_kp[l], (size_t)pl->lv[l].keep_cap * B);
     }
-    DALLOC(pl->d_cand_cnt, (size_t)B * L); DALLOC(pl->d_hist, (size_t)B * L * 256); DALLOC(pl->d_seg_cnt, (size_t)B * L);
+    pl->total_tiles = pl->lv[L - 1].tile_base + pl->lv[L - 1].tiles_x * pl->lv[L - 1].tiles_y;
+    DALLOC(pl->d_tile_cnt, (size_t)B * pl->total_tiles); DALLOC(pl->d_seg_cnt, (size_t)B * L);
     DALLOC(pl->d_flags, 4);
     HIPCHK(ctx, hipMemset(pl->d_flags, 0, 16));
     DALLOC(pl->d_kps, (size_t)nrec * kcap); DALLOC(pl->d_desc, (size_t)nrec * kcap * 32); DALLOC(pl->d_nkp, nrec);

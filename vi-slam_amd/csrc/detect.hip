@@ -177,21 +177,19 @@ __device__ __forceinline__ pk16 pretest_pk(uint32_t C, uint32_t N, uint32_t S, u
     return pmax((c - T) - mx, (mn - c) - T);
 }
 
-struct FastLevel { const uint8_t* img; uint32_t* cand; size_t frame_bytes; int w, h, stride, cand_cap, tiles_x, tile_base; };
+struct FastLevel { const uint8_t* img; uint32_t* cand; size_t frame_bytes; int w, h, stride, ntiles, tiles_x, tile_base; };
+#define TILE_CAND_CAP (FT_W * FT_H / 4)     // 3x3 NMS bound per 64x32 tile: a tile's slot can never overflow
 struct FastArgs { FastLevel lv[VIS_MAX_LEVELS]; int L, total_tiles; };
 
 // ONE launch for all pyramid levels of all frames: blockIdx.x enumerates the 64x32 tiles of every level,
 // blockIdx.y the frame.  Phases: (A) pixel tile + halo -> LDS with dword loads, (B) pretest on every
 // score position, survivors are compacted into an LDS queue, (C) dense full cornerScore on the queue,
-// (D) 3x3 NMS + border cull on the scored survivors, packed candidates + score histogram.
-__global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edge, int32_t* __restrict__ cand_cnt,
-                                              int32_t* __restrict__ hist, int nframes) {
+// (D) 3x3 NMS + border cull on the scored survivors -> packed candidates in the tile's own slot.
+__global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edge, int32_t* __restrict__ tile_cnt, int nframes) {
     __shared__ __attribute__((aligned(16))) uint32_t px[PX_H * PX_W / 4];
     __shared__ uint8_t sc[SC_H * SC_S];
     __shared__ uint16_t queue[SC_H * SC_W];
-    __shared__ uint32_t lhist[256];
-    __shared__ uint32_t lcand[FT_W * FT_H / 4];
-    __shared__ int lcount, gbase, qn;
+    __shared__ int lcount, qn;
     const int tid = threadIdx.x;
     int f, gtile;
     if (!xcd_frame_map(blockIdx.x, F.total_tiles, nframes, f, gtile)) return;
@@ -205,7 +203,8 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edg
     // tiles that cannot emit (entirely inside the culled border) do nothing
     if (ox + FT_W <= edge || ox >= w - edge || oy + FT_H <= edge || oy >= h - edge) return;
     const uint8_t* base = V.img + (size_t)f * V.frame_bytes;
-    lhist[tid] = 0;
+    // every tile owns a fixed slot of TILE_CAND_CAP candidates: no returning atomics, no cross-tile ordering
+    uint32_t* slot = V.cand + ((size_t)f * V.ntiles + tile) * TILE_CAND_CAP;
     if (tid == 0) { lcount = 0; qn = 0; }
     for (int wv = tid; wv < PX_H * (PX_W / 4); wv += 256) {
         const int r = wv / (PX_W / 4), cw = wv % (PX_W / 4);
@@ -229,6 +228,10 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edg
         for (int u = tid; u < SC_H * 16; u += 256) {
             const int sy = u >> 4, q = u & 15;
             const int gy = oy - 1 + sy;
+            const int gx0 = ox + 4 * q;                                  // image x of position sx = 4q+1
+            const bool rowok = gy >= loy && gy < hiy && gx0 + 3 >= lox && gx0 < hix;
+            bool p0 = false, p1 = false, p2 = false, p3 = false;
+            if (rowok) {
             const uint32_t* r0 = px + (sy + 3) * (PX_W / 4) + q;          // centre row, dword q
             const uint32_t* rp2 = r0 + 2 * (PX_W / 4), * rm2 = r0 - 2 * (PX_W / 4);
             const uint32_t c0 = r0[0], C = r0[1], c2 = r0[2];
@@ -240,12 +243,11 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edg
             const uint32_t SE = __builtin_amdgcn_alignbyte(b2, b1, 2), SW = __builtin_amdgcn_alignbyte(b1, b0, 2);
             const pk16 plo = pretest_pk<false>(C, N, S, E, W, NE, SW, SE, NW, T);
             const pk16 phi = pretest_pk<true>(C, N, S, E, W, NE, SW, SE, NW, T);
-            const bool rowok = gy >= loy && gy < hiy;
-            const int gx0 = ox + 4 * q;                                  // image x of position sx = 4q+1
-            const bool p0 = rowok && plo.x > 0 && gx0 >= lox && gx0 < hix;
-            const bool p1 = rowok && plo.y > 0 && gx0 + 1 >= lox && gx0 + 1 < hix;
-            const bool p2 = rowok && phi.x > 0 && gx0 + 2 >= lox && gx0 + 2 < hix;
-            const bool p3 = rowok && phi.y > 0 && gx0 + 3 >= lox && gx0 + 3 < hix;
+            p0 = plo.x > 0 && gx0 >= lox && gx0 < hix;
+            p1 = plo.y > 0 && gx0 + 1 >= lox && gx0 + 1 < hix;
+            p2 = phi.x > 0 && gx0 + 2 >= lox && gx0 + 2 < hix;
+            p3 = phi.y > 0 && gx0 + 3 >= lox && gx0 + 3 < hix;
+            }
             // wave-aggregated queue append (queue order is irrelevant: k_select sorts)
             const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1), m2 = __ballot(p2), m3 = __ballot(p3);
             const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
@@ -289,21 +291,11 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edg
         if (s && gx >= edge && gx < w - edge && gy >= edge && gy < h - edge &&
             s > p[-1] && s > p[1] && s > p[-SC_S - 1] && s > p[-SC_S] && s > p[-SC_S + 1] &&
             s > p[SC_S - 1] && s > p[SC_S] && s > p[SC_S + 1]) {
-            const int slot = atomicAdd(&lcount, 1);
-            lcand[slot] = ((uint32_t)s << 24) | ((uint32_t)gy << 12) | (uint32_t)gx;
-            atomicAdd(&lhist[s], 1u);
+            slot[atomicAdd(&lcount, 1)] = ((uint32_t)s << 24) | ((uint32_t)gy << 12) | (uint32_t)gx;
         }
     }
     __syncthreads();
-    const int n = lcount;
-    if (n == 0) return;
-    const int seg = f * F.L + level;
-    if (tid == 0) gbase = atomicAdd(&cand_cnt[seg], n);
-    __syncthreads();
-    const int gb = gbase;
-    for (int i = tid; i < n; i += 256)
-        if (gb + i < V.cand_cap) V.cand[(size_t)f * V.cand_cap + gb + i] = lcand[i];
-    if (lhist[tid]) atomicAdd(&hist[(size_t)seg * 256 + tid], (int)lhist[tid]);
+    if (tid == 0) tile_cnt[(size_t)f * F.total_tiles + gtile] = lcount;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -311,7 +303,7 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edg
 struct LevelArgs {
     const uint8_t* img; size_t frame_bytes;
     const uint32_t* cand; float4* seg_kp;
-    int w, h, stride, quota, surv_cap, keep_cap, cand_cap; float scale;
+    int w, h, stride, quota, surv_cap, keep_cap, ntiles, tile_base; float scale;
 };
 struct DetLevels { LevelArgs lv[VIS_MAX_LEVELS]; int L; };
 
@@ -352,8 +344,8 @@ __device__ float harris7(const uint8_t* __restrict__ img, int stride, int x, int
     return (fa * fb - fc * fc - 0.04f * s * s) * scale_sq_sq;
 }
 
-__global__ __launch_bounds__(256) void k_select(DetLevels D, const int32_t* __restrict__ cand_cnt,
-                                                const int32_t* __restrict__ hist, int32_t* __restrict__ seg_cnt,
+__global__ __launch_bounds__(256) void k_select(DetLevels D, const int32_t* __restrict__ tile_cnt, int total_tiles,
+                                                int32_t* __restrict__ seg_cnt,
                                                 int32_t* __restrict__ flags, int max_surv, int nframes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
@@ -363,26 +355,43 @@ __global__ __launch_bounds__(256) void k_select(DetLevels D, const int32_t* __re
     const LevelArgs A = D.lv[l];
     int* sv = reinterpret_cast<int*>(smem + (size_t)max_surv * 8);   // all LDS in the dynamic region (16-B aligned base)
     int& s_cut = sv[0]; int& s_n = sv[1]; int& s_keep = sv[2];
+    int* lhist = sv + 4;                                            // 256 bins
     const int seg = f * D.L + l;
-    int C = cand_cnt[seg];
-    if (C > A.cand_cap) { C = A.cand_cap; if (tid == 0) atomicOr(flags, 1); }
+    const int32_t* tc = tile_cnt + (size_t)f * total_tiles + A.tile_base;
+    const uint32_t* cand = A.cand + (size_t)f * A.ntiles * TILE_CAND_CAP;
+    lhist[tid] = 0;
+    if (tid == 0) { s_n = 0; s_keep = 0; }
+    __syncthreads();
+    // pass 1: FAST-score histogram of this (frame, level) over its tiles' slots
+    for (int t = tid; t < A.ntiles; t += 256) {
+        const int c = min(tc[t], TILE_CAND_CAP);
+        const uint32_t* e = cand + (size_t)t * TILE_CAND_CAP;
+        for (int i = 0; i < c; i++) atomicAdd(&lhist[e[i] >> 24], 1);
+    }
+    __syncthreads();
     if (tid == 0) {
+        int C = 0;
+        for (int sidx = 0; sidx < 256; sidx++) C += lhist[sidx];
         const int n = 2 * A.quota;
         int cut = 0;
         if (C > n) {                                  // KeyPointsFilter::retainBest(2*quota) on FAST score
             cut = 256;
-            if (n > 0) { int acc = 0; for (int s = 255; s >= 0; s--) { acc += hist[(size_t)seg * 256 + s]; if (acc >= n) { cut = s; break; } } }
+            if (n > 0) { int acc = 0; for (int sidx = 255; sidx >= 0; sidx--) { acc += lhist[sidx]; if (acc >= n) { cut = sidx; break; } } }
         }
-        s_cut = cut; s_n = 0; s_keep = 0;
+        s_cut = cut;
     }
     __syncthreads();
-    const uint32_t* cand = A.cand + (size_t)f * A.cand_cap;
     const int cut = s_cut;
-    for (int i = tid; i < C; i += 256) {
-        const uint32_t c = cand[i];
-        if ((int)(c >> 24) >= cut) {
-            const int slot = atomicAdd(&s_n, 1);
-            if (slot < A.surv_cap) keys[slot] = c;
+    // pass 2: gather the survivors
+    for (int t = tid; t < A.ntiles; t += 256) {
+        const int c = min(tc[t], TILE_CAND_CAP);
+        const uint32_t* e = cand + (size_t)t * TILE_CAND_CAP;
+        for (int i = 0; i < c; i++) {
+            const uint32_t cv = e[i];
+            if ((int)(cv >> 24) >= cut) {
+                const int slot = atomicAdd(&s_n, 1);
+                if (slot < A.surv_cap) keys[slot] = cv;
+            }
         }
     }
     __syncthreads();
@@ -649,7 +658,7 @@ static void fill_det_levels(const Plan* pl, const uint8_t* d_frames, DetLevels& 
         A.cand = pl->d_cand[l]; A.seg_kp = pl->d_seg_kp[l];
         A.w = pl->lv[l].w; A.h = pl->lv[l].h; A.stride = pl->lv[l].stride;
         A.quota = pl->lv[l].quota; A.surv_cap = pl->lv[l].surv_cap; A.keep_cap = pl->lv[l].keep_cap;
-        A.cand_cap = pl->lv[l].cand_cap; A.scale = pl->lv[l].scale;
+        A.ntiles = pl->lv[l].tiles_x * pl->lv[l].tiles_y; A.tile_base = pl->lv[l].tile_base; A.scale = pl->lv[l].scale;
     }
 }
 
@@ -692,8 +701,7 @@ static void fill_desc_args(const vis_params& p, DescArgs& G, std::vector<uint32_
 int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int rec0) {
     hipStream_t st = ctx->stream;
     const int L = pl->L;
-    HIPCHK(ctx, hipMemsetAsync(pl->d_cand_cnt, 0, sizeof(int32_t) * (size_t)pl->B * L, st));
-    HIPCHK(ctx, hipMemsetAsync(pl->d_hist, 0, sizeof(int32_t) * (size_t)pl->B * L * 256, st));
+    HIPCHK(ctx, hipMemsetAsync(pl->d_tile_cnt, 0, sizeof(int32_t) * (size_t)pl->B * pl->total_tiles, st));
     HIPCHK(ctx, hipMemsetAsync(pl->d_seg_cnt, 0, sizeof(int32_t) * (size_t)pl->B * L, st));
     DetLevels D; fill_det_levels(pl, d_frames, D);
     DescArgs G;
@@ -715,25 +723,24 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[1], st);
     {
         FastArgs FA; FA.L = L;
-        int tb = 0;
         for (int l = 0; l < L; l++) {
             const LevelInfo& V = pl->lv[l];
             FA.lv[l].img = D.lv[l].img; FA.lv[l].cand = pl->d_cand[l]; FA.lv[l].frame_bytes = V.frame_bytes;
-            FA.lv[l].w = V.w; FA.lv[l].h = V.h; FA.lv[l].stride = V.stride; FA.lv[l].cand_cap = V.cand_cap;
-            FA.lv[l].tiles_x = V.tiles_x; FA.lv[l].tile_base = tb;
-            tb += V.tiles_x * V.tiles_y;
+            FA.lv[l].w = V.w; FA.lv[l].h = V.h; FA.lv[l].stride = V.stride; FA.lv[l].ntiles = V.tiles_x * V.tiles_y;
+            FA.lv[l].tiles_x = V.tiles_x; FA.lv[l].tile_base = V.tile_base;
         }
+        const int tb = pl->total_tiles;
         FA.total_tiles = tb;
         hipLaunchKernelGGL(k_fast, dim3(xcd_grid(n, tb)), dim3(256), 0, st, FA, ctx->p.fast_threshold, ctx->p.edge_threshold,
-                           pl->d_cand_cnt, pl->d_hist, n);
+                           pl->d_tile_cnt, n);
         nfast = 1;
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[2], st);
     int max_surv = 0; for (int l = 0; l < L; l++) max_surv = std::max(max_surv, pl->lv[l].surv_cap);
-    if ((size_t)max_surv * 8 + 16 > 65536) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (160 KiB per CU on gfx950)
-        HIPCHK(ctx, hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)max_surv * 8 + 16)));
+    if ((size_t)max_surv * 8 + 16 + 1024 > 65536) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (160 KiB per CU on gfx950)
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)max_surv * 8 + 16 + 1024)));
     }
-    hipLaunchKernelGGL(k_select, dim3(xcd_grid(n, L)), dim3(256), (size_t)max_surv * 8 + 16, st, D, pl->d_cand_cnt, pl->d_hist,
+    hipLaunchKernelGGL(k_select, dim3(xcd_grid(n, L)), dim3(256), (size_t)max_surv * 8 + 16 + 1024, st, D, pl->d_tile_cnt, pl->total_tiles,
                        pl->d_seg_cnt, pl->d_flags, max_surv, n);
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[3], st);
     hipLaunchKernelGGL(k_describe, dim3(xcd_grid(n, (pl->kcap + 3) / 4)), dim3(256), 0, st, D, G, pl->d_seg_cnt,

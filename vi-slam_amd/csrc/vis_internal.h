@@ -18,7 +18,8 @@ struct LevelInfo {
     int quota;                   // nfeaturesPerLevel
     float scale;                 // layerScale
     size_t frame_bytes;          // stride*h
-    int cand_cap;                // ceil(w/2)*ceil(h/2): NMS upper bound, cannot overflow
+    int cand_cap;                // tiles * 512: every 64x32 FAST tile owns a slot sized by the 3x3-NMS bound
+    int tile_base;               // first global tile index of this level
     int surv_cap;                // survivors of the FAST cut (2*quota + ties), LDS sort size
     int keep_cap;                // kept per level (quota + ties)
     int tiles_x, tiles_y;        // FAST tiles
@@ -44,9 +45,9 @@ struct Plan {
     int16_t* d_ialpha[VIS_MAX_LEVELS] = {};
     int32_t* d_yofs[VIS_MAX_LEVELS] = {};
     int16_t* d_ibeta[VIS_MAX_LEVELS] = {};
-    uint32_t* d_cand[VIS_MAX_LEVELS] = {};   // B x cand_cap packed (score<<24 | y<<12 | x)
-    int32_t* d_cand_cnt = nullptr;           // B x L
-    int32_t* d_hist = nullptr;               // B x L x 256
+    uint32_t* d_cand[VIS_MAX_LEVELS] = {};   // B x tiles_l x 512 packed (score<<24 | y<<12 | x)
+    int32_t* d_tile_cnt = nullptr;           // B x total_tiles candidates per tile
+    int total_tiles = 0;
     int32_t* d_seg_cnt = nullptr;            // B x L kept counts
     float4*  d_seg_kp[VIS_MAX_LEVELS] = {};  // B x keep_cap (x, y, response, unused)
     int32_t* d_flags = nullptr;              // device error flags (1 word)
