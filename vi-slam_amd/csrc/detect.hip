@@ -106,13 +106,14 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
 
 // ------------------------------------------------------------------------------------------------
 // k_fast
-#define FT_W 64
+#define FT_W 128
 #define FT_H 32
-#define PX_W (FT_W + 8)      // 72 bytes per LDS pixel row (3 ring + 1 NMS halo each side)
+#define PX_XO 16             // the LDS pixel tile starts 16 px left of the tile: rows are whole 16-byte vectors
+#define PX_W (FT_W + 32)     // 160 bytes per LDS pixel row (needs 3 ring + 1 NMS halo each side)
 #define PX_H (FT_H + 8)
 #define SC_W (FT_W + 2)
 #define SC_H (FT_H + 2)
-#define SC_S 68              // LDS score row stride
+#define SC_S (FT_W + 4)      // LDS score row stride
 
 // full cornerScore<16> without the early exit (callers have already thinned the candidates)
 __device__ __forceinline__ int fast_score16_full(const uint8_t* c, int t) {
@@ -178,10 +179,10 @@ __device__ __forceinline__ pk16 pretest_pk(uint32_t C, uint32_t N, uint32_t S, u
 }
 
 struct FastLevel { const uint8_t* img; uint32_t* cand; size_t frame_bytes; int w, h, stride, ntiles, tiles_x, tile_base; };
-#define TILE_CAND_CAP (FT_W * FT_H / 4)     // 3x3 NMS bound per 64x32 tile: a tile's slot can never overflow
+#define TILE_CAND_CAP (FT_W * FT_H / 4)     // 3x3 NMS bound per FT_W x FT_H tile: a tile's slot can never overflow
 struct FastArgs { FastLevel lv[VIS_MAX_LEVELS]; int L, total_tiles; };
 
-// ONE launch for all pyramid levels of all frames: blockIdx.x enumerates the 64x32 tiles of every level,
+// ONE launch for all pyramid levels of all frames: blockIdx.x enumerates the 128x32 tiles of every level,
 // blockIdx.y the frame.  Phases: (A) pixel tile + halo -> LDS with dword loads, (B) pretest on every
 // score position, survivors are compacted into an LDS queue, (C) dense full cornerScore on the queue,
 // (D) 3x3 NMS + border cull on the scored survivors -> packed candidates in the tile's own slot.
@@ -206,13 +207,26 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edg
     // every tile owns a fixed slot of TILE_CAND_CAP candidates: no returning atomics, no cross-tile ordering
     uint32_t* slot = V.cand + ((size_t)f * V.ntiles + tile) * TILE_CAND_CAP;
     if (tid == 0) { lcount = 0; qn = 0; }
-    for (int wv = tid; wv < PX_H * (PX_W / 4); wv += 256) {
-        const int r = wv / (PX_W / 4), cw = wv % (PX_W / 4);
-        const int gx = ox - 4 + cw * 4, gy = oy - 4 + r;
-        uint32_t v = 0;
-        if (gy >= 0 && gy < h && gx >= 0 && gx + 3 < stride)
-            v = *reinterpret_cast<const uint32_t*>(base + (size_t)gy * stride + gx);
-        px[wv] = v;
+    // tile + halo -> LDS: 10 x 16-byte vectors per row (rows start 16 px left of the tile so every vector
+    // is aligned in memory when stride % 16 == 0; otherwise dword loads)
+    if ((stride & 15) == 0) {
+        for (int i = tid; i < PX_H * (PX_W / 16); i += 256) {
+            const int r = i / (PX_W / 16), c4 = i - r * (PX_W / 16);
+            const int gx = ox - PX_XO + c4 * 16, gy = oy - 4 + r;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (gy >= 0 && gy < h && gx >= 0 && gx + 15 < stride)
+                v = *reinterpret_cast<const uint4*>(base + (size_t)gy * stride + gx);
+            reinterpret_cast<uint4*>(px)[i] = v;
+        }
+    } else {
+        for (int wv = tid; wv < PX_H * (PX_W / 4); wv += 256) {
+            const int r = wv / (PX_W / 4), cw = wv % (PX_W / 4);
+            const int gx = ox - PX_XO + cw * 4, gy = oy - 4 + r;
+            uint32_t v = 0;
+            if (gy >= 0 && gy < h && gx >= 0 && gx + 3 < stride)
+                v = *reinterpret_cast<const uint32_t*>(base + (size_t)gy * stride + gx);
+            px[wv] = v;
+        }
     }
     for (int i = tid; i < SC_H * SC_S / 4; i += 256) reinterpret_cast<uint32_t*>(sc)[i] = 0;
     __syncthreads();
@@ -225,14 +239,14 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edg
         // are one aligned LDS dword; 11 dword reads + 4 v_alignbyte give centre and the 8 tested ring
         // pixels for all four; 34 rows x 16 units
         const pk16 T = {(short)threshold, (short)threshold};
-        for (int u = tid; u < SC_H * 16; u += 256) {
-            const int sy = u >> 4, q = u & 15;
+        for (int u = tid; u < SC_H * (FT_W / 4); u += 256) {
+            const int sy = u / (FT_W / 4), q = u - sy * (FT_W / 4);
             const int gy = oy - 1 + sy;
             const int gx0 = ox + 4 * q;                                  // image x of position sx = 4q+1
             const bool rowok = gy >= loy && gy < hiy && gx0 + 3 >= lox && gx0 < hix;
             bool p0 = false, p1 = false, p2 = false, p3 = false;
             if (rowok) {
-            const uint32_t* r0 = px + (sy + 3) * (PX_W / 4) + q;          // centre row, dword q
+            const uint32_t* r0 = px + (sy + 3) * (PX_W / 4) + q + (PX_XO / 4 - 1);   // r0[1] = the 4 centre pixels
             const uint32_t* rp2 = r0 + 2 * (PX_W / 4), * rm2 = r0 - 2 * (PX_W / 4);
             const uint32_t c0 = r0[0], C = r0[1], c2 = r0[2];
             const uint32_t N = r0[3 * (PX_W / 4) + 1], S = r0[-3 * (PX_W / 4) + 1];
@@ -268,7 +282,7 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edg
         if (tid < 2 * SC_H) {
             const int sy = tid >> 1, sx = (tid & 1) ? SC_W - 1 : 0;
             const int gx = ox - 1 + sx, gy = oy - 1 + sy;
-            if (gy >= loy && gy < hiy && gx >= lox && gx < hix && fast_pretest(pxb + (sy + 3) * PX_W + (sx + 3), threshold))
+            if (gy >= loy && gy < hiy && gx >= lox && gx < hix && fast_pretest(pxb + (sy + 3) * PX_W + (sx + PX_XO - 1), threshold))
                 queue[atomicAdd(&qn, 1)] = (uint16_t)(sy * SC_W + sx);
         }
     }
@@ -277,7 +291,7 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edg
     for (int i = tid; i < nq; i += 256) {
         const int pos = queue[i];
         const int sy = pos / SC_W, sx = pos - sy * SC_W;
-        const int s = fast_score16_full(pxb + (sy + 3) * PX_W + (sx + 3), threshold);
+        const int s = fast_score16_full(pxb + (sy + 3) * PX_W + (sx + PX_XO - 1), threshold);
         sc[sy * SC_S + sx] = (uint8_t)s;
     }
     __syncthreads();

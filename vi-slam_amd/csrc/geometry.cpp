@@ -23,9 +23,9 @@ int vis_compute_levels(const vis_params& p, int w, int h, int stride0, LevelInfo
         if (lv[l].w < 8 || lv[l].h < 8) return VIS_E_INVALID;
         lv[l].stride = (l == 0) ? stride0 : ((lv[l].w + 63) / 64) * 64;
         lv[l].frame_bytes = (size_t)lv[l].stride * lv[l].h;
-        lv[l].tiles_x = (lv[l].w + 63) / 64;
+        lv[l].tiles_x = (lv[l].w + 127) / 128;
         lv[l].tiles_y = (lv[l].h + 31) / 32;
-        lv[l].cand_cap = lv[l].tiles_x * lv[l].tiles_y * 512;
+        lv[l].cand_cap = lv[l].tiles_x * lv[l].tiles_y * 1024;
         lv[l].tile_base = l == 0 ? 0 : lv[l - 1].tile_base + lv[l - 1].tiles_x * lv[l - 1].tiles_y;
     }
     float factor = (float)(1.0 / sf);
