@@ -46,60 +46,68 @@ __device__ __forceinline__ uint32_t pick_byte(uint32_t w0, uint32_t w1, uint32_t
     return (lo >> ((off & 3) * 8)) & 0xFFu;
 }
 
-__global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, int sw, int sstride, size_t sframe,
+// cv::resize's per-column / per-row tables are recomputed in registers (same IEEE operations as the host
+// builds them with: double for the source coordinate, float for the fraction, round-half-even for the
+// Q11 coefficient), so the only memory dependency of a thread is its 2 x 12 source bytes -- the
+// table-driven version chained three dependent loads (yofs -> xofs -> pixels) and was latency bound.
+__device__ __forceinline__ void resize_coef(int d, double scale, int slen, int& s0, int& c0, int& c1) {
+    float fx = (float)((d + 0.5) * scale - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= slen - 1) { fx = 0.f; sx = slen - 1; }
+    s0 = sx;
+    c0 = __float2int_rn((1.f - fx) * 2048.f);
+    c1 = __float2int_rn(fx * 2048.f);
+}
+
+__global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, int sw, int sh, int sstride, size_t sframe,
                                                 uint8_t* __restrict__ dst, int dw, int dh, int dstride, size_t dframe,
-                                                const int32_t* __restrict__ xofs, const int16_t* __restrict__ ialpha,
-                                                const int32_t* __restrict__ yofs, const int16_t* __restrict__ ibeta,
+                                                double scale_x, double scale_y,
                                                 int bx_count, int per_frame, int nframes) {
     int f, inner;
     if (!xcd_frame_map(blockIdx.x, per_frame, nframes, f, inner)) return;
     const int dx4 = ((inner % bx_count) * 64 + threadIdx.x) * 4;
     const int dy = (inner / bx_count) * 4 + threadIdx.y;
     if (dx4 >= dw || dy >= dh) return;
-    const int2 ys = *reinterpret_cast<const int2*>(yofs + 2 * dy);
-    const uint32_t bb = *reinterpret_cast<const uint32_t*>(ibeta + 2 * dy);
-    const int b0 = (int)(short)(bb & 0xFFFF), b1 = (int)(short)(bb >> 16);
-    const uint8_t* S0 = src + (size_t)f * sframe + (size_t)ys.x * sstride;
-    const uint8_t* S1 = src + (size_t)f * sframe + (size_t)ys.y * sstride;
+    // vertical: row indices are clamped, the coefficients are not (resizeGeneric_Invoker)
+    int b0, b1, sy0, sy1;
+    {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        const int sy = (int)floorf(fy);
+        fy -= (float)sy;
+        sy0 = min(max(sy, 0), sh - 1); sy1 = min(max(sy + 1, 0), sh - 1);
+        b0 = __float2int_rn((1.f - fy) * 2048.f); b1 = __float2int_rn(fy * 2048.f);
+    }
+    const uint8_t* S0 = src + (size_t)f * sframe + (size_t)sy0 * sstride;
+    const uint8_t* S1 = src + (size_t)f * sframe + (size_t)sy1 * sstride;
+    int sxs[4], a0s[4], a1s[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) resize_coef(min(dx4 + k, dw - 1), scale_x, sw, sxs[k], a0s[k], a1s[k]);
+    // the 4 outputs read source bytes sxs[0] .. sxs[3]+1 (span <= 12 for any down-scale factor < 3.6);
+    // clamp the window start so the 12-byte fetch stays inside the row (rows are >= 12 bytes)
+    const int wb = min(sxs[0], sstride - 12);
+    const uint32_t a0w = *reinterpret_cast<const u32_unaligned*>(S0 + wb);
+    const uint32_t a1w = *reinterpret_cast<const u32_unaligned*>(S0 + wb + 4);
+    const uint32_t a2w = *reinterpret_cast<const u32_unaligned*>(S0 + wb + 8);
+    const uint32_t c0w = *reinterpret_cast<const u32_unaligned*>(S1 + wb);
+    const uint32_t c1w = *reinterpret_cast<const u32_unaligned*>(S1 + wb + 4);
+    const uint32_t c2w = *reinterpret_cast<const u32_unaligned*>(S1 + wb + 8);
     uint32_t out = 0;
-    if (dx4 + 3 < dw) {
-        const int4 xo = *reinterpret_cast<const int4*>(xofs + dx4);           // tables are padded to a multiple of 4
-        const uint4 al = *reinterpret_cast<const uint4*>(ialpha + 2 * dx4);
-        const int base = xo.x;
-        // the 4 outputs read source bytes base .. xo.w+1 (span <= 12 for any down-scale factor < 3.6);
-        // clamp the window start so the 12-byte fetch stays inside the row (rows are >= 12 bytes)
-        const int wb = min(base, sstride - 12);
-        const uint32_t a0w = *reinterpret_cast<const u32_unaligned*>(S0 + wb);
-        const uint32_t a1w = *reinterpret_cast<const u32_unaligned*>(S0 + wb + 4);
-        const uint32_t a2w = *reinterpret_cast<const u32_unaligned*>(S0 + wb + 8);
-        const uint32_t c0w = *reinterpret_cast<const u32_unaligned*>(S1 + wb);
-        const uint32_t c1w = *reinterpret_cast<const u32_unaligned*>(S1 + wb + 4);
-        const uint32_t c2w = *reinterpret_cast<const u32_unaligned*>(S1 + wb + 8);
-        const int sxs[4] = {xo.x, xo.y, xo.z, xo.w};
-        const uint32_t als[4] = {al.x, al.y, al.z, al.w};
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int o0 = sxs[k] - wb, o1 = min(sxs[k] + 1, sw - 1) - wb;
-            const int a0 = (int)(short)(als[k] & 0xFFFF), a1 = (int)(short)(als[k] >> 16);
-            const int r0 = (int)pick_byte(a0w, a1w, a2w, o0) * a0 + (int)pick_byte(a0w, a1w, a2w, o1) * a1;
-            const int r1 = (int)pick_byte(c0w, c1w, c2w, o0) * a0 + (int)pick_byte(c0w, c1w, c2w, o1) * a1;
-            const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-            out |= (uint32_t)(v & 255) << (8 * k);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int dx = dx4 + k;
-            if (dx < dw) {
-                const int sx = xofs[dx];
-                const int sx1 = min(sx + 1, sw - 1);
-                const int a0 = ialpha[2 * dx], a1 = ialpha[2 * dx + 1];
-                const int r0 = S0[sx] * a0 + S0[sx1] * a1;
-                const int r1 = S1[sx] * a0 + S1[sx1] * a1;
-                const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-                out |= (uint32_t)(v & 255) << (8 * k);
-            }
-        }
+    for (int k = 0; k < 4; k++) {
+        // the two horizontally adjacent source bytes (sx, sx+1) as the low 16 bits of one funnel shift.
+        // At the right edge (sx == sw-1) the second byte is a don't-care: its coefficient is 0.
+        const int o0 = sxs[k] - wb;                                        // 0 .. 10
+        const bool s1 = o0 >= 4, s2 = o0 >= 8;
+        const uint32_t lo0 = s2 ? a2w : (s1 ? a1w : a0w), hi0 = s2 ? 0u : (s1 ? a2w : a1w);
+        const uint32_t lo1 = s2 ? c2w : (s1 ? c1w : c0w), hi1 = s2 ? 0u : (s1 ? c2w : c1w);
+        const uint32_t p0 = __builtin_amdgcn_alignbyte(hi0, lo0, (uint32_t)(o0 & 3));
+        const uint32_t p1 = __builtin_amdgcn_alignbyte(hi1, lo1, (uint32_t)(o0 & 3));
+        const int r0 = (int)(p0 & 0xFFu) * a0s[k] + (int)((p0 >> 8) & 0xFFu) * a1s[k];
+        const int r1 = (int)(p1 & 0xFFu) * a0s[k] + (int)((p1 >> 8) & 0xFFu) * a1s[k];
+        const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        out |= (dx4 + k < dw) ? ((uint32_t)(v & 255) << (8 * k)) : 0u;
     }
     *reinterpret_cast<uint32_t*>(dst + (size_t)f * dframe + (size_t)dy * dstride + dx4) = out;
 }
@@ -730,9 +738,10 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
         const LevelInfo& V = pl->lv[l];
         const LevelInfo& U = pl->lv[l - 1];
         const int bxc = (V.w + 255) / 256, per_frame = bxc * ((V.h + 3) / 4);
-        hipLaunchKernelGGL(k_resize, dim3(xcd_grid(n, per_frame)), dim3(64, 4), 0, st, D.lv[l - 1].img, U.w, U.stride, U.frame_bytes,
-                           pl->d_pyr[l], V.w, V.h, V.stride, V.frame_bytes,
-                           pl->d_xofs[l], pl->d_ialpha[l], pl->d_yofs[l], pl->d_ibeta[l], bxc, per_frame, n);
+        // scale exactly as cv::resize derives it: inv_scale = (double)dsize/ssize; scale = 1./inv_scale
+        const double scale_x = 1. / ((double)V.w / U.w), scale_y = 1. / ((double)V.h / U.h);
+        hipLaunchKernelGGL(k_resize, dim3(xcd_grid(n, per_frame)), dim3(64, 4), 0, st, D.lv[l - 1].img, U.w, U.h, U.stride, U.frame_bytes,
+                           pl->d_pyr[l], V.w, V.h, V.stride, V.frame_bytes, scale_x, scale_y, bxc, per_frame, n);
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[1], st);
     {

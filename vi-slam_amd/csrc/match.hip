@@ -22,20 +22,27 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ desc, 
     const int rt = dir == 0 ? pair_t[pair] : pair_q[pair];
     if (rq < 0 || rt < 0) return;
     const int nq = min(nkp[rq], kcap), nt = min(nkp[rt], kcap);
-    if ((int)(blockIdx.x * blockDim.x) >= nq) return;
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint4* Q = reinterpret_cast<const uint4*>(desc + ((size_t)rq * kcap + min(q, nq - 1)) * 32);
-    const uint4 qa = Q[0], qb = Q[1];
+    // two query rows per lane (q and q + blockDim): every scalar-loaded train row feeds twice the
+    // VALU work, halving the scalar-load stalls per popcount and doubling the independent chains
+    const int qbase = blockIdx.x * blockDim.x * 2;
+    if (qbase >= nq) return;
+    const int q0i = qbase + threadIdx.x, q1i = q0i + blockDim.x;
+    const uint4* Q0 = reinterpret_cast<const uint4*>(desc + ((size_t)rq * kcap + min(q0i, nq - 1)) * 32);
+    const uint4* Q1 = reinterpret_cast<const uint4*>(desc + ((size_t)rq * kcap + min(q1i, nq - 1)) * 32);
+    const uint4 qa = Q0[0], qb = Q0[1], ra = Q1[0], rb = Q1[1];
     const uint4* T = reinterpret_cast<const uint4*>(desc + (size_t)rt * kcap * 32);
-    uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
+    uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu, j0 = 0xFFFFFFFFu, j1 = 0xFFFFFFFFu;
+#define KNN_DIST(xa, xb, ta, tb, d_) do {                                                          \
+        d_ = __popc((xa).x ^ (ta).x);                                                              \
+        d_ += __popc((xa).y ^ (ta).y); d_ += __popc((xa).z ^ (ta).z); d_ += __popc((xa).w ^ (ta).w); \
+        d_ += __popc((xb).x ^ (tb).x); d_ += __popc((xb).y ^ (tb).y); d_ += __popc((xb).z ^ (tb).z); \
+        d_ += __popc((xb).w ^ (tb).w); } while (0)
 #define KNN_STEP(ta, tb, tt) do {                                                                   \
-        uint32_t d_ = __popc(qa.x ^ (ta).x);                                                        \
-        d_ += __popc(qa.y ^ (ta).y); d_ += __popc(qa.z ^ (ta).z); d_ += __popc(qa.w ^ (ta).w);      \
-        d_ += __popc(qb.x ^ (tb).x); d_ += __popc(qb.y ^ (tb).y); d_ += __popc(qb.z ^ (tb).z);      \
-        d_ += __popc(qb.w ^ (tb).w);                                                                \
-        const uint32_t key_ = (d_ << 16) | (uint32_t)(tt);                                          \
-        k1 = min(k1, max(k0, key_));                                                                \
-        k0 = min(k0, key_); } while (0)
+        uint32_t da_, db_;                                                                          \
+        KNN_DIST(qa, qb, ta, tb, da_); KNN_DIST(ra, rb, ta, tb, db_);                               \
+        const uint32_t ka_ = (da_ << 16) | (uint32_t)(tt), kb_ = (db_ << 16) | (uint32_t)(tt);      \
+        k1 = min(k1, max(k0, ka_)); k0 = min(k0, ka_);                                              \
+        j1 = min(j1, max(j0, kb_)); j0 = min(j0, kb_); } while (0)
     // the train descriptors are wave-uniform (SGPRs): groups of KNN_U rows are fetched with back-to-back
     // scalar loads (s_load_dwordx16) so one load latency is paid per group, not per row; the other waves
     // of the SIMD cover it with their xor/popcount work
@@ -53,10 +60,10 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ desc, 
         KNN_STEP(ta, tb, t);
     }
 #undef KNN_STEP
-    if (q < nq) {
-        uint32_t* out = (dir == 0 ? knn12 : knn21) + ((size_t)pair * kcap + q) * 2;
-        out[0] = k0; out[1] = k1;
-    }
+#undef KNN_DIST
+    uint32_t* outp = (dir == 0 ? knn12 : knn21) + (size_t)pair * kcap * 2;
+    if (q0i < nq) { outp[2 * q0i] = k0; outp[2 * q0i + 1] = k1; }
+    if (q1i < nq) { outp[2 * q1i] = j0; outp[2 * q1i + 1] = j1; }
 }
 
 __device__ __forceinline__ uint32_t fmap_f(float f) {
@@ -192,7 +199,7 @@ int launch_match(vis_ctx* ctx, Plan* pl, int npairs) {
     if (npairs <= 0) return VIS_OK;
     // small problems: one wave per block so a single pair still spreads over many CUs
     const int bs = (npairs * ((pl->kcap + 255) / 256) * 2 >= 512) ? 256 : 64;
-    dim3 grid((pl->kcap + bs - 1) / bs, npairs, 2);
+    dim3 grid((pl->kcap + 2 * bs - 1) / (2 * bs), npairs, 2);
     hipLaunchKernelGGL(k_knn2, grid, dim3(bs), 0, ctx->stream, pl->d_desc, pl->d_nkp, pl->kcap,
                        pl->d_pair_q, pl->d_pair_t, pl->d_knn12, pl->d_knn21);
     HIPCHK(ctx, hipGetLastError());
