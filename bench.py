@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step (per GPU)")
+    ap.add_argument("--batch", type=int, default=512, help="frames per step (per GPU)")
     ap.add_argument("--ring", type=int, default=2, help="distinct batches resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -162,11 +162,15 @@ def main():
         per_launch_bytes = bytes_per_frame * B / nlaunch
         per_launch_s = fam[dom] * 1e-3 / nlaunch
         achieved = per_launch_bytes / per_launch_s / 1e9
+        # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/profile_workload.py, separate
+        # FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE correction calibrated on a 256 MiB copy); measured at
+        # profiles/pmc_traffic.json["batch_frames"] frames per launch and scaled linearly to this run's batch
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(kname, {}).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic = pj[kname]["hbm_bytes_per_launch"] * (B / pj["batch_frames"])
             except Exception:
                 traffic = None
         fps = vdist.aggregate_fps(world, a.steps, B, dt)
