@@ -167,7 +167,7 @@ void plan_destroy(Plan* pl) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(pl->d_stage);
     for (int l = 0; l < VIS_MAX_LEVELS; l++) {
-        F(pl->d_pyr[l]); F(pl->d_xofs[l]); F(pl->d_ialpha[l]); F(pl->d_yofs[l]); F(pl->d_ibeta[l]);
+        F(pl->d_pyr[l]);
         F(pl->d_cand[l]); F(pl->d_seg_kp[l]);
     }
     F(pl->d_tile_cnt); F(pl->d_seg_cnt); F(pl->d_flags); F(pl->d_angle_tab);
@@ -195,16 +195,8 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
     pl->max_iters = ctx->p.ransac_max_iters;
     DALLOC(pl->d_stage, (size_t)stride * h);
     for (int l = 1; l < L; l++) {
-        const LevelInfo& V = pl->lv[l]; const LevelInfo& U = pl->lv[l - 1];
+        const LevelInfo& V = pl->lv[l];
         DALLOC(pl->d_pyr[l], V.frame_bytes * B);
-        std::vector<int32_t> xofs, yofs; std::vector<int16_t> ia, ib;
-        vis_resize_tables(U.w, U.h, V.w, V.h, xofs, ia, yofs, ib);
-        DALLOC(pl->d_xofs[l], xofs.size()); DALLOC(pl->d_ialpha[l], ia.size());
-        DALLOC(pl->d_yofs[l], yofs.size()); DALLOC(pl->d_ibeta[l], ib.size());
-        HIPCHK(ctx, hipMemcpy(pl->d_xofs[l], xofs.data(), xofs.size() * 4, hipMemcpyHostToDevice));
-        HIPCHK(ctx, hipMemcpy(pl->d_ialpha[l], ia.data(), ia.size() * 2, hipMemcpyHostToDevice));
-        HIPCHK(ctx, hipMemcpy(pl->d_yofs[l], yofs.data(), yofs.size() * 4, hipMemcpyHostToDevice));
-        HIPCHK(ctx, hipMemcpy(pl->d_ibeta[l], ib.data(), ib.size() * 2, hipMemcpyHostToDevice));
     }
     for (int l = 0; l < L; l++) {
         DALLOC(pl->d_cand[l], (size_t)pl->lv[l].cand_cap * B);

@@ -1,5 +1,5 @@
 // geometry.cpp -- host-side tables of the detector: pyramid level geometry, per-level feature
-// quotas, cv::resize fixed-point coefficient tables, grid-filter band limits, and the
+// quotas, grid-filter band limits, and the
 // integer-only synthetic stream generator.  Plain C++ (no device code).
 //
 // Follows what cv::ORB / cv::resize derive for the reference call site
@@ -48,37 +48,6 @@ int vis_compute_levels(const vis_params& p, int w, int h, int stride0, LevelInfo
         lv[l].keep_cap = q + q / 8 + 32;
     }
     return VIS_OK;
-}
-
-// cv::resize(INTER_LINEAR), 8-bit: xofs/ialpha/yofs/ibeta exactly as resize() builds them
-// (INTER_RESIZE_COEF_BITS = 11; coefficient = saturate_cast<short>(float_coef * 2048)).
-void vis_resize_tables(int sw, int sh, int dw, int dh, std::vector<int32_t>& xofs,
-                       std::vector<int16_t>& ialpha, std::vector<int32_t>& yofs,
-                       std::vector<int16_t>& ibeta) {
-    const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
-    const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
-    xofs.resize(dw); ialpha.resize(2 * (size_t)dw); yofs.resize(2 * (size_t)dh); ibeta.resize(2 * (size_t)dh);
-    for (int dx = 0; dx < dw; dx++) {
-        float fx = (float)((dx + 0.5) * scale_x - 0.5);
-        int sx = (int)std::floor(fx);
-        fx -= sx;
-        if (sx < 0) { fx = 0; sx = 0; }
-        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
-        xofs[dx] = sx;
-        ialpha[2 * dx] = (int16_t)round_half_even((double)((1.f - fx) * 2048));
-        ialpha[2 * dx + 1] = (int16_t)round_half_even((double)(fx * 2048));
-    }
-    for (int dy = 0; dy < dh; dy++) {
-        float fy = (float)((dy + 0.5) * scale_y - 0.5);
-        int sy = (int)std::floor(fy);
-        fy -= sy;
-        // row indices are clamped (coefficients are not): store both clamped rows
-        int s0 = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);
-        int s1 = sy + 1 < 0 ? 0 : (sy + 1 >= sh ? sh - 1 : sy + 1);
-        yofs[2 * dy] = s0; yofs[2 * dy + 1] = s1;
-        ibeta[2 * dy] = (int16_t)round_half_even((double)((1.f - fy) * 2048));
-        ibeta[2 * dy + 1] = (int16_t)round_half_even((double)(fy * 2048));
-    }
 }
 
 // Matcher::bestMatchesFilter window limits: winW = w_size/floor(sqrt(n)) stored as float, limits

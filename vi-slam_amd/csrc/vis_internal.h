@@ -41,10 +41,6 @@ struct Plan {
     // ---- device buffers
     uint8_t* d_stage = nullptr;              // single-frame upload staging (stride x h)
     uint8_t* d_pyr[VIS_MAX_LEVELS] = {};     // level l >= 1: B x h_l x stride_l
-    int32_t* d_xofs[VIS_MAX_LEVELS] = {};    // resize tables (level l from l-1)
-    int16_t* d_ialpha[VIS_MAX_LEVELS] = {};
-    int32_t* d_yofs[VIS_MAX_LEVELS] = {};
-    int16_t* d_ibeta[VIS_MAX_LEVELS] = {};
     uint32_t* d_cand[VIS_MAX_LEVELS] = {};   // B x tiles_l x 512 packed (score<<24 | y<<12 | x)
     int32_t* d_tile_cnt = nullptr;           // B x total_tiles candidates per tile
     int total_tiles = 0;
@@ -114,9 +110,6 @@ struct vis_ctx {
 
 // ---- host-side geometry / tables (geometry.cpp) ----
 int  vis_compute_levels(const vis_params& p, int w, int h, int stride0, LevelInfo* lv);
-void vis_resize_tables(int sw, int sh, int dw, int dh, std::vector<int32_t>& xofs,
-                       std::vector<int16_t>& ialpha, std::vector<int32_t>& yofs,
-                       std::vector<int16_t>& ibeta);
 void vis_grid_limits(const vis_params& p, int* root, std::vector<float>& hf, std::vector<float>& wf);
 
 // ---- plan management (plan.hip) ----
