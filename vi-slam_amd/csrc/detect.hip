@@ -61,6 +61,7 @@ __device__ __forceinline__ void resize_coef(int d, double scale, int slen, int& 
     c1 = __float2int_rn(fx * 2048.f);
 }
 
+#define RS_ROWS 4            // destination rows per thread: the column coefficients are computed once per thread
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, int sw, int sh, int sstride, size_t sframe,
                                                 uint8_t* __restrict__ dst, int dw, int dh, int dstride, size_t dframe,
                                                 double scale_x, double scale_y,
@@ -68,48 +69,54 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
     int f, inner;
     if (!xcd_frame_map(blockIdx.x, per_frame, nframes, f, inner)) return;
     const int dx4 = ((inner % bx_count) * 64 + threadIdx.x) * 4;
-    const int dy = (inner / bx_count) * 4 + threadIdx.y;
-    if (dx4 >= dw || dy >= dh) return;
-    // vertical: row indices are clamped, the coefficients are not (resizeGeneric_Invoker)
-    int b0, b1, sy0, sy1;
-    {
-        float fy = (float)((dy + 0.5) * scale_y - 0.5);
-        const int sy = (int)floorf(fy);
-        fy -= (float)sy;
-        sy0 = min(max(sy, 0), sh - 1); sy1 = min(max(sy + 1, 0), sh - 1);
-        b0 = __float2int_rn((1.f - fy) * 2048.f); b1 = __float2int_rn(fy * 2048.f);
-    }
-    const uint8_t* S0 = src + (size_t)f * sframe + (size_t)sy0 * sstride;
-    const uint8_t* S1 = src + (size_t)f * sframe + (size_t)sy1 * sstride;
+    const int dy0 = ((inner / bx_count) * 4 + threadIdx.y) * RS_ROWS;
+    if (dx4 >= dw || dy0 >= dh) return;
     int sxs[4], a0s[4], a1s[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) resize_coef(min(dx4 + k, dw - 1), scale_x, sw, sxs[k], a0s[k], a1s[k]);
     // the 4 outputs read source bytes sxs[0] .. sxs[3]+1 (span <= 12 for any down-scale factor < 3.6);
     // clamp the window start so the 12-byte fetch stays inside the row (rows are >= 12 bytes)
     const int wb = min(sxs[0], sstride - 12);
-    const uint32_t a0w = *reinterpret_cast<const u32_unaligned*>(S0 + wb);
-    const uint32_t a1w = *reinterpret_cast<const u32_unaligned*>(S0 + wb + 4);
-    const uint32_t a2w = *reinterpret_cast<const u32_unaligned*>(S0 + wb + 8);
-    const uint32_t c0w = *reinterpret_cast<const u32_unaligned*>(S1 + wb);
-    const uint32_t c1w = *reinterpret_cast<const u32_unaligned*>(S1 + wb + 4);
-    const uint32_t c2w = *reinterpret_cast<const u32_unaligned*>(S1 + wb + 8);
-    uint32_t out = 0;
+    int offs[4]; bool s1s[4], s2s[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        // the two horizontally adjacent source bytes (sx, sx+1) as the low 16 bits of one funnel shift.
-        // At the right edge (sx == sw-1) the second byte is a don't-care: its coefficient is 0.
-        const int o0 = sxs[k] - wb;                                        // 0 .. 10
-        const bool s1 = o0 >= 4, s2 = o0 >= 8;
-        const uint32_t lo0 = s2 ? a2w : (s1 ? a1w : a0w), hi0 = s2 ? 0u : (s1 ? a2w : a1w);
-        const uint32_t lo1 = s2 ? c2w : (s1 ? c1w : c0w), hi1 = s2 ? 0u : (s1 ? c2w : c1w);
-        const uint32_t p0 = __builtin_amdgcn_alignbyte(hi0, lo0, (uint32_t)(o0 & 3));
-        const uint32_t p1 = __builtin_amdgcn_alignbyte(hi1, lo1, (uint32_t)(o0 & 3));
-        const int r0 = (int)(p0 & 0xFFu) * a0s[k] + (int)((p0 >> 8) & 0xFFu) * a1s[k];
-        const int r1 = (int)(p1 & 0xFFu) * a0s[k] + (int)((p1 >> 8) & 0xFFu) * a1s[k];
-        const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-        out |= (dx4 + k < dw) ? ((uint32_t)(v & 255) << (8 * k)) : 0u;
+    for (int k = 0; k < 4; k++) { const int o0 = sxs[k] - wb; offs[k] = o0 & 3; s1s[k] = o0 >= 4; s2s[k] = o0 >= 8; }
+    const uint8_t* sbase = src + (size_t)f * sframe + wb;
+    uint8_t* dbase = dst + (size_t)f * dframe + dx4;
+    // issue the source loads of all RS_ROWS rows first (24 dwords in flight per thread), then compute
+    uint32_t W[RS_ROWS][6]; int B0[RS_ROWS], B1[RS_ROWS];
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; r++) {
+        const int dy = min(dy0 + r, dh - 1);
+        // vertical: row indices are clamped, the coefficients are not (resizeGeneric_Invoker)
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        const int sy = (int)floorf(fy);
+        fy -= (float)sy;
+        const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
+        B0[r] = __float2int_rn((1.f - fy) * 2048.f); B1[r] = __float2int_rn(fy * 2048.f);
+        const uint8_t* S0 = sbase + (size_t)sy0 * sstride;
+        const uint8_t* S1 = sbase + (size_t)sy1 * sstride;
+        W[r][0] = *reinterpret_cast<const u32_unaligned*>(S0);     W[r][1] = *reinterpret_cast<const u32_unaligned*>(S0 + 4);
+        W[r][2] = *reinterpret_cast<const u32_unaligned*>(S0 + 8); W[r][3] = *reinterpret_cast<const u32_unaligned*>(S1);
+        W[r][4] = *reinterpret_cast<const u32_unaligned*>(S1 + 4); W[r][5] = *reinterpret_cast<const u32_unaligned*>(S1 + 8);
     }
-    *reinterpret_cast<uint32_t*>(dst + (size_t)f * dframe + (size_t)dy * dstride + dx4) = out;
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; r++) {
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            // the two horizontally adjacent source bytes (sx, sx+1) as the low 16 bits of one funnel shift.
+            // At the right edge (sx == sw-1) the second byte is a don't-care: its coefficient is 0.
+            const uint32_t lo0 = s2s[k] ? W[r][2] : (s1s[k] ? W[r][1] : W[r][0]), hi0 = s2s[k] ? 0u : (s1s[k] ? W[r][2] : W[r][1]);
+            const uint32_t lo1 = s2s[k] ? W[r][5] : (s1s[k] ? W[r][4] : W[r][3]), hi1 = s2s[k] ? 0u : (s1s[k] ? W[r][5] : W[r][4]);
+            const uint32_t p0 = __builtin_amdgcn_alignbyte(hi0, lo0, (uint32_t)offs[k]);
+            const uint32_t p1 = __builtin_amdgcn_alignbyte(hi1, lo1, (uint32_t)offs[k]);
+            const int r0 = (int)(p0 & 0xFFu) * a0s[k] + (int)((p0 >> 8) & 0xFFu) * a1s[k];
+            const int r1 = (int)(p1 & 0xFFu) * a0s[k] + (int)((p1 >> 8) & 0xFFu) * a1s[k];
+            const int v = (((B0[r] * (r0 >> 4)) >> 16) + ((B1[r] * (r1 >> 4)) >> 16) + 2) >> 2;
+            out |= (dx4 + k < dw) ? ((uint32_t)(v & 255) << (8 * k)) : 0u;
+        }
+        if (dy0 + r < dh) *reinterpret_cast<uint32_t*>(dbase + (size_t)(dy0 + r) * dstride) = out;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -472,8 +479,9 @@ __global__ __launch_bounds__(256) void k_select(DetLevels D, const int32_t* __re
 #define PW 43
 #define PS 44                 // raw patch LDS row stride
 #define HW 37                 // horizontally blurred columns kept (patch cols 3..39)
-#define HS 38
-#define WAVE_LDS (PW * PS + PW * HS * 2 + 12)     // bytes per wave, multiple of 4
+#define HTS 46                // the row-blurred patch is stored TRANSPOSED: hbT[col][row], 46 u16 per column (odd dword
+                              // stride): the 7 vertical taps of a sample are then 4 consecutive dwords
+#define WAVE_LDS (PW * PS + HW * HTS * 2 + 8)     // bytes per wave, multiple of 4
 
 __device__ const int8_t g_pattern[256 * 4] = {
 #include "orb_pattern.inc"
@@ -489,6 +497,7 @@ struct DescArgs {
     int umax[16];
     int kq[7];                // 7-tap Gaussian, Q8
     uint32_t k0, k1;          // the same taps packed as bytes for v_dot4_u32_u8: (k0..k3), (k4..k6, 0)
+    uint32_t kp[4];           // and as u16 pairs for v_dot2_u32_u16: (k0,k1) (k2,k3) (k4,k5) (k6,0)
     const uint32_t* angle_tab; // [31 rows][9 dwords][2]: byte weights (u+16 inside the disc, else 0) and byte mask (1/0)
     float rad_per_deg;        // (float)(CV_PI/180.f)
     int patch_size;
@@ -617,9 +626,9 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
             const uint32_t a = __builtin_amdgcn_alignbyte(w1, w0, j), b = __builtin_amdgcn_alignbyte(w2, w1, j);
             o[j] = __builtin_amdgcn_udot4(a, G.k0, __builtin_amdgcn_udot4(b, G.k1, 0u, false), false);
         }
-        uint32_t* hw = reinterpret_cast<uint32_t*>(hb + r * HS + 4 * g4);      // <= 255*257 = 65535 per output
-        hw[0] = o[0] | (o[1] << 16);
-        if (g4 < 9) hw[1] = o[2] | (o[3] << 16);                             // group 9 holds only output 36
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (4 * g4 + j < HW) hb[(4 * g4 + j) * HTS + r] = (uint16_t)o[j];   // <= 255*257 = 65535 per output
     }
     WAVE_SYNC();
     float ang = angle;
@@ -639,11 +648,19 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
             const float fx = px * a - py * b;
             const float fy = px * b + py * a;
             const int ix = __float2int_rn(fx), iy = __float2int_rn(fy);
-            const uint16_t* hp = hb + (PR + iy - 3) * HS + (PR + ix - 3);
-            int s = 0;
-#pragma unroll
-            for (int j = 0; j < 7; j++) s += G.kq[j] * hp[j * HS];
-            s = (s + (1 << 15)) >> 16;
+            // vertical 7 taps = 4 consecutive dwords of column (PR+ix-3) starting at row (PR+iy-3)
+            const int row0 = PR + iy - 3;
+            const uint32_t* cw = reinterpret_cast<const uint32_t*>(hb + (PR + ix - 3) * HTS) + (row0 >> 1);
+            const uint32_t w0 = cw[0], w1 = cw[1], w2 = cw[2], w3 = cw[3];
+            const uint32_t sh = (uint32_t)(row0 & 1) * 2u;
+            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+            const uint32_t t0 = __builtin_amdgcn_alignbyte(w1, w0, sh), t1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+            const uint32_t t2 = __builtin_amdgcn_alignbyte(w3, w2, sh), t3 = __builtin_amdgcn_alignbyte(0u, w3, sh);
+            uint32_t su = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t0), __builtin_bit_cast(us2, G.kp[0]), 0u, false);
+            su = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t1), __builtin_bit_cast(us2, G.kp[1]), su, false);
+            su = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t2), __builtin_bit_cast(us2, G.kp[2]), su, false);
+            su = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t3), __builtin_bit_cast(us2, G.kp[3]), su, false);
+            int s = (int)((su + (1u << 15)) >> 16);
             val[e] = s > 255 ? 255 : s;
         }
         words[k] = __ballot(val[0] < val[1]);
@@ -701,6 +718,8 @@ static void fill_desc_args(const vis_params& p, DescArgs& G, std::vector<uint32_
     for (int i = 0; i < n; i++) { cf[i] = (float)(cf[i] * sum); G.kq[i] = (int)std::lrint((double)cf[i] * 256.0); }
     G.k0 = (uint32_t)G.kq[0] | ((uint32_t)G.kq[1] << 8) | ((uint32_t)G.kq[2] << 16) | ((uint32_t)G.kq[3] << 24);
     G.k1 = (uint32_t)G.kq[4] | ((uint32_t)G.kq[5] << 8) | ((uint32_t)G.kq[6] << 16);
+    G.kp[0] = (uint32_t)G.kq[0] | ((uint32_t)G.kq[1] << 16); G.kp[1] = (uint32_t)G.kq[2] | ((uint32_t)G.kq[3] << 16);
+    G.kp[2] = (uint32_t)G.kq[4] | ((uint32_t)G.kq[5] << 16); G.kp[3] = (uint32_t)G.kq[6];
     G.rad_per_deg = (float)(M_PI / 180.f);
     G.patch_size = p.patch_size;
     G.angle_tab = nullptr;
@@ -737,7 +756,7 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
     for (int l = 1; l < L; l++) {
         const LevelInfo& V = pl->lv[l];
         const LevelInfo& U = pl->lv[l - 1];
-        const int bxc = (V.w + 255) / 256, per_frame = bxc * ((V.h + 3) / 4);
+        const int bxc = (V.w + 255) / 256, per_frame = bxc * ((V.h + 4 * RS_ROWS - 1) / (4 * RS_ROWS));
         // scale exactly as cv::resize derives it: inv_scale = (double)dsize/ssize; scale = 1./inv_scale
         const double scale_x = 1. / ((double)V.w / U.w), scale_y = 1. / ((double)V.h / U.h);
         hipLaunchKernelGGL(k_resize, dim3(xcd_grid(n, per_frame)), dim3(64, 4), 0, st, D.lv[l - 1].img, U.w, U.h, U.stride, U.frame_bytes,
