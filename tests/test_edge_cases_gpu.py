@@ -1,0 +1,127 @@
+"""GPU parity on the edges of the parameter space (bit-exact vs the oracle): other thresholds, scale
+factors, level counts, tiny images, heavy ties, repeated calls / parameter changes on one context."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(vislam, orc, ctx, p, img, cap=None):
+    ctx.set_params(p)
+    k, d = ctx.orb_detect_compute(img, slot=0, cap=cap)
+    ok, od = orc.orb_detect_compute(p, img, cap=cap)
+    assert len(k) == len(ok), (len(k), len(ok))
+    assert k.tobytes() == ok.tobytes()
+    assert (d == od).all()
+    return k, d
+
+
+@pytest.mark.parametrize("thr", [5, 20, 60, 120])
+def test_fast_thresholds(vislam, orc, ctx, canvas, thr):
+    p = vislam.default_params()
+    p.fast_threshold, p.nfeatures, p.w_size, p.h_size = thr, 600, 480, 360
+    _check(vislam, orc, ctx, p, vislam.synth_frame(canvas, 11, 480, 360))
+
+
+@pytest.mark.parametrize("sf,levels", [(1.1, 8), (1.5, 5), (2.0, 3), (1.2, 1), (1.2, 12)])
+def test_scale_factors_and_level_counts(vislam, orc, ctx, canvas, sf, levels):
+    p = vislam.default_params()
+    p.scale_factor, p.nlevels, p.nfeatures, p.w_size, p.h_size = sf, levels, 700, 640, 480
+    _check(vislam, orc, ctx, p, vislam.synth_frame(canvas, 4, 640, 480))
+
+
+@pytest.mark.parametrize("edge", [22, 31, 48])
+def test_edge_thresholds(vislam, orc, ctx, canvas, edge):
+    p = vislam.default_params()
+    p.edge_threshold, p.nfeatures, p.w_size, p.h_size = edge, 500, 400, 300
+    _check(vislam, orc, ctx, p, vislam.synth_frame(canvas, 6, 400, 300))
+
+
+def test_smallest_image_and_huge_quota(vislam, orc, ctx):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (72, 96), dtype=np.uint8)           # interior is only 34 x 10 pixels
+    p = vislam.default_params()
+    p.nlevels, p.nfeatures, p.w_size, p.h_size = 1, 2500, 96, 72   # quota larger than anything detectable
+    k, d = _check(vislam, orc, ctx, p, img, cap=12000)
+    assert 0 < len(k) < 400
+
+
+def test_heavy_ties_checkerboard(vislam, orc, ctx):
+    """a periodic pattern gives hundreds of identical FAST scores and identical Harris responses: the
+    retainBest tie rule (keep every response >= the cut) and the canonical order are both exercised"""
+    img = np.full((240, 320), 100, np.uint8)
+    for y in range(40, 200, 20):
+        for x in range(40, 280, 20):
+            img[y:y + 7, x:x + 7] = 220                            # 96 identical squares -> 384 identical corners
+            for cy, cx in ((y, x), (y, x + 6), (y + 6, x), (y + 6, x + 6)):
+                img[cy, cx] = 240                                  # unique local maximum at every corner (NMS is strict)
+    p = vislam.default_params()
+    p.nlevels, p.nfeatures, p.w_size, p.h_size = 1, 150, 320, 240
+    ctx.set_params(p)
+    try:
+        k, d = ctx.orb_detect_compute(img, slot=0, cap=20000)
+    except vislam.VisError as e:                                   # ties beyond the slack are reported, never silent
+        assert e.code == -4
+        return
+    ok, od = orc.orb_detect_compute(p, img, cap=20000)
+    assert k.tobytes() == ok.tobytes() and (d == od).all()
+    assert len(k) > 150                                            # ties kept beyond the quota
+
+
+def test_context_reuse_and_param_changes(vislam, orc, ctx, canvas):
+    img = vislam.synth_frame(canvas, 2, 752, 480)
+    p = vislam.default_params()
+    a = _check(vislam, orc, ctx, p, img)
+    p.nfeatures = 300
+    b = _check(vislam, orc, ctx, p, img)
+    p.nfeatures = 1000
+    c = _check(vislam, orc, ctx, p, img)
+    assert a[0].tobytes() == c[0].tobytes() and len(b[0]) < len(a[0])
+    # slots are invalidated by set_params: matching a stale slot is an error, not garbage
+    with pytest.raises(vislam.VisError):
+        ctx.bf_knn2_hamming(0, 5, 10, 10)
+
+
+@pytest.mark.parametrize("cells,w,h", [(1, 752, 480), (4, 752, 480), (49, 700, 400), (100, 752, 480), (1024, 752, 480)])
+def test_grid_sizes(vislam, orc, ctx, canvas, cells, w, h):
+    p = vislam.default_params()
+    p.n_cells, p.w_size, p.h_size = cells, w, h                    # w_size < image width exercises the column clamp
+    ctx.set_params(p)
+    k0, d0 = ctx.orb_detect_compute(vislam.synth_frame(canvas, 0, 752, 480), slot=0)
+    k1, d1 = ctx.orb_detect_compute(vislam.synth_frame(canvas, 1, 752, 480), slot=1)
+    good, sym = ctx.good_matches(0, 1)
+    o12, o21 = orc.knn2_hamming(d0, d1)
+    og, osym = orc.good_matches(p, k0, k1, o12, o21)
+    assert good.tobytes() == og.tobytes() and sym.tobytes() == osym.tobytes()
+    assert len(good) <= int(np.floor(np.sqrt(cells))) ** 2
+
+
+@pytest.mark.parametrize("seed,thr,prob", [(1, 1.0, 0.999), (0xFFFFFFFFFFFFFFFF, 0.5, 0.99), (12345, 3.0, 0.9999)])
+def test_ransac_parameters(vislam, orc, ctx, seed, thr, prob):
+    import test_pose_gpu
+    p = vislam.default_params()
+    p.fy = p.fx
+    p.ransac_seed, p.ransac_threshold, p.ransac_prob = seed, thr, prob
+    ctx.set_params(p)
+    x1, x2, R, t = test_pose_gpu.two_view(120, 17, 0.35, 0.4)
+    E, mask, ninl, iters = ctx.essential_ransac(x1, x2)
+    oE, omask, oninl, oiters = orc.essential_ransac(p, x1, x2)
+    assert (ninl, iters) == (oninl, oiters) and (mask == omask).all()
+    s = 1.0 if float((E * oE).sum()) >= 0 else -1.0
+    assert np.abs(E - s * oE).max() <= 1e-9
+
+
+def test_invalid_arguments_are_rejected(vislam, ctx):
+    p = vislam.default_params()
+    for field, val in (("patch_size", 29), ("nlevels", 0), ("nlevels", 17), ("edge_threshold", 10), ("scale_factor", 1.0),
+                       ("ransac_max_iters", 0), ("nfeatures", 0)):
+        q = p.copy()
+        setattr(q, field, val)
+        with pytest.raises(vislam.VisError) as ei:
+            ctx.set_params(q)
+        assert ei.value.code == -1, field
+    ctx.set_params(p)
+    with pytest.raises(vislam.VisError):
+        ctx.orb_detect_compute(np.zeros((40, 40), np.uint8))        # smaller than twice the border
+    with pytest.raises(vislam.VisError):
+        ctx.camera_update(np.zeros((100, 100), np.uint8))            # not a multiple of 16
