@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="frames per step (per GPU)")
     ap.add_argument("--ring", type=int, default=2, help="distinct batches resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stages", type=int, default=vislam.STAGE_ALL, help="debug: bitmask of stages (1 detect, 2 match, 4 pose); the reported metric needs all 7")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,7 +117,7 @@ def main():
     fbytes = W * H
 
     def step(i):
-        ctx.batch_run(dframes.data_ptr() + (i % R) * B * fbytes, B, vislam.STAGE_ALL)
+        ctx.batch_run(dframes.data_ptr() + (i % R) * B * fbytes, B, a.stages)
 
     for i in range(a.warmup):
         step(i)

@@ -298,18 +298,25 @@ __global__ __launch_bounds__(256) void k_pose_prep(PoseParams P, const float* __
 
 // One wave per block, one lane per hypothesis.  hbest[pair][h] = (best inlier count << 4) | first model with that
 // count, or -1 when the sample produced no model.  models[pair][h][m][9] receives every E (row-major).
-__global__ __launch_bounds__(64) void k_ransac_hyp(PoseParams P, int h0, const double* __restrict__ n1, const double* __restrict__ n2,
+// A wave covers (64 / hc) frame pairs x hc consecutive hypotheses: the first launch uses hc = 16 (4 pairs per
+// wave: the adaptive stop usually ends within the first few samples, so 4x fewer 118-KB-LDS workgroups
+// compete with the detect kernels of the next batch), later chunks use hc = 64.
+__global__ __launch_bounds__(64) void k_ransac_hyp(PoseParams P, int h0, int hc, int h_end, int npairs,
+                                                   const double* __restrict__ n1, const double* __restrict__ n2,
                                                    const int32_t* __restrict__ samples, const int32_t* __restrict__ rstate,
                                                    double* __restrict__ models, int32_t* __restrict__ hbest) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* ldsM = reinterpret_cast<double*>(smem);
     double* ldsB = ldsM + 200 * 64;
-    const int pair = blockIdx.y, lane = threadIdx.x;
-    const int h = h0 + blockIdx.x * 64 + lane;
+    const int lane = threadIdx.x;
+    const int ppb = 64 / hc;                                       // pairs per block
+    const int pair_raw = blockIdx.y * ppb + lane / hc;
+    const int pair = min(pair_raw, npairs - 1);
+    const int h = h0 + blockIdx.x * hc + (lane % hc);
     const int32_t* rs = rstate + (size_t)pair * RS;
     const int niters = rs[0], M = rs[6];
-    if (h0 + (int)blockIdx.x * 64 >= niters) return;               // adaptive stop already below this block
-    const bool active = h < niters && h < max(P.max_iters, 1);
+    const bool active = pair_raw < npairs && h < niters && h < h_end && h < max(P.max_iters, 1);
+    if (!__any(active)) return;                                    // adaptive stop already below this wave
     const double* pa = n1 + (size_t)pair * P.mcap * 2;
     const double* pb = n2 + (size_t)pair * P.mcap * 2;
     const int hh = active ? h : 0;                                 // inactive lanes redo hypothesis 0 (results dropped)
@@ -589,7 +596,7 @@ __global__ __launch_bounds__(64) void k_ransac_hyp(PoseParams P, int h0, const d
 #pragma unroll
         for (int i = 0; i < 9; i++) E[i] = E[i] / fn;
         int good = 0;
-        for (int i = 0; i < M; i++) good += sampson_inlier(E, pa[2 * i], pa[2 * i + 1], pb[2 * i], pb[2 * i + 1], thr2);
+        for (int i = 0; i < M; i++) good += sampson_inlier(E, pa[2 * i], pa[2 * i + 1], pb[2 * i], pb[2 * i + 1], thr2);   // M is per lane (its pair)
         if (active) {
 #pragma unroll
             for (int k = 0; k < 9; k++) mo[9 * count + k] = E[k];
@@ -825,12 +832,13 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
     }
     hipLaunchKernelGGL(k_pose_prep, dim3(npairs), dim3(256), 0, st, P, d_p1, d_p2, d_npts, d_n1, d_n2, d_samples, d_rstate);
     if (do_ransac) {
-        const int first = std::min(64, std::max(max_iters, 1));
-        hipLaunchKernelGGL(k_ransac_hyp, dim3(1, npairs), dim3(64), HYP_LDS_BYTES, st, P, 0, d_n1, d_n2, d_samples, d_rstate, d_models, d_counts);
+        const int first = std::min(16, std::max(max_iters, 1));
+        hipLaunchKernelGGL(k_ransac_hyp, dim3(1, (npairs + 3) / 4), dim3(64), HYP_LDS_BYTES, st, P, 0, 16, first, npairs, d_n1, d_n2,
+                           d_samples, d_rstate, d_models, d_counts);
         hipLaunchKernelGGL(k_ransac_scan, dim3(npairs), dim3(64), 0, st, P, first, d_counts, d_rstate);
         if (max_iters > first) {
-            hipLaunchKernelGGL(k_ransac_hyp, dim3((max_iters - first + 63) / 64, npairs), dim3(64), HYP_LDS_BYTES, st, P, first, d_n1, d_n2,
-                               d_samples, d_rstate, d_models, d_counts);
+            hipLaunchKernelGGL(k_ransac_hyp, dim3((max_iters - first + 63) / 64, npairs), dim3(64), HYP_LDS_BYTES, st, P, first, 64, max_iters,
+                               npairs, d_n1, d_n2, d_samples, d_rstate, d_models, d_counts);
             hipLaunchKernelGGL(k_ransac_scan, dim3(npairs), dim3(64), 0, st, P, max_iters, d_counts, d_rstate);
         }
     }
