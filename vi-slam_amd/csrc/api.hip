@@ -174,7 +174,7 @@ void plan_destroy(Plan* pl) {
     F(pl->d_kps); F(pl->d_desc); F(pl->d_nkp);
     F(pl->d_pair_q); F(pl->d_pair_t); F(pl->d_pair_q_noprev); F(pl->d_knn12); F(pl->d_knn21);
     F(pl->d_sym); F(pl->d_nsym); F(pl->d_good); F(pl->d_ngood); F(pl->d_p1); F(pl->d_p2); F(pl->d_hf); F(pl->d_wf);
-    F(pl->d_n1); F(pl->d_n2); F(pl->d_mask); F(pl->d_samples); F(pl->d_models); F(pl->d_counts); F(pl->d_rstate); F(pl->d_pose);
+    F(pl->d_n1); F(pl->d_n2); F(pl->d_mask); F(pl->d_samples); F(pl->d_models); F(pl->d_counts); F(pl->d_rstate); F(pl->d_pose); F(pl->d_worklist);
     delete pl;
 }
 
@@ -233,6 +233,7 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
     DALLOC(pl->d_counts, (size_t)npairs * pl->max_iters * 10);
     DALLOC(pl->d_rstate, (size_t)npairs * VIS_RSTATE_WORDS);
     DALLOC(pl->d_pose, npairs);
+    DALLOC(pl->d_worklist, (size_t)npairs + 1);
     HIPCHK(ctx, hipMemset(pl->d_pose, 0, (size_t)npairs * sizeof(PoseOut)));
     { int rc2 = vis_build_sample_table(ctx, ncell); if (rc2) { plan_destroy(pl); return rc2; } }
     *out = pl;
@@ -273,7 +274,7 @@ int vis_build_sample_table(vis_ctx* ctx, int max_m) {
 int launch_pose(vis_ctx* ctx, Plan* pl, int npairs) {
     if (npairs <= 0) return VIS_OK;
     return pose_run(ctx, npairs, pl->root * pl->root, pl->max_iters, pl->d_p1, pl->d_p2, pl->d_ngood, pl->d_n1, pl->d_n2,
-                    pl->d_samples, pl->d_models, pl->d_counts, pl->d_rstate, nullptr, pl->d_mask, pl->d_pose, 1, 1);
+                    pl->d_samples, pl->d_models, pl->d_counts, pl->d_rstate, nullptr, pl->d_mask, pl->d_pose, 1, 1, pl->d_worklist);
 }
 
 static int ensure_scratch(vis_ctx* ctx, size_t bytes) {
@@ -548,6 +549,7 @@ static int pose_host(vis_ctx* ctx, const float* p1xy, const float* p2xy, int m, 
     double* d_E = cv.take<double>(9);
     uint8_t* d_mask = cv.take<uint8_t>(mcap);
     PoseOut* d_pose = cv.take<PoseOut>(1);
+    int32_t* d_worklist = cv.take<int32_t>(2);
     if (m) {
         HIPCHK(ctx, hipMemcpy(d_p1, p1xy, (size_t)m * 8, hipMemcpyHostToDevice));
         HIPCHK(ctx, hipMemcpy(d_p2, p2xy, (size_t)m * 8, hipMemcpyHostToDevice));
@@ -559,7 +561,7 @@ static int pose_host(vis_ctx* ctx, const float* p1xy, const float* p2xy, int m, 
     if (rc) return rc;
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[6], ctx->stream);
     rc = pose_run(ctx, 1, mcap, iters, d_p1, d_p2, d_npts, d_n1, d_n2, d_samples, d_models, d_counts, d_rstate,
-                  E_in ? d_E : nullptr, d_mask, d_pose, do_ransac, do_pose);
+                  E_in ? d_E : nullptr, d_mask, d_pose, do_ransac, do_pose, d_worklist);
     if (rc) return rc;
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[7], ctx->stream);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -301,18 +301,22 @@ __global__ __launch_bounds__(256) void k_pose_prep(PoseParams P, const float* __
 // A wave covers (64 / hc) frame pairs x hc consecutive hypotheses: the first launch uses hc = 16 (4 pairs per
 // wave: the adaptive stop usually ends within the first few samples, so 4x fewer 118-KB-LDS workgroups
 // compete with the detect kernels of the next batch), later chunks use hc = 64.
-__global__ __launch_bounds__(64) void k_ransac_hyp(PoseParams P, int h0, int hc, int h_end, int npairs,
-                                                   const double* __restrict__ n1, const double* __restrict__ n2,
-                                                   const int32_t* __restrict__ samples, const int32_t* __restrict__ rstate,
-                                                   double* __restrict__ models, int32_t* __restrict__ hbest) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* ldsM = reinterpret_cast<double*>(smem);
-    double* ldsB = ldsM + 200 * 64;
+// Later chunks (h >= 16) are only needed for the pairs whose adaptive bound is still above 16 after the
+// first scan: k_ransac_scan appends those pairs to a work list and a SMALL fixed grid walks the list
+// (worklist != nullptr), so the common case "nothing left to do" costs a handful of workgroups instead of
+// thousands of 118-KB-LDS workgroups that exit immediately.
+// The hypothesis body is one (large) device function shared by two entry points: the direct grid used for
+// the first chunk and the work-list walker used for the later ones.
+__device__ __forceinline__ void ransac_hyp_body(const PoseParams& P, int h0, int hc, int h_end, int npairs, int bx, int by,
+                                             const double* __restrict__ n1, const double* __restrict__ n2,
+                                             const int32_t* __restrict__ samples, const int32_t* __restrict__ rstate,
+                                             double* __restrict__ models, int32_t* __restrict__ hbest,
+                                             double* ldsM, double* ldsB) {
     const int lane = threadIdx.x;
     const int ppb = 64 / hc;                                       // pairs per block
-    const int pair_raw = blockIdx.y * ppb + lane / hc;
+    const int pair_raw = by * ppb + lane / hc;
     const int pair = min(pair_raw, npairs - 1);
-    const int h = h0 + blockIdx.x * hc + (lane % hc);
+    const int h = h0 + bx * hc + (lane % hc);
     const int32_t* rs = rstate + (size_t)pair * RS;
     const int niters = rs[0], M = rs[6];
     const bool active = pair_raw < npairs && h < niters && h < h_end && h < max(P.max_iters, 1);
@@ -607,6 +611,32 @@ __global__ __launch_bounds__(64) void k_ransac_hyp(PoseParams P, int h0, int hc,
     if (active) hbest[(size_t)pair * P.max_iters + h] = count ? ((bestc << 4) | bestm) : -1;
 }
 
+__global__ __launch_bounds__(64) void k_ransac_hyp(PoseParams P, int h0, int hc, int h_end, int npairs,
+                                                   const double* __restrict__ n1, const double* __restrict__ n2,
+                                                   const int32_t* __restrict__ samples, const int32_t* __restrict__ rstate,
+                                                   double* __restrict__ models, int32_t* __restrict__ hbest) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* ldsM = reinterpret_cast<double*>(smem);
+    ransac_hyp_body(P, h0, hc, h_end, npairs, blockIdx.x, blockIdx.y, n1, n2, samples, rstate, models, hbest, ldsM, ldsM + 200 * 64);
+}
+
+// Later chunks (h >= 16) are only needed for the pairs whose adaptive bound is still above 16 after the
+// first scan: k_ransac_scan appends those pairs to a work list and a SMALL fixed grid walks the list, so
+// the common case "nothing left to do" costs a handful of workgroups instead of thousands of 118-KB-LDS
+// workgroups that exit immediately.
+__global__ __launch_bounds__(64) void k_ransac_hyp_list(PoseParams P, int h0, int h_end, int npairs,
+                                                        const double* __restrict__ n1, const double* __restrict__ n2,
+                                                        const int32_t* __restrict__ samples, const int32_t* __restrict__ rstate,
+                                                        double* __restrict__ models, int32_t* __restrict__ hbest,
+                                                        const int32_t* __restrict__ worklist, int chunks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* ldsM = reinterpret_cast<double*>(smem);
+    const int total = worklist[0] * chunks;
+    for (int wi = blockIdx.x; wi < total; wi += gridDim.x)
+        ransac_hyp_body(P, h0, 64, h_end, npairs, wi % chunks, worklist[1 + wi / chunks], n1, n2, samples, rstate, models, hbest,
+                        ldsM, ldsM + 200 * 64);
+}
+
 DEV int update_num_iters(double p, double ep, int modelPoints, int maxIters) {
     p = fmax(p, 0.); p = fmin(p, 1.);
     ep = fmax(ep, 0.); ep = fmin(ep, 1.);
@@ -622,7 +652,8 @@ DEV int update_num_iters(double p, double ep, int modelPoints, int maxIters) {
 // carry the same scalar state).  Within one iteration only its best count matters: counts are accepted
 // in model order when strictly greater, so the survivor is the first model reaching the iteration's
 // maximum, and the iteration bound only ever shrinks with larger counts.
-__global__ __launch_bounds__(64) void k_ransac_scan(PoseParams P, int hi, const int32_t* __restrict__ hbest, int32_t* __restrict__ rstate) {
+__global__ __launch_bounds__(64) void k_ransac_scan(PoseParams P, int hi, const int32_t* __restrict__ hbest, int32_t* __restrict__ rstate,
+                                                    int32_t* __restrict__ worklist) {
     const int pair = blockIdx.x, lane = threadIdx.x;
     int32_t* rs = rstate + (size_t)pair * RS;
     if (rs[5] != 0) { if (rs[5] == 1 && lane == 0) { rs[2] = 0; rs[3] = 0; rs[1] = 5; rs[7] = 1; rs[4] = 1; } return; }
@@ -643,7 +674,10 @@ __global__ __launch_bounds__(64) void k_ransac_scan(PoseParams P, int hi, const 
             }
         }
     }
-    if (lane == 0) { rs[0] = niters; rs[1] = maxGood; rs[2] = bi; rs[3] = bm; rs[4] = iter; rs[7] = iter; }
+    if (lane == 0) {
+        rs[0] = niters; rs[1] = maxGood; rs[2] = bi; rs[3] = bm; rs[4] = iter; rs[7] = iter;
+        if (worklist && niters > hi && hi < P.max_iters) worklist[1 + atomicAdd(&worklist[0], 1)] = pair;   // needs more hypotheses
+    }
 }
 
 __device__ void svd3_decompose(const double* E, double* U, double* Vt) {
@@ -822,24 +856,28 @@ static PoseParams make_pose_params(const vis_ctx* ctx, int max_iters, int mcap) 
 // d_p1/d_p2: npairs x mcap x 2 floats; d_npts: npairs
 int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p1, const float* d_p2, const int32_t* d_npts,
              double* d_n1, double* d_n2, int32_t* d_samples, double* d_models, int32_t* d_counts, int32_t* d_rstate,
-             const double* d_E_in, uint8_t* d_mask, PoseOut* d_pose, int do_ransac, int do_pose) {
+             const double* d_E_in, uint8_t* d_mask, PoseOut* d_pose, int do_ransac, int do_pose, int32_t* d_worklist) {
     hipStream_t st = ctx->stream;
     PoseParams P = make_pose_params(ctx, max_iters, mcap);
     static bool attr_set = false;
     if (!attr_set) {
         HIPCHK(ctx, hipFuncSetAttribute((const void*)k_ransac_hyp, hipFuncAttributeMaxDynamicSharedMemorySize, HYP_LDS_BYTES));
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)k_ransac_hyp_list, hipFuncAttributeMaxDynamicSharedMemorySize, HYP_LDS_BYTES));
         attr_set = true;
     }
     hipLaunchKernelGGL(k_pose_prep, dim3(npairs), dim3(256), 0, st, P, d_p1, d_p2, d_npts, d_n1, d_n2, d_samples, d_rstate);
     if (do_ransac) {
         const int first = std::min(16, std::max(max_iters, 1));
+        HIPCHK(ctx, hipMemsetAsync(d_worklist, 0, sizeof(int32_t), st));
         hipLaunchKernelGGL(k_ransac_hyp, dim3(1, (npairs + 3) / 4), dim3(64), HYP_LDS_BYTES, st, P, 0, 16, first, npairs, d_n1, d_n2,
                            d_samples, d_rstate, d_models, d_counts);
-        hipLaunchKernelGGL(k_ransac_scan, dim3(npairs), dim3(64), 0, st, P, first, d_counts, d_rstate);
+        hipLaunchKernelGGL(k_ransac_scan, dim3(npairs), dim3(64), 0, st, P, first, d_counts, d_rstate, d_worklist);
         if (max_iters > first) {
-            hipLaunchKernelGGL(k_ransac_hyp, dim3((max_iters - first + 63) / 64, npairs), dim3(64), HYP_LDS_BYTES, st, P, first, 64, max_iters,
-                               npairs, d_n1, d_n2, d_samples, d_rstate, d_models, d_counts);
-            hipLaunchKernelGGL(k_ransac_scan, dim3(npairs), dim3(64), 0, st, P, max_iters, d_counts, d_rstate);
+            const int chunks = (max_iters - first + 63) / 64;
+            const int nb = std::min(256, npairs * chunks);
+            hipLaunchKernelGGL(k_ransac_hyp_list, dim3(nb), dim3(64), HYP_LDS_BYTES, st, P, first, max_iters,
+                               npairs, d_n1, d_n2, d_samples, d_rstate, d_models, d_counts, (const int32_t*)d_worklist, chunks);
+            hipLaunchKernelGGL(k_ransac_scan, dim3(npairs), dim3(64), 0, st, P, max_iters, d_counts, d_rstate, (int32_t*)nullptr);
         }
     }
     hipLaunchKernelGGL(k_pose_final, dim3(npairs), dim3(256), 0, st, P, d_n1, d_n2, d_models, d_rstate, d_E_in, d_mask, d_pose, do_pose);
