@@ -171,7 +171,7 @@ void plan_destroy(Plan* pl) {
         F(pl->d_cand[l]); F(pl->d_seg_kp[l]);
     }
     F(pl->d_tile_cnt); F(pl->d_seg_cnt); F(pl->d_flags); F(pl->d_angle_tab);
-    F(pl->d_kps); F(pl->d_desc); F(pl->d_nkp);
+    F(pl->d_kps); F(pl->d_desc); F(pl->d_nkp); F(pl->d_descx);
     F(pl->d_pair_q); F(pl->d_pair_t); F(pl->d_pair_q_noprev); F(pl->d_knn12); F(pl->d_knn21);
     F(pl->d_sym); F(pl->d_nsym); F(pl->d_good); F(pl->d_ngood); F(pl->d_p1); F(pl->d_p2); F(pl->d_hf); F(pl->d_wf);
     F(pl->d_n1); F(pl->d_n2); F(pl->d_mask); F(pl->d_samples); F(pl->d_models); F(pl->d_counts); F(pl->d_rstate); F(pl->d_pose); F(pl->d_worklist);
@@ -209,6 +209,7 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
     DALLOC(pl->d_kps, (size_t)nrec * kcap); DALLOC(pl->d_desc, (size_t)nrec * kcap * 32); DALLOC(pl->d_nkp, nrec);
     HIPCHK(ctx, hipMemset(pl->d_nkp, 0, (size_t)nrec * 4));
     HIPCHK(ctx, hipMemset(pl->d_desc, 0, (size_t)nrec * kcap * 32));
+    DALLOC(pl->d_descx, (size_t)nrec * kcap * 256);
     DALLOC(pl->d_pair_q, npairs); DALLOC(pl->d_pair_t, npairs); DALLOC(pl->d_pair_q_noprev, npairs);
     {
         std::vector<int32_t> q(npairs), t(npairs), qn(npairs);
@@ -395,7 +396,9 @@ extern "C" int vis_bf_knn2_hamming(vis_ctx* ctx, int slot_q, int slot_t, vis_dma
     int rc = set_single_pair(ctx, pl, slot_q, slot_t);
     if (rc) return rc;
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[4], ctx->stream);
-    rc = launch_match(ctx, pl, 1);
+    rc = launch_expand(ctx, pl, slot_q, 1);
+    if (!rc && slot_t != slot_q) rc = launch_expand(ctx, pl, slot_t, 1);
+    if (!rc) rc = launch_match(ctx, pl, 1);
     if (rc) return rc;
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[5], ctx->stream);
     int32_t nq = 0, nt = 0;
@@ -414,7 +417,7 @@ extern "C" int vis_bf_knn2_hamming_host(vis_ctx* ctx, const uint8_t* desc_q, int
     if (n_q > 65535 || n_t > 65535) return VIS_E_INVALID;
     (void)hipSetDevice(ctx->device);
     const int kcap = std::max(std::max(n_q, n_t), 1);
-    int rc = ensure_scratch(ctx, (size_t)kcap * 32 * 2 + (size_t)kcap * 8 * 2 + 4096);
+    int rc = ensure_scratch(ctx, (size_t)kcap * 32 * 2 + (size_t)kcap * 8 * 2 + (size_t)kcap * 512 + 8192);
     if (rc) return rc;
     Carver cv{(char*)ctx->d_scratch, 0};
     Plan tp;
@@ -422,6 +425,7 @@ extern "C" int vis_bf_knn2_hamming_host(vis_ctx* ctx, const uint8_t* desc_q, int
     tp.d_desc = cv.take<uint8_t>((size_t)kcap * 64);
     tp.d_nkp = cv.take<int32_t>(2); tp.d_pair_q = cv.take<int32_t>(1); tp.d_pair_t = cv.take<int32_t>(1);
     tp.d_knn12 = cv.take<uint32_t>((size_t)kcap * 2); tp.d_knn21 = cv.take<uint32_t>((size_t)kcap * 2);
+    tp.d_descx = cv.take<int8_t>((size_t)kcap * 512);
     const int32_t nk[2] = {n_q, n_t}, zero = 0, one = 1;
     if (n_q) HIPCHK(ctx, hipMemcpy(tp.d_desc, desc_q, (size_t)n_q * 32, hipMemcpyHostToDevice));
     if (n_t) HIPCHK(ctx, hipMemcpy(tp.d_desc + (size_t)kcap * 32, desc_t, (size_t)n_t * 32, hipMemcpyHostToDevice));
@@ -429,7 +433,8 @@ extern "C" int vis_bf_knn2_hamming_host(vis_ctx* ctx, const uint8_t* desc_q, int
     HIPCHK(ctx, hipMemcpy(tp.d_pair_q, &zero, 4, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(tp.d_pair_t, &one, 4, hipMemcpyHostToDevice));
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[4], ctx->stream);
-    rc = launch_match(ctx, &tp, 1);
+    rc = launch_expand(ctx, &tp, 0, 2);
+    if (!rc) rc = launch_match(ctx, &tp, 1);
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[5], ctx->stream);
     if (rc) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -467,7 +472,9 @@ extern "C" int vis_good_matches(vis_ctx* ctx, int slot_prev, int slot_cur, vis_d
     int rc = set_single_pair(ctx, pl, slot_prev, slot_cur);
     if (rc) return rc;
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[4], ctx->stream);
-    rc = launch_match(ctx, pl, 1);
+    rc = launch_expand(ctx, pl, slot_prev, 1);
+    if (!rc && slot_cur != slot_prev) rc = launch_expand(ctx, pl, slot_cur, 1);
+    if (!rc) rc = launch_match(ctx, pl, 1);
     if (rc) return rc;
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[5], ctx->stream);
     rc = launch_filter(ctx, pl, 1);
@@ -667,7 +674,8 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
     if (!pl->have_prev) pl->d_pair_q = pl->d_pair_q_noprev;
     rc = VIS_OK;
     if (stages & VIS_STAGE_MATCH) {
-        rc = launch_match(ctx, pl, n);
+        rc = launch_expand(ctx, pl, 0, n + 1);
+        if (!rc) rc = launch_match(ctx, pl, n);
         if (!rc) {
             if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[5], st);
             // the filter rewrites the pose inputs of the previous batch: wait until its pose work is done

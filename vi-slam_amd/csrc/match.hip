@@ -9,6 +9,7 @@
 //          reference's O(N1*N2) iterator scan.
 // Bit-exact against oracle/match.cpp (tests/test_match_gpu.py).
 #include "vis_internal.h"
+#include <cstdlib>
 
 // One lane = one query row; the train descriptor of the current iteration is wave-uniform, so the
 // compiler keeps it in SGPRs (s_load_dwordx8) and the inner loop is 8 x (v_xor, v_bcnt accumulate)
@@ -64,6 +65,111 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ desc, 
     uint32_t* outp = (dir == 0 ? knn12 : knn21) + (size_t)pair * kcap * 2;
     if (q0i < nq) { outp[2 * q0i] = k0; outp[2 * q0i + 1] = k1; }
     if (q1i < nq) { outp[2 * q1i] = j0; outp[2 * q1i + 1] = j1; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA formulation of the same 2-NN (default path).  Every hot kernel of this library is bound by the
+// integer VALU issue rate (~0.62 T wave-instructions/s measured, tools/valu_peak.hip); the matrix pipe is
+// idle.  With descriptor bits expanded to int8 +1/-1, sum_k a_k b_k = 256 - 2*Hamming, so one
+// v_mfma_i32_32x32x32_i8 chain (K = 256 = 8 instructions) yields a 32 x 32 block of exact distances and
+// the VALU only maintains the packed top-2 keys: ~6 VALU instructions per pair instead of 19.
+// Columns (lane & 31) = the 32 descriptors whose neighbours this wave tracks (B operand, in registers);
+// rows = the swept set, staged through LDS 32 descriptors at a time (row stride 272 B: conflict-free
+// ds_read_b128).  Results are bit-identical to k_knn2 (same key order): tests/test_match_gpu.py.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void k_expand(const uint8_t* __restrict__ desc, const int32_t* __restrict__ nkp, int kcap,
+                                                int8_t* __restrict__ X, int rec_first, int rec_count) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long dsc = gid >> 4;
+    const int part = (int)(gid & 15);
+    const int rec_i = (int)(dsc / kcap), i = (int)(dsc - (long long)rec_i * kcap);
+    if (rec_i >= rec_count) return;
+    const int rec = rec_first + rec_i;
+    if (i >= min(nkp[rec], kcap)) return;
+    const uint8_t* d = desc + ((size_t)rec * kcap + i) * 32 + 2 * part;
+    const uint32_t bits = (uint32_t)d[0] | ((uint32_t)d[1] << 8);
+    uint32_t o[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        const uint32_t spread = (((bits >> (4 * n)) & 0xFu) * 0x00204081u) & 0x01010101u;     // 4 bits -> 4 bytes of 0/1
+        o[n] = spread | ((spread ^ 0x01010101u) * 0xFFu);                                       // 1 -> +1, 0 -> -1 (0xFF)
+    }
+    *reinterpret_cast<uint4*>(X + ((size_t)rec * kcap + i) * 256 + 16 * part) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+#define KM_ROW 17            // uint4 per LDS row: 256 B of descriptor + 16 B pad
+__global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, const int32_t* __restrict__ nkp, int kcap,
+                                                  const int32_t* __restrict__ pair_q, const int32_t* __restrict__ pair_t,
+                                                  uint32_t* __restrict__ knn12, uint32_t* __restrict__ knn21) {
+    __shared__ __attribute__((aligned(16))) uint4 tile[2][32 * KM_ROW];
+    const int pair = blockIdx.y, dir = blockIdx.z;
+    const int rf = dir == 0 ? pair_q[pair] : pair_t[pair];        // fixed set: top-2 tracked per descriptor
+    const int rs = dir == 0 ? pair_t[pair] : pair_q[pair];        // swept set
+    if (rf < 0 || rs < 0) return;
+    const int nf = min(nkp[rf], kcap), ns = min(nkp[rs], kcap);
+    const int fbase = blockIdx.x * 128;
+    if (fbase >= nf) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int fidx = fbase + wave * 32 + col;
+    v4i bf[8];
+    {
+        const int8_t* xf = X + ((size_t)rf * kcap + min(fidx, nf - 1)) * 256 + 16 * h;
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) bf[ks] = *reinterpret_cast<const v4i*>(xf + 32 * ks);
+    }
+    const int8_t* xs = X + (size_t)rs * kcap * 256;
+    const int ntiles = (ns + 31) / 32;
+    auto stage = [&](int t, int buf) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int idx = tid + 256 * k;
+            const int row = idx >> 4, c16 = idx & 15;
+            const int srow = min(t * 32 + row, ns - 1);
+            tile[buf][row * KM_ROW + c16] = *reinterpret_cast<const uint4*>(xs + (size_t)srow * 256 + 16 * c16);
+        }
+    };
+    uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
+    if (ntiles > 0) stage(0, 0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; t++) {
+        if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
+        const uint4* tb = tile[t & 1] + col * KM_ROW + h;
+        v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) {
+            const uint4 au = tb[2 * ks];
+            const v4i a = {(int)au.x, (int)au.y, (int)au.z, (int)au.w};
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[ks], acc, 0, 0, 0);
+        }
+        const int toff = t * 32 + 4 * h;
+        if (t * 32 + 32 <= ns) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const uint32_t key = ((uint32_t)(256 - acc[r]) << 15) + (uint32_t)(toff + (r & 3) + 8 * (r >> 2));
+                k1 = min(k1, max(k0, key));
+                k0 = min(k0, key);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int trow = toff + (r & 3) + 8 * (r >> 2);
+                const uint32_t key = trow < ns ? (((uint32_t)(256 - acc[r]) << 15) + (uint32_t)trow) : 0xFFFFFFFFu;
+                k1 = min(k1, max(k0, key));
+                k0 = min(k0, key);
+            }
+        }
+        __syncthreads();
+    }
+    // lanes l and l+32 hold the two row halves of the same column
+    const uint32_t o0 = __shfl_xor(k0, 32), o1 = __shfl_xor(k1, 32);
+    const uint32_t m0 = min(k0, o0), m1 = min(max(k0, o0), min(k1, o1));
+    if (h == 0 && fidx < nf) {
+        uint32_t* outp = (dir == 0 ? knn12 : knn21) + ((size_t)pair * kcap + fidx) * 2;
+        outp[0] = m0; outp[1] = m1;
+    }
 }
 
 __device__ __forceinline__ uint32_t fmap_f(float f) {
@@ -195,8 +301,25 @@ __global__ __launch_bounds__(256) void k_filter(const vis_keypoint* __restrict__
     }
 }
 
+int launch_expand(vis_ctx* ctx, Plan* pl, int rec_first, int rec_count) {
+    if (rec_count <= 0 || !pl->d_descx) return VIS_OK;
+    const long long threads = (long long)rec_count * pl->kcap * 16;
+    hipLaunchKernelGGL(k_expand, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, pl->d_desc, pl->d_nkp, pl->kcap,
+                       pl->d_descx, rec_first, rec_count);
+    HIPCHK(ctx, hipGetLastError());
+    return VIS_OK;
+}
+
 int launch_match(vis_ctx* ctx, Plan* pl, int npairs) {
     if (npairs <= 0) return VIS_OK;
+    static const bool force_popcount = getenv("VIS_KNN_POPCOUNT") != nullptr;     // A/B measurements only
+    if (pl->d_descx && pl->kcap < 32768 && !force_popcount) {
+        dim3 grid((pl->kcap + 127) / 128, npairs, 2);
+        hipLaunchKernelGGL(k_knn_mfma, grid, dim3(256), 0, ctx->stream, pl->d_descx, pl->d_nkp, pl->kcap,
+                           pl->d_pair_q, pl->d_pair_t, pl->d_knn12, pl->d_knn21);
+        HIPCHK(ctx, hipGetLastError());
+        return VIS_OK;
+    }
     // small problems: one wave per block so a single pair still spreads over many CUs
     const int bs = (npairs * ((pl->kcap + 255) / 256) * 2 >= 512) ? 256 : 64;
     dim3 grid((pl->kcap + 2 * bs - 1) / (2 * bs), npairs, 2);

@@ -52,6 +52,7 @@ struct Plan {
     vis_keypoint* d_kps = nullptr;           // nrec x kcap
     uint8_t* d_desc = nullptr;               // nrec x kcap x 32
     int32_t* d_nkp = nullptr;                // nrec
+    int8_t* d_descx = nullptr;               // nrec x kcap x 256: descriptor bits as int8 +1/-1 (MFMA matcher operand)
     // pairs
     int32_t* d_pair_q = nullptr;             // npairs: query record index (-1 = no pair)
     int32_t* d_pair_t = nullptr;
@@ -119,6 +120,7 @@ void plan_destroy(Plan* pl);
 
 // ---- kernel launchers (each enqueues on ctx->stream) ----
 int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int rec0);
+int launch_expand(vis_ctx* ctx, Plan* pl, int rec_first, int rec_count);
 int launch_match(vis_ctx* ctx, Plan* pl, int npairs);
 int launch_filter(vis_ctx* ctx, Plan* pl, int npairs);
 int launch_pose(vis_ctx* ctx, Plan* pl, int npairs);
