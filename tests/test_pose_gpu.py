@@ -117,3 +117,33 @@ def test_batch_pipeline_pose(vislam, orc, canvas):
             assert np.abs(pose["R"] - np.array(r.R).reshape(3, 3)).max() <= 1e-7
             assert np.abs(pose["t"] - np.array(r.t)).max() <= 1e-7
     c.close()
+
+
+def test_recycled_device_memory_does_not_leak_into_results(vislam, orc, canvas):
+    """regression: lanes of a RANSAC wave whose pair has no work (first frame of a stream: M = 0) once read
+    never-written sample slots; with recycled device memory that became an out-of-bounds index.  Poison the
+    allocator with a context that is destroyed, then run a fresh stream and check parity."""
+    import torch
+    p = vislam.default_params()
+    p.fy = p.fx
+    rng = np.random.default_rng(0)
+    a = vislam.Context(0, p)
+    noise = torch.from_numpy(rng.integers(0, 256, (8, 480, 752), dtype=np.uint8)).cuda()
+    a.batch_plan(752, 480, 752, 8)
+    a.batch_run(noise.data_ptr(), 8)
+    a.batch_sync()
+    a.close()
+    c = vislam.Context(0, p)
+    frames = np.stack([vislam.synth_frame(canvas, t, 752, 480) for t in range(5)])
+    dev = torch.from_numpy(frames).cuda()
+    c.batch_plan(752, 480, 752, 8)
+    c.batch_run(dev.data_ptr(), 5)
+    c.batch_sync()
+    assert c.batch_status() == 0
+    prev = None
+    for t in range(5):
+        ok, od, r = orc.pipeline_frame(p, frames[t], prev)
+        prev = (ok, od)
+        pose = c.batch_pose(t)
+        assert pose["n_inliers"] == r.n_inliers and pose["iters_run"] == r.iters_run
+    c.close()

@@ -74,7 +74,12 @@ extern "C" int vis_create(int device, vis_ctx** out) {
     if (hipStreamCreateWithFlags(&ctx->pose_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_filter_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_pose_done, hipEventDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_pose_start, hipEventDefault) != hipSuccess) { delete ctx; return VIS_E_HIP; }
+        hipEventCreateWithFlags(&ctx->ev_pose_start, hipEventDefault) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->match_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_detect_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_match_start, hipEventDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_match_done[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_match_done[1], hipEventDisableTiming) != hipSuccess) { delete ctx; return VIS_E_HIP; }
     ctx->ev_ok = true;
     for (int i = 0; i < 10; i++) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) ctx->ev_ok = false;
     *out = ctx;
@@ -85,6 +90,7 @@ extern "C" void vis_destroy(vis_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->match_stream) (void)hipStreamSynchronize(ctx->match_stream);
     if (ctx->pose_stream) (void)hipStreamSynchronize(ctx->pose_stream);
     plan_destroy(ctx->single); plan_destroy(ctx->batch);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -94,14 +100,20 @@ extern "C" void vis_destroy(vis_ctx* ctx) {
     if (ctx->ev_filter_done) (void)hipEventDestroy(ctx->ev_filter_done);
     if (ctx->ev_pose_done) (void)hipEventDestroy(ctx->ev_pose_done);
     if (ctx->ev_pose_start) (void)hipEventDestroy(ctx->ev_pose_start);
+    if (ctx->match_stream) { (void)hipStreamSynchronize(ctx->match_stream); (void)hipStreamDestroy(ctx->match_stream); }
+    if (ctx->ev_detect_done) (void)hipEventDestroy(ctx->ev_detect_done);
+    if (ctx->ev_match_start) (void)hipEventDestroy(ctx->ev_match_start);
+    for (int i = 0; i < 2; i++) if (ctx->ev_match_done[i]) (void)hipEventDestroy(ctx->ev_match_done[i]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
 static void sync_all(vis_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->match_stream) (void)hipStreamSynchronize(ctx->match_stream);
     if (ctx->pose_stream) (void)hipStreamSynchronize(ctx->pose_stream);
     ctx->pose_pending = false;
+    if (ctx->batch) ctx->batch->match_pending[0] = ctx->batch->match_pending[1] = false;
 }
 
 extern "C" const char* vis_last_error(vis_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -172,18 +184,20 @@ void plan_destroy(Plan* pl) {
     }
     F(pl->d_tile_cnt); F(pl->d_seg_cnt); F(pl->d_flags); F(pl->d_angle_tab);
     F(pl->d_kps); F(pl->d_desc); F(pl->d_nkp); F(pl->d_descx);
-    F(pl->d_pair_q); F(pl->d_pair_t); F(pl->d_pair_q_noprev); F(pl->d_knn12); F(pl->d_knn21);
+    for (int i = 0; i < 2; i++) { F(pl->d_pq[i]); F(pl->d_pt[i]); F(pl->d_pqn[i]); }
+    F(pl->d_knn12); F(pl->d_knn21);
     F(pl->d_sym); F(pl->d_nsym); F(pl->d_good); F(pl->d_ngood); F(pl->d_p1); F(pl->d_p2); F(pl->d_hf); F(pl->d_wf);
     F(pl->d_n1); F(pl->d_n2); F(pl->d_mask); F(pl->d_samples); F(pl->d_models); F(pl->d_counts); F(pl->d_rstate); F(pl->d_pose); F(pl->d_worklist);
     delete pl;
 }
 
-int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npairs, Plan** out) {
+int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npairs, Plan** out, int nsets) {
     *out = nullptr;
     if (B < 1 || nrec < 1 || npairs < 1 || stride < w || (stride & 3)) return VIS_E_INVALID;
     Plan* pl = new (std::nothrow) Plan();
     if (!pl) return VIS_E_NOMEM;
-    pl->w = w; pl->h = h; pl->stride = stride; pl->B = B; pl->L = ctx->p.nlevels; pl->nrec = nrec; pl->npairs = npairs;
+    pl->w = w; pl->h = h; pl->stride = stride; pl->B = B; pl->L = ctx->p.nlevels; pl->npairs = npairs;
+    pl->nsets = nsets; pl->rec_per_set = nrec; nrec *= nsets; pl->nrec = nrec;
     int rc = vis_compute_levels(ctx->p, w, h, stride, pl->lv);
     if (rc) { delete pl; return rc; }
     const int L = pl->L;
@@ -210,14 +224,16 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
     HIPCHK(ctx, hipMemset(pl->d_nkp, 0, (size_t)nrec * 4));
     HIPCHK(ctx, hipMemset(pl->d_desc, 0, (size_t)nrec * kcap * 32));
     DALLOC(pl->d_descx, (size_t)nrec * kcap * 256);
-    DALLOC(pl->d_pair_q, npairs); DALLOC(pl->d_pair_t, npairs); DALLOC(pl->d_pair_q_noprev, npairs);
-    {
+    for (int sidx = 0; sidx < nsets; sidx++) {
+        DALLOC(pl->d_pq[sidx], npairs); DALLOC(pl->d_pt[sidx], npairs); DALLOC(pl->d_pqn[sidx], npairs);
+        const int base = sidx * pl->rec_per_set;
         std::vector<int32_t> q(npairs), t(npairs), qn(npairs);
-        for (int i = 0; i < npairs; i++) { q[i] = i; t[i] = i + 1; qn[i] = i == 0 ? -1 : i; }
-        HIPCHK(ctx, hipMemcpy(pl->d_pair_q, q.data(), (size_t)npairs * 4, hipMemcpyHostToDevice));
-        HIPCHK(ctx, hipMemcpy(pl->d_pair_t, t.data(), (size_t)npairs * 4, hipMemcpyHostToDevice));
-        HIPCHK(ctx, hipMemcpy(pl->d_pair_q_noprev, qn.data(), (size_t)npairs * 4, hipMemcpyHostToDevice));
+        for (int i = 0; i < npairs; i++) { q[i] = base + i; t[i] = base + i + 1; qn[i] = i == 0 ? -1 : base + i; }
+        HIPCHK(ctx, hipMemcpy(pl->d_pq[sidx], q.data(), (size_t)npairs * 4, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(pl->d_pt[sidx], t.data(), (size_t)npairs * 4, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(pl->d_pqn[sidx], qn.data(), (size_t)npairs * 4, hipMemcpyHostToDevice));
     }
+    pl->d_pair_q = pl->d_pq[0]; pl->d_pair_t = pl->d_pt[0]; pl->d_pair_q_noprev = pl->d_pqn[0];
     DALLOC(pl->d_knn12, (size_t)npairs * kcap * 2); DALLOC(pl->d_knn21, (size_t)npairs * kcap * 2);
     DALLOC(pl->d_sym, (size_t)npairs * kcap); DALLOC(pl->d_nsym, npairs);
     DALLOC(pl->d_good, (size_t)npairs * ncell); DALLOC(pl->d_ngood, npairs);
@@ -235,6 +251,16 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
     DALLOC(pl->d_rstate, (size_t)npairs * VIS_RSTATE_WORDS);
     DALLOC(pl->d_pose, npairs);
     DALLOC(pl->d_worklist, (size_t)npairs + 1);
+    // defence in depth: nothing should read these before writing them, but a recycled allocation must never
+    // turn a missed guard into an out-of-bounds index (see the inactive-lane fix in k_ransac_hyp)
+    HIPCHK(ctx, hipMemset(pl->d_samples, 0, (size_t)npairs * pl->max_iters * 5 * sizeof(int32_t)));
+    HIPCHK(ctx, hipMemset(pl->d_counts, 0xFF, (size_t)npairs * pl->max_iters * 10 * sizeof(int32_t)));
+    HIPCHK(ctx, hipMemset(pl->d_rstate, 0, (size_t)npairs * VIS_RSTATE_WORDS * sizeof(int32_t)));
+    HIPCHK(ctx, hipMemset(pl->d_worklist, 0, ((size_t)npairs + 1) * sizeof(int32_t)));
+    HIPCHK(ctx, hipMemset(pl->d_knn12, 0xFF, (size_t)npairs * kcap * 2 * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMemset(pl->d_knn21, 0xFF, (size_t)npairs * kcap * 2 * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMemset(pl->d_p1, 0, (size_t)npairs * ncell * 2 * sizeof(float)));
+    HIPCHK(ctx, hipMemset(pl->d_p2, 0, (size_t)npairs * ncell * 2 * sizeof(float)));
     HIPCHK(ctx, hipMemset(pl->d_pose, 0, (size_t)npairs * sizeof(PoseOut)));
     { int rc2 = vis_build_sample_table(ctx, ncell); if (rc2) { plan_destroy(pl); return rc2; } }
     *out = pl;
@@ -639,87 +665,100 @@ extern "C" int vis_batch_plan(vis_ctx* ctx, int w, int h, int stride, int max_fr
     (void)hipSetDevice(ctx->device);
     sync_all(ctx);
     plan_destroy(ctx->batch); ctx->batch = nullptr;
-    return plan_create(ctx, w, h, stride, max_frames, max_frames + 1, max_frames, &ctx->batch);
+    return plan_create(ctx, w, h, stride, max_frames, max_frames + 1, max_frames, &ctx->batch, 2);
 }
 
 extern "C" int vis_batch_reset(vis_ctx* ctx) {
     if (!ctx || !ctx->batch) return VIS_E_STATE;
+    sync_all(ctx);
     ctx->batch->have_prev = false; ctx->batch->last_n = 0; ctx->batch->carry_from = 0; ctx->batch->pair0_valid = false;
     return VIS_OK;
 }
 
+// Three streams per context: A = detect chain (caller's / own stream), M = expand + knn + filters,
+// P = RANSAC + recoverPose.  Batch i+1's detect chain overlaps batch i's matcher (MFMA + LDS, little VALU)
+// and pose (latency-bound FP64): the records (keypoints, descriptors, expanded descriptors) are double
+// buffered, everything else is single buffered and ordered with events.
 extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int stages) {
     if (!ctx || !d_frames) return VIS_E_INVALID;
     Plan* pl = ctx->batch;
     if (!pl) return VIS_E_STATE;
     if (n < 1 || n > pl->B || ((uintptr_t)d_frames & 3)) return VIS_E_INVALID;
     (void)hipSetDevice(ctx->device);
-    hipStream_t st = ctx->stream;
+    hipStream_t sA = ctx->stream, sM = ctx->match_stream, sP = ctx->pose_stream;
     ctx->tm.launches_total = 0;
-    // carry the previous batch's last frame (record last_n) into record 0 before it is overwritten
-    if ((stages & VIS_STAGE_DETECT) && pl->carry_from > 0) {
-        const int c = pl->carry_from;
-        HIPCHK(ctx, hipMemcpyAsync(pl->d_kps, pl->d_kps + (size_t)c * pl->kcap, (size_t)pl->kcap * sizeof(vis_keypoint), hipMemcpyDeviceToDevice, st));
-        HIPCHK(ctx, hipMemcpyAsync(pl->d_desc, pl->d_desc + (size_t)c * pl->kcap * 32, (size_t)pl->kcap * 32, hipMemcpyDeviceToDevice, st));
-        HIPCHK(ctx, hipMemcpyAsync(pl->d_nkp, pl->d_nkp + c, 4, hipMemcpyDeviceToDevice, st));
-        pl->have_prev = true; pl->carry_from = 0;
+    const bool detect = (stages & VIS_STAGE_DETECT) != 0;
+    const int cur = detect ? (pl->run_count++ & 1) : (pl->last_base / pl->rec_per_set);
+    const int base = cur * pl->rec_per_set;
+    int rc = VIS_OK;
+    if (detect) {
+        // this record set was last read by the matcher two batches ago
+        if (pl->match_pending[cur]) HIPCHK(ctx, hipStreamWaitEvent(sA, ctx->ev_match_done[cur], 0));
+        if (pl->carry_from > 0) {      // previous batch's last frame -> record 0 of this set
+            const int c = pl->carry_from;
+            HIPCHK(ctx, hipMemcpyAsync(pl->d_kps + (size_t)base * pl->kcap, pl->d_kps + (size_t)c * pl->kcap, (size_t)pl->kcap * sizeof(vis_keypoint), hipMemcpyDeviceToDevice, sA));
+            HIPCHK(ctx, hipMemcpyAsync(pl->d_desc + (size_t)base * pl->kcap * 32, pl->d_desc + (size_t)c * pl->kcap * 32, (size_t)pl->kcap * 32, hipMemcpyDeviceToDevice, sA));
+            HIPCHK(ctx, hipMemcpyAsync(pl->d_nkp + base, pl->d_nkp + c, 4, hipMemcpyDeviceToDevice, sA));
+            pl->have_prev = true; pl->carry_from = 0;
+        }
     }
     pl->pair0_valid = pl->have_prev;
-    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[0], st);
-    int rc;
-    if (stages & VIS_STAGE_DETECT) { rc = launch_detect(ctx, pl, d_frames, n, 1); if (rc) return rc; }
-    else if (ctx->ev_ok) for (int i = 1; i <= 4; i++) (void)hipEventRecord(ctx->ev[i], st);
-    // pair i: query = record i (frame i-1, or the carried frame for i = 0), train = record i+1 (frame i)
-    int32_t* saved_q = pl->d_pair_q;
-    if (!pl->have_prev) pl->d_pair_q = pl->d_pair_q_noprev;
-    rc = VIS_OK;
+    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[0], sA);
+    if (detect) { rc = launch_detect(ctx, pl, d_frames, n, base + 1); if (rc) return rc; }
+    else if (ctx->ev_ok) for (int i = 1; i <= 4; i++) (void)hipEventRecord(ctx->ev[i], sA);
+    HIPCHK(ctx, hipEventRecord(ctx->ev_detect_done, sA));
+    if (stages & (VIS_STAGE_MATCH | VIS_STAGE_POSE)) HIPCHK(ctx, hipStreamWaitEvent(sM, ctx->ev_detect_done, 0));
+    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev_match_start, sM);
+    // pair i: query = record base+i (frame i-1, or the carried frame for i = 0), train = record base+i+1 (frame i)
+    pl->d_pair_q = pl->have_prev ? pl->d_pq[cur] : pl->d_pqn[cur];
+    pl->d_pair_t = pl->d_pt[cur];
+    ctx->stream = sM;
     if (stages & VIS_STAGE_MATCH) {
-        rc = launch_expand(ctx, pl, 0, n + 1);
+        rc = launch_expand(ctx, pl, base, n + 1);
         if (!rc) rc = launch_match(ctx, pl, n);
         if (!rc) {
-            if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[5], st);
+            if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[5], sM);
             // the filter rewrites the pose inputs of the previous batch: wait until its pose work is done
-            if (ctx->pose_pending) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_pose_done, 0));
-            rc = launch_filter(ctx, pl, n);
+            if (ctx->pose_pending) { hipError_t e = hipStreamWaitEvent(sM, ctx->ev_pose_done, 0); if (e != hipSuccess) rc = VIS_E_HIP; }
+            if (!rc) rc = launch_filter(ctx, pl, n);
         }
-        if (!rc && ctx->ev_ok) (void)hipEventRecord(ctx->ev[6], st);
-    } else if (ctx->ev_ok) { (void)hipEventRecord(ctx->ev[5], st); (void)hipEventRecord(ctx->ev[6], st); }
+        if (!rc && ctx->ev_ok) (void)hipEventRecord(ctx->ev[6], sM);
+        if (!rc) { (void)hipEventRecord(ctx->ev_match_done[cur], sM); pl->match_pending[cur] = true; }
+    } else if (ctx->ev_ok) { (void)hipEventRecord(ctx->ev[5], sM); (void)hipEventRecord(ctx->ev[6], sM); }
     if (!rc && (stages & VIS_STAGE_POSE)) {
-        // RANSAC + recoverPose run on a second stream: 1 wave per frame pair is latency- not
-        // throughput-bound, so it overlaps the next batch's detect/describe/knn on the main stream
-        HIPCHK(ctx, hipEventRecord(ctx->ev_filter_done, st));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->pose_stream, ctx->ev_filter_done, 0));
-        hipStream_t saved = ctx->stream;
-        ctx->stream = ctx->pose_stream;
-        (void)hipEventRecord(ctx->ev_pose_start, ctx->pose_stream);
+        (void)hipEventRecord(ctx->ev_filter_done, sM);
+        (void)hipStreamWaitEvent(sP, ctx->ev_filter_done, 0);
+        ctx->stream = sP;
+        (void)hipEventRecord(ctx->ev_pose_start, sP);
         rc = launch_pose(ctx, pl, n);
-        (void)hipEventRecord(ctx->ev_pose_done, ctx->pose_stream);
-        ctx->stream = saved;
+        (void)hipEventRecord(ctx->ev_pose_done, sP);
         ctx->pose_pending = true;
     }
-    pl->d_pair_q = saved_q;
+    ctx->stream = sA;
     if (rc) return rc;
-    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[7], st);
-    if (stages & VIS_STAGE_DETECT) pl->carry_from = n;
-    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[8], st);
-    pl->last_n = n;
+    if (detect) pl->carry_from = base + n;
+    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[8], sA);
+    pl->last_n = n; pl->last_base = base;
     return VIS_OK;
 }
 
 extern "C" int vis_batch_sync(vis_ctx* ctx) {
     if (!ctx) return VIS_E_INVALID;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->match_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->match_stream));
     const bool had_pose = ctx->pose_pending;
     if (ctx->pose_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->pose_stream));
     ctx->pose_pending = false;
+    if (ctx->batch) ctx->batch->match_pending[0] = ctx->batch->match_pending[1] = false;
     if (ctx->ev_ok) {
         collect_detect_timings(ctx);
         float a = 0;
-        if (hipEventElapsedTime(&a, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->tm.ms_knn = a;
+        if (hipEventElapsedTime(&a, ctx->ev_match_start, ctx->ev[5]) == hipSuccess) ctx->tm.ms_knn = a;
         if (hipEventElapsedTime(&a, ctx->ev[5], ctx->ev[6]) == hipSuccess) ctx->tm.ms_filter = a;
         ctx->tm.ms_pose = 0;
         if (had_pose && hipEventElapsedTime(&a, ctx->ev_pose_start, ctx->ev_pose_done) == hipSuccess) ctx->tm.ms_pose = a;
         if (hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[8]) == hipSuccess) ctx->tm.ms_total = a;
+        if (hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[6]) == hipSuccess && a > ctx->tm.ms_total) ctx->tm.ms_total = a;
         if (had_pose && hipEventElapsedTime(&a, ctx->ev[0], ctx->ev_pose_done) == hipSuccess && a > ctx->tm.ms_total) ctx->tm.ms_total = a;
     }
     return VIS_OK;
@@ -740,11 +779,12 @@ extern "C" int vis_batch_get_keypoints(vis_ctx* ctx, int frame, vis_keypoint* kp
     if (frame < 0 || frame >= pl->last_n) return VIS_E_INVALID;
     sync_all(ctx);
     int32_t n = 0;
-    HIPCHK(ctx, hipMemcpy(&n, pl->d_nkp + frame + 1, 4, hipMemcpyDeviceToHost));
+    const int rbase = pl->last_base;
+    HIPCHK(ctx, hipMemcpy(&n, pl->d_nkp + rbase + frame + 1, 4, hipMemcpyDeviceToHost));
     if (n_out) *n_out = n;
     if ((kps || desc) && n > cap) return VIS_E_CAPACITY;
-    if (kps && n) HIPCHK(ctx, hipMemcpy(kps, pl->d_kps + (size_t)(frame + 1) * pl->kcap, (size_t)n * sizeof(vis_keypoint), hipMemcpyDeviceToHost));
-    if (desc && n) HIPCHK(ctx, hipMemcpy(desc, pl->d_desc + (size_t)(frame + 1) * pl->kcap * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
+    if (kps && n) HIPCHK(ctx, hipMemcpy(kps, pl->d_kps + (size_t)(rbase + frame + 1) * pl->kcap, (size_t)n * sizeof(vis_keypoint), hipMemcpyDeviceToHost));
+    if (desc && n) HIPCHK(ctx, hipMemcpy(desc, pl->d_desc + (size_t)(rbase + frame + 1) * pl->kcap * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
     return VIS_OK;
 }
 
@@ -755,8 +795,8 @@ extern "C" int vis_batch_get_knn(vis_ctx* ctx, int frame, vis_dmatch* out12, int
     if (frame < 0 || frame >= pl->last_n) return VIS_E_INVALID;
     sync_all(ctx);
     int32_t nq = 0, nt = 0;
-    HIPCHK(ctx, hipMemcpy(&nq, pl->d_nkp + frame, 4, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(&nt, pl->d_nkp + frame + 1, 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(&nq, pl->d_nkp + pl->last_base + frame, 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(&nt, pl->d_nkp + pl->last_base + frame + 1, 4, hipMemcpyDeviceToHost));
     if (frame == 0 && !pl->pair0_valid) { nq = 0; nt = 0; }      // first frame of a stream has no pair
     if (n12) *n12 = nq;
     if (n21) *n21 = nt;

@@ -329,7 +329,9 @@ __device__ __forceinline__ void ransac_hyp_body(const PoseParams& P, int h0, int
     double A[9][5];
 #pragma unroll
     for (int i = 0; i < 5; i++) {
-        const int id = sm[i];
+        // inactive lanes (their pair has no work, e.g. M < 5 or the adaptive bound is already reached) share the
+        // wave with active pairs: they must not touch the (possibly never written) sample table
+        const int id = active ? sm[i] : 0;
         const double x1 = pa[2 * id], y1 = pa[2 * id + 1], x2 = pb[2 * id], y2 = pb[2 * id + 1];
         A[0][i] = x2 * x1; A[1][i] = x2 * y1; A[2][i] = x2;
         A[3][i] = y2 * x1; A[4][i] = y2 * y1; A[5][i] = y2;

@@ -80,7 +80,10 @@ struct Plan {
     int max_iters = 0;
     bool have_prev = false;                  // batch: record 0 holds the previous batch's last frame
     int last_n = 0;                          // frames in the last batch
-    int carry_from = 0;                      // record to copy into record 0 at the next run (0 = none)
+    int carry_from = 0;                      // absolute record to copy into the next set's record 0 (0 = none)
+    int nsets = 1, rec_per_set = 0, run_count = 0, last_base = 0;   // batch plans double-buffer their records
+    int32_t* d_pq[2] = {nullptr, nullptr}; int32_t* d_pt[2] = {nullptr, nullptr}; int32_t* d_pqn[2] = {nullptr, nullptr};
+    bool match_pending[2] = {false, false};
     bool pair0_valid = false;                // last run: frame 0 had a predecessor
 };
 
@@ -90,6 +93,8 @@ struct vis_ctx {
     hipStream_t stream = nullptr;
     hipStream_t pose_stream = nullptr;       // RANSAC/pose of batch i overlaps detect/match of batch i+1
     hipEvent_t ev_filter_done = nullptr, ev_pose_done = nullptr, ev_pose_start = nullptr;
+    hipStream_t match_stream = nullptr;      // knn + filters of batch i overlap the detect chain of batch i+1
+    hipEvent_t ev_detect_done = nullptr, ev_match_start = nullptr, ev_match_done[2] = {nullptr, nullptr};
     bool pose_pending = false;
     vis_params p;
     std::string err;
@@ -115,7 +120,7 @@ int  vis_compute_levels(const vis_params& p, int w, int h, int stride0, LevelInf
 void vis_grid_limits(const vis_params& p, int* root, std::vector<float>& hf, std::vector<float>& wf);
 
 // ---- plan management (plan.hip) ----
-int  plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npairs, Plan** out);
+int  plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npairs, Plan** out, int nsets = 1);
 void plan_destroy(Plan* pl);
 
 // ---- kernel launchers (each enqueues on ctx->stream) ----
