@@ -349,23 +349,27 @@ __device__ __forceinline__ float funmap(uint32_t m) {
 __device__ float harris7(const uint8_t* __restrict__ img, int stride, int x, int y) {
     int a = 0, b = 0, c = 0;
     const uint8_t* p0 = img + (size_t)(y - 4) * stride + (x - 4);
-    int r0[9], r1[9], r2[9];
+    // 9 x 9 neighbourhood as 9 x 3 unaligned dwords (27 loads instead of 81 byte loads); every kept
+    // candidate is >= edge_threshold (>= 22) pixels inside the image, so x-4 .. x+7 stays inside the row
+    uint32_t w[9][3];
 #pragma unroll
-    for (int j = 0; j < 9; j++) { r0[j] = p0[j]; r1[j] = p0[stride + j]; }
+    for (int i = 0; i < 9; i++) {
+        const uint8_t* pr = p0 + (size_t)i * stride;
+        w[i][0] = *reinterpret_cast<const u32_unaligned*>(pr);
+        w[i][1] = *reinterpret_cast<const u32_unaligned*>(pr + 4);
+        w[i][2] = *reinterpret_cast<const u32_unaligned*>(pr + 8);
+    }
+#define HPX(i, j) ((int)((w[i][(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu))
 #pragma unroll
-    for (int i = 0; i < 7; i++) {
-        const uint8_t* pr = p0 + (size_t)(i + 2) * stride;
-#pragma unroll
-        for (int j = 0; j < 9; j++) r2[j] = pr[j];
+    for (int i = 1; i <= 7; i++) {
 #pragma unroll
         for (int j = 1; j <= 7; j++) {
-            const int Ix = (r1[j + 1] - r1[j - 1]) * 2 + (r0[j + 1] - r0[j - 1]) + (r2[j + 1] - r2[j - 1]);
-            const int Iy = (r2[j] - r0[j]) * 2 + (r2[j - 1] - r0[j - 1]) + (r2[j + 1] - r0[j + 1]);
+            const int Ix = (HPX(i, j + 1) - HPX(i, j - 1)) * 2 + (HPX(i - 1, j + 1) - HPX(i - 1, j - 1)) + (HPX(i + 1, j + 1) - HPX(i + 1, j - 1));
+            const int Iy = (HPX(i + 1, j) - HPX(i - 1, j)) * 2 + (HPX(i + 1, j - 1) - HPX(i - 1, j - 1)) + (HPX(i + 1, j + 1) - HPX(i - 1, j + 1));
             a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
         }
-#pragma unroll
-        for (int j = 0; j < 9; j++) { r0[j] = r1[j]; r1[j] = r2[j]; }
     }
+#undef HPX
     const float scale = 1.f / ((1 << 2) * 7 * 255.f);
     const float scale_sq_sq = scale * scale * scale * scale;
     const float fa = (float)a, fb = (float)b, fc = (float)c;
@@ -391,16 +395,37 @@ __global__ __launch_bounds__(256) void k_select(DetLevels D, const int32_t* __re
     lhist[tid] = 0;
     if (tid == 0) { s_n = 0; s_keep = 0; }
     __syncthreads();
-    // pass 1: FAST-score histogram of this (frame, level) over its tiles' slots
-    for (int t = tid; t < A.ntiles; t += 256) {
-        const int c = min(tc[t], TILE_CAND_CAP);
-        const uint32_t* e = cand + (size_t)t * TILE_CAND_CAP;
-        for (int i = 0; i < c; i++) atomicAdd(&lhist[e[i] >> 24], 1);
+    // tile counts -> exclusive prefix (LDS), so that both passes run over a FLAT candidate index with
+    // independent loads (a thread-per-tile loop chained ~20 dependent loads per thread)
+    int* tpre = lhist + 256;                                       // A.ntiles + 1 entries
+    for (int t = tid; t < A.ntiles; t += 256) tpre[t + 1] = min(tc[t], TILE_CAND_CAP);
+    if (tid == 0) tpre[0] = 0;
+    __syncthreads();
+    if (tid < 64) {                                                // one wave scans (ntiles is a few hundred at most per chunk)
+        int carry = 0;
+        for (int b = 0; b < A.ntiles; b += 64) {
+            const int i = b + tid;
+            int v = i < A.ntiles ? tpre[i + 1] : 0;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o); if (tid >= o) v += u; }
+            if (i < A.ntiles) tpre[i + 1] = v + carry;
+            carry += __shfl(v, 63);
+        }
+    }
+    __syncthreads();
+    const int C = tpre[A.ntiles];
+    auto locate = [&](int j, int& t) {                             // largest t with tpre[t] <= j
+        int lo = 0, hi = A.ntiles;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tpre[mid] <= j) lo = mid; else hi = mid; }
+        t = lo;
+    };
+    // pass 1: FAST-score histogram of this (frame, level)
+    for (int j = tid; j < C; j += 256) {
+        int t; locate(j, t);
+        atomicAdd(&lhist[cand[(size_t)t * TILE_CAND_CAP + (j - tpre[t])] >> 24], 1);
     }
     __syncthreads();
     if (tid == 0) {
-        int C = 0;
-        for (int sidx = 0; sidx < 256; sidx++) C += lhist[sidx];
         const int n = 2 * A.quota;
         int cut = 0;
         if (C > n) {                                  // KeyPointsFilter::retainBest(2*quota) on FAST score
@@ -412,15 +437,12 @@ __global__ __launch_bounds__(256) void k_select(DetLevels D, const int32_t* __re
     __syncthreads();
     const int cut = s_cut;
     // pass 2: gather the survivors
-    for (int t = tid; t < A.ntiles; t += 256) {
-        const int c = min(tc[t], TILE_CAND_CAP);
-        const uint32_t* e = cand + (size_t)t * TILE_CAND_CAP;
-        for (int i = 0; i < c; i++) {
-            const uint32_t cv = e[i];
-            if ((int)(cv >> 24) >= cut) {
-                const int slot = atomicAdd(&s_n, 1);
-                if (slot < A.surv_cap) keys[slot] = cv;
-            }
+    for (int j = tid; j < C; j += 256) {
+        int t; locate(j, t);
+        const uint32_t cv = cand[(size_t)t * TILE_CAND_CAP + (j - tpre[t])];
+        if ((int)(cv >> 24) >= cut) {
+            const int slot = atomicAdd(&s_n, 1);
+            if (slot < A.surv_cap) keys[slot] = cv;
         }
     }
     __syncthreads();
@@ -779,10 +801,12 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[2], st);
     int max_surv = 0; for (int l = 0; l < L; l++) max_surv = std::max(max_surv, pl->lv[l].surv_cap);
-    if ((size_t)max_surv * 8 + 16 + 1024 > 65536) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (160 KiB per CU on gfx950)
-        HIPCHK(ctx, hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)max_surv * 8 + 16 + 1024)));
+    int max_nt = 0; for (int l = 0; l < L; l++) max_nt = std::max(max_nt, pl->lv[l].tiles_x * pl->lv[l].tiles_y);
+    const size_t sel_lds = (size_t)max_surv * 8 + 16 + 1024 + ((size_t)max_nt + 1) * 4;
+    if (sel_lds > 65536) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (160 KiB per CU on gfx950)
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
     }
-    hipLaunchKernelGGL(k_select, dim3(xcd_grid(n, L)), dim3(256), (size_t)max_surv * 8 + 16 + 1024, st, D, pl->d_tile_cnt, pl->total_tiles,
+    hipLaunchKernelGGL(k_select, dim3(xcd_grid(n, L)), dim3(256), sel_lds, st, D, pl->d_tile_cnt, pl->total_tiles,
                        pl->d_seg_cnt, pl->d_flags, max_surv, n);
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[3], st);
     hipLaunchKernelGGL(k_describe, dim3(xcd_grid(n, (pl->kcap + 3) / 4)), dim3(256), 0, st, D, G, pl->d_seg_cnt,
