@@ -69,13 +69,17 @@ extern "C" int vis_create(int device, vis_ctx** out) {
     vis_default_params(&ctx->p);
     std::memset(&ctx->tm, 0, sizeof(ctx->tm));
     for (int i = 0; i < VIS_NSLOTS; i++) ctx->slot_valid[i] = 0;
-    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return VIS_E_HIP; }
+    // the detect chain is the critical path of the batch pipeline: it gets the high-priority queue, the
+    // overlapped matcher / pose streams the low-priority ones
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);            // lo = numerically largest = least urgent
+    if (hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) { delete ctx; return VIS_E_HIP; }
     ctx->stream = ctx->own_stream;
-    if (hipStreamCreateWithFlags(&ctx->pose_stream, hipStreamNonBlocking) != hipSuccess ||
+    if (hipStreamCreateWithPriority(&ctx->pose_stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_filter_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_pose_done, hipEventDefault) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_pose_start, hipEventDefault) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->match_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithPriority(&ctx->match_stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_detect_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_match_start, hipEventDefault) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_match_done[0], hipEventDisableTiming) != hipSuccess ||
