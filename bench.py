@@ -175,6 +175,17 @@ def main():
             except Exception:
                 traffic = None
         fps = vdist.aggregate_fps(world, a.steps, B, dt)
+        # the detect/match kernels are bound by integer VALU issue, not by bytes: report that roofline too
+        # (instruction counts from the committed SQ_INSTS_VALU pass, peak measured by tools/valu_peak.hip)
+        valu = None
+        try:
+            pj = json.load(open(pmc))
+            vi = pj["raw"][kname]["SQ_INSTS_VALU"]["mean"] * (B / pj["batch_frames"])
+            peak = pj["valu_peak_measured"]["wave_insts_per_s"]
+            valu = {"kernel": kname, "wave_insts_per_launch": vi, "achieved": vi / per_launch_s, "peak": peak,
+                    "unit": "wave-instr/s", "frac": vi / per_launch_s / peak}
+        except Exception:
+            valu = None
         out = {
             "metric": "frames/sec detect+match+pose, 752x480 mono8", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -185,6 +196,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": per_launch_s * 1e3},
+            "valu_roofline": valu,
             "kernels_ms_per_step": {k: round(v, 4) for k, v in fam.items()},
             "detect_describe_GBps": alg["total_detect_describe"] * B / ((fam["ms_pyramid"] + fam["ms_fast"] + fam["ms_select"] + fam["ms_describe"]) * 1e-3) / 1e9,
         }
