@@ -61,7 +61,7 @@ __device__ __forceinline__ void resize_coef(int d, double scale, int slen, int& 
     c1 = __float2int_rn(fx * 2048.f);
 }
 
-#define RS_ROWS 4            // destination rows per thread: the column coefficients are computed once per thread
+#define RS_ROWS 8            // destination rows per thread: the column coefficients are computed once per thread
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 
@@ -76,9 +76,14 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
                                                 int bx_count, int per_frame, int nframes) {
     int f, inner;
     if (!xcd_frame_map(blockIdx.x, per_frame, nframes, f, inner)) return;
-    const int dx4 = ((inner % bx_count) * 64 + threadIdx.x) * 4;
-    const int dy0 = ((inner / bx_count) * 4 + threadIdx.y) * RS_ROWS;
-    if (dx4 >= dw || dy0 >= dh) return;
+    // flat (row group, 4-pixel column group) index: rows are narrower than 256 px on most levels, a 2-D block
+    // mapping leaves a quarter of the lanes idle
+    const int idx = inner * 256 + threadIdx.y * 64 + threadIdx.x;
+    int rg = (int)(((float)idx + 0.5f) * (1.0f / (float)bx_count));
+    int cg = idx - rg * bx_count;
+    if (cg < 0) { rg--; cg += bx_count; } else if (cg >= bx_count) { rg++; cg -= bx_count; }
+    const int dx4 = cg * 4, dy0 = rg * RS_ROWS;
+    if (dy0 >= dh) return;
     int sxs[4], a0s[4], a1s[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) resize_coef(min(dx4 + k, dw - 1), scale_x, sw, sxs[k], a0s[k], a1s[k]);
@@ -107,8 +112,8 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
             fy -= (float)sy;
             const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
             B0[r] = (uint32_t)__float2int_rn((1.f - fy) * 2048.f); B1[r] = (uint32_t)__float2int_rn(fy * 2048.f);
-            W0[r] = *reinterpret_cast<const u64_unaligned*>(sbase + (size_t)sy0 * sstride);
-            W1[r] = *reinterpret_cast<const u64_unaligned*>(sbase + (size_t)sy1 * sstride);
+            W0[r] = *reinterpret_cast<const u64_unaligned*>(sbase + (uint32_t)__umul24(sy0, sstride));
+            W1[r] = *reinterpret_cast<const u64_unaligned*>(sbase + (uint32_t)__umul24(sy1, sstride));
         }
 #pragma unroll
         for (int r = 0; r < RS_ROWS; r++) {
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
                 const uint32_t v = ((__umul24(B0[r], r0 >> 4) >> 16) + (__umul24(B1[r], r1 >> 4) >> 16) + 2u) >> 2;
                 out |= (v & 255u) << (8 * k);
             }
-            if (dy0 + r < dh) *reinterpret_cast<uint32_t*>(dbase + (size_t)(dy0 + r) * dstride) = out & keep;
+            if (dy0 + r < dh) *reinterpret_cast<uint32_t*>(dbase + (uint32_t)__umul24(dy0 + r, dstride)) = out & keep;
         }
         return;
     }
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
             const int v = (((B0[r] * (r0 >> 4)) >> 16) + ((B1[r] * (r1 >> 4)) >> 16) + 2) >> 2;
             out |= (uint32_t)(v & 255) << (8 * k);
         }
-        if (dy0 + r < dh) *reinterpret_cast<uint32_t*>(dbase + (size_t)(dy0 + r) * dstride) = out & keep;
+        if (dy0 + r < dh) *reinterpret_cast<uint32_t*>(dbase + (uint32_t)__umul24(dy0 + r, dstride)) = out & keep;
     }
 }
 
@@ -829,7 +834,7 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
     for (int l = 1; l < L; l++) {
         const LevelInfo& V = pl->lv[l];
         const LevelInfo& U = pl->lv[l - 1];
-        const int bxc = (V.w + 255) / 256, per_frame = bxc * ((V.h + 4 * RS_ROWS - 1) / (4 * RS_ROWS));
+        const int bxc = (V.w + 3) / 4, per_frame = (bxc * ((V.h + RS_ROWS - 1) / RS_ROWS) + 255) / 256;   // bxc = 4-px groups per row
         // scale exactly as cv::resize derives it: inv_scale = (double)dsize/ssize; scale = 1./inv_scale
         const double scale_x = 1. / ((double)V.w / U.w), scale_y = 1. / ((double)V.h / U.h);
         if (scale_x <= 2.0)
