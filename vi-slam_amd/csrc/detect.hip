@@ -546,7 +546,8 @@ __global__ __launch_bounds__(256) void k_select(DetLevels D, const int32_t* __re
     float4* out = A.seg_kp + (size_t)f * A.keep_cap;
     for (int i = tid; i < keep; i += 256) {
         const uint64_t k = keys[i];
-        out[i] = make_float4((float)(int)(k & 0xFFFF), (float)(int)((k >> 16) & 0xFFFF), funmap(~(uint32_t)(k >> 32)), 0.f);
+        // .w carries the integer coordinates (y << 16 | x) for k_describe's scalar address math
+        out[i] = make_float4((float)(int)(k & 0xFFFF), (float)(int)((k >> 16) & 0xFFFF), funmap(~(uint32_t)(k >> 32)), __uint_as_float((uint32_t)k));
     }
     if (tid == 0) seg_cnt[seg] = keep;
 }
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(256) void k_select(DetLevels D, const int32_t* __re
 #define PR 21                 // raw patch radius: 18 (max rotated sample offset) + 3 (blur taps)
 #define PW 43
 #define PS 44                 // raw patch LDS row stride
-#define HW 37                 // horizontally blurred columns kept (patch cols 3..39)
+#define HW 40                 // horizontally blurred columns stored (patch cols 3..42; samples use 3..39)
 #define HTS 46                // the row-blurred patch is stored TRANSPOSED: hbT[col][row], 46 u16 per column (odd dword
                               // stride): the 7 vertical taps of a sample are then 4 consecutive dwords
 #define WAVE_LDS (PW * PS + HW * HTS * 2 + 8)     // bytes per wave, multiple of 4
@@ -629,12 +630,26 @@ __device__ __forceinline__ void sincos_det(double x, double* s, double* c) {
     }
 }
 
+// sum over the 64 lanes of a wave: 4 DPP adds (quad swaps, half-row and row mirrors) + 4 v_readlane
+__device__ __forceinline__ int wave_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);     // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);     // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);    // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);    // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+           __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
+// Everything that identifies the keypoint (level, index, patch origin) is wave-uniform and is kept in SGPRs
+// (v_readfirstlane), so per-lane addresses are 32-bit offsets from scalar bases; lane -> (row, column)
+// mappings are fixed per phase, so the unrolled loops only add constants.
 __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const int32_t* __restrict__ seg_cnt,
                                                   vis_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                   int32_t* __restrict__ nkp, int kcap, int rec0,
                                                   int32_t* __restrict__ flags, int nframes) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[4 * WAVE_LDS];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int f, kb;
     if (!xcd_frame_map(blockIdx.x, (kcap + 3) / 4, nframes, f, kb)) return;
     const int g = kb * 4 + wv;
@@ -647,66 +662,76 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
     }
     if (total > kcap) { total = kcap; if (g == 0 && lane == 0) atomicOr(flags, 8); }
     if (g == 0 && lane == 0) nkp[rec0 + f] = total;
+    lev = __builtin_amdgcn_readfirstlane(lev); idx = __builtin_amdgcn_readfirstlane(idx);
     if (lev < 0 || g >= kcap) return;
-    const LevelArgs A = D.lv[lev];
+    const LevelArgs& A = D.lv[lev];
+    const int stride = A.stride;
     const float4 kpr = A.seg_kp[(size_t)f * A.keep_cap + idx];
-    const int x0 = (int)kpr.x, y0 = (int)kpr.y;
+    const uint32_t xy = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(kpr.w));
+    const int x0 = (int)(xy & 0xFFFFu), y0 = (int)(xy >> 16);
     uint8_t* raw = lds + wv * WAVE_LDS;
-    uint16_t* hb = reinterpret_cast<uint16_t*>(raw + PW * PS);
-    const uint8_t* img = A.img + (size_t)f * A.frame_bytes + (size_t)(y0 - PR) * A.stride + (x0 - PR);
-    // 43 rows x 44 bytes as 11 unaligned dwords per row: 473 dwords = 8 wave-wide loads, all in flight
-    // before the first LDS write (the patch of a kept keypoint is >= 9 px inside the image)
+    uint32_t* hb32 = reinterpret_cast<uint32_t*>(raw + PW * PS);
+    const uint8_t* img = A.img + (size_t)f * A.frame_bytes + (size_t)(y0 - PR) * stride + (x0 - PR);
+    // 43 rows x 44 bytes as 11 unaligned dwords per row; lane = (row % 5, dword), 9 loads cover rows 0..44,
+    // all in flight before the first LDS write (the patch of a kept keypoint is >= 9 px inside the image)
     {
-        uint32_t v[8];
+        const int rs = (lane * 47) >> 9, c = lane - rs * 11;          // lane / 11 for lane < 64
+        const uint32_t goff = (uint32_t)(__mul24(rs, stride) + 4 * c);
+        const int gstep = 5 * stride;
+        uint8_t* lw = raw + rs * PS + 4 * c;
+        uint32_t v[9];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int i = lane + 64 * k;
-            const int r = i / 11, c = i - r * 11;
-            v[k] = (i < PW * 11) ? *reinterpret_cast<const u32_unaligned*>(img + (size_t)r * A.stride + 4 * c) : 0u;
-        }
+        for (int k = 0; k < 9; k++)
+            v[k] = (lane < 55 && rs + 5 * k < PW) ? *reinterpret_cast<const u32_unaligned*>((img + (size_t)k * gstep) + goff) : 0u;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int i = lane + 64 * k;
-            const int r = i / 11, c = i - r * 11;
-            if (i < PW * 11) *reinterpret_cast<uint32_t*>(raw + r * PS + 4 * c) = v[k];
-        }
+        for (int k = 0; k < 9; k++)
+            if (lane < 55 && rs + 5 * k < PW) *reinterpret_cast<uint32_t*>(lw + k * 5 * PS) = v[k];
     }
     WAVE_SYNC();
     // IC angle over the radius-15 disc: each (row, dword) item is two byte dot products against a
-    // precomputed weight/mask table: m10 = sum (u+16) I - 16 sum I,  m01 = sum v I   (all exact integers)
+    // precomputed weight/mask table: m10 = sum (u+16) I - 16 sum I,  m01 = sum v I   (all exact integers).
+    // lane = (row % 7, dword); the table is padded with zero rows up to 35.
     int sA = 0, sB = 0, sC = 0;
+    if (lane < 63) {
+        const int rs = (lane * 57) >> 9, dw = lane - rs * 9;          // lane / 9
+        const uint8_t* pr = raw + (PR - 15 + rs) * PS + 4 + 4 * dw;
+        const uint2* tb = reinterpret_cast<const uint2*>(G.angle_tab) + lane;
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const int item = lane + 64 * k;
-        if (item < 31 * 9) {
-            const int rv = item / 9, dw = item - rv * 9;
-            const uint32_t pixw = *reinterpret_cast<const uint32_t*>(raw + (PR - 15 + rv) * PS + 4 + 4 * dw);
-            const uint2 wm = *reinterpret_cast<const uint2*>(G.angle_tab + 2 * item);
+        for (int k = 0; k < 5; k++) {
+            const uint32_t pixw = *reinterpret_cast<const uint32_t*>(pr + k * 7 * PS);
+            const uint2 wm = tb[63 * k];
             const int a = (int)__builtin_amdgcn_udot4(pixw, wm.x, 0u, false);
             const int b = (int)__builtin_amdgcn_udot4(pixw, wm.y, 0u, false);
-            sA += a; sB += b; sC += (rv - 15) * b;
+            sA += a; sB += b; sC += __mul24(rs + 7 * k - 15, b);
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { sA += __shfl_xor(sA, o); sB += __shfl_xor(sB, o); sC += __shfl_xor(sC, o); }
+    sA = wave_sum(sA); sB = wave_sum(sB); sC = wave_sum(sC);
     const int m10 = sA - 16 * sB, m01 = sC;
     const float angle = fast_atan2_deg((float)m01, (float)m10);
-    // horizontal 7-tap pass over all 43 rows, patch columns 3..39.  One task = (row, group of 4 outputs):
-    // 3 aligned dword reads, byte windows by v_alignbyte, 2 x v_dot4_u32_u8 per output, 2 dword stores.
-    for (int task = lane; task < PW * 10; task += 64) {
-        const int r = task / 10, g4 = task - r * 10;
-        const uint32_t* rw = reinterpret_cast<const uint32_t*>(raw + r * PS) + g4;
-        const uint32_t w0 = rw[0], w1 = rw[1], w2 = rw[2];
-        uint32_t o[4];
-        o[0] = __builtin_amdgcn_udot4(w0, G.k0, __builtin_amdgcn_udot4(w1, G.k1, 0u, false), false);
+    // horizontal 7-tap pass over all rows, patch columns 3..42.  One task = (row pair, group of 4 outputs):
+    // 2 x 3 dword reads, byte windows by v_alignbyte, 2 x v_dot4_u32_u8 per output; the two rows of a column are
+    // one dword of the transposed buffer (hbT[col][row], 23 dwords per column).  lane = (pair % 6, group).
+    if (lane < 60) {
+        const int rs = (lane * 52) >> 9, g4 = lane - rs * 10;         // lane / 10
+        const uint8_t* rb = raw + 2 * rs * PS + 4 * g4;
+        uint32_t* wb = hb32 + 4 * g4 * (HTS / 2) + rs;
 #pragma unroll
-        for (int j = 1; j < 4; j++) {
-            const uint32_t a = __builtin_amdgcn_alignbyte(w1, w0, j), b = __builtin_amdgcn_alignbyte(w2, w1, j);
-            o[j] = __builtin_amdgcn_udot4(a, G.k0, __builtin_amdgcn_udot4(b, G.k1, 0u, false), false);
+        for (int k = 0; k < 4; k++) {
+            if (rs + 6 * k < (PW + 1) / 2) {
+                const uint32_t* r0 = reinterpret_cast<const uint32_t*>(rb + k * 12 * PS);
+                const uint32_t* r1 = reinterpret_cast<const uint32_t*>(rb + k * 12 * PS + PS);   // row 43 of the last pair is
+                const uint32_t a0 = r0[0], a1 = r0[1], a2 = r0[2];                               // never sampled with weight != 0
+                const uint32_t b0 = r1[0], b1 = r1[1], b2 = r1[2];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t al = j ? __builtin_amdgcn_alignbyte(a1, a0, j) : a0, ah = j ? __builtin_amdgcn_alignbyte(a2, a1, j) : a1;
+                    const uint32_t bl = j ? __builtin_amdgcn_alignbyte(b1, b0, j) : b0, bh = j ? __builtin_amdgcn_alignbyte(b2, b1, j) : b1;
+                    const uint32_t oa = __builtin_amdgcn_udot4(al, G.k0, __builtin_amdgcn_udot4(ah, G.k1, 0u, false), false);
+                    const uint32_t ob = __builtin_amdgcn_udot4(bl, G.k0, __builtin_amdgcn_udot4(bh, G.k1, 0u, false), false);
+                    wb[j * (HTS / 2) + 6 * k] = oa | (ob << 16);       // <= 255*257 = 65535 per output
+                }
+            }
         }
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (4 * g4 + j < HW) hb[(4 * g4 + j) * HTS + r] = (uint16_t)o[j];   // <= 255*257 = 65535 per output
     }
     WAVE_SYNC();
     float ang = angle;
@@ -715,6 +740,7 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
     sincos_det((double)ang, &sd, &cd);
     const float a = (float)cd, b = (float)sd;
     unsigned long long words[4];
+    const uint8_t* hbb = reinterpret_cast<const uint8_t*>(hb32);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int bit = lane + 64 * k;
@@ -728,7 +754,7 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
             const int ix = __float2int_rn(fx), iy = __float2int_rn(fy);
             // vertical 7 taps = 4 consecutive dwords of column (PR+ix-3) starting at row (PR+iy-3)
             const int row0 = PR + iy - 3;
-            const uint32_t* cw = reinterpret_cast<const uint32_t*>(hb + (PR + ix - 3) * HTS) + (row0 >> 1);
+            const uint32_t* cw = reinterpret_cast<const uint32_t*>(hbb + __mul24(PR + ix - 3, HTS * 2) + ((row0 >> 1) << 2));
             const uint32_t w0 = cw[0], w1 = cw[1], w2 = cw[2], w3 = cw[3];
             const uint32_t sh = (uint32_t)(row0 & 1) * 2u;
             typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -741,7 +767,7 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
             int s = (int)((su + (1u << 15)) >> 16);
             val[e] = s > 255 ? 255 : s;
         }
-        words[k] = __ballot(val[0] < val[1]);
+        words[k] = __builtin_amdgcn_ballot_w64(val[0] < val[1]);
     }
     uint8_t* dout = desc + ((size_t)(rec0 + f) * kcap + g) * 32;
     if (lane < 4) reinterpret_cast<unsigned long long*>(dout)[lane] = words[lane];
@@ -803,7 +829,7 @@ static void fill_desc_args(const vis_params& p, DescArgs& G, std::vector<uint32_
     G.angle_tab = nullptr;
     if (tab_out) {
         // row rv (v = rv-15), dword dw covers patch columns 4+4dw .. 7+4dw, i.e. u = pc - 21
-        tab_out->assign(31 * 9 * 2, 0u);
+        tab_out->assign(35 * 9 * 2, 0u);       // 31 rows + 4 zero rows (k_describe's fixed lane mapping over-runs)
         for (int rv = 0; rv < 31; rv++)
             for (int dw = 0; dw < 9; dw++) {
                 uint32_t wv = 0, mv = 0;
