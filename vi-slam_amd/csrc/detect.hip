@@ -310,13 +310,14 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edg
         // are one aligned LDS dword; 11 dword reads + 4 v_alignbyte give centre and the 8 tested ring
         // pixels for all four; 34 rows x 16 units
         const pk16 T = {(short)threshold, (short)threshold};
-        for (int u = tid; u < SC_H * (FT_W / 4); u += 256) {
-            const int sy = u / (FT_W / 4), q = u - sy * (FT_W / 4);
+        const int q = tid & (FT_W / 4 - 1);                              // the unit column of a thread is fixed (256 % 32 == 0)
+        const int gx0 = ox + 4 * q;                                      // image x of position sx = 4q+1
+        const bool x0 = gx0 >= lox && gx0 < hix, x1 = gx0 + 1 >= lox && gx0 + 1 < hix;
+        const bool x2 = gx0 + 2 >= lox && gx0 + 2 < hix, x3 = gx0 + 3 >= lox && gx0 + 3 < hix;
+        const int lane = tid & 63;
+        for (int sy = tid / (FT_W / 4); sy < SC_H; sy += 256 / (FT_W / 4)) {
             const int gy = oy - 1 + sy;
-            const int gx0 = ox + 4 * q;                                  // image x of position sx = 4q+1
-            const bool rowok = gy >= loy && gy < hiy && gx0 + 3 >= lox && gx0 < hix;
-            bool p0 = false, p1 = false, p2 = false, p3 = false;
-            if (rowok) {
+            const bool rowok = gy >= loy && gy < hiy;
             const uint32_t* r0 = px + (sy + 3) * (PX_W / 4) + q + (PX_XO / 4 - 1);   // r0[1] = the 4 centre pixels
             const uint32_t* rp2 = r0 + 2 * (PX_W / 4), * rm2 = r0 - 2 * (PX_W / 4);
             const uint32_t c0 = r0[0], C = r0[1], c2 = r0[2];
@@ -328,25 +329,27 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edg
             const uint32_t SE = __builtin_amdgcn_alignbyte(b2, b1, 2), SW = __builtin_amdgcn_alignbyte(b1, b0, 2);
             const pk16 plo = pretest_pk<false>(C, N, S, E, W, NE, SW, SE, NW, T);
             const pk16 phi = pretest_pk<true>(C, N, S, E, W, NE, SW, SE, NW, T);
-            p0 = plo.x > 0 && gx0 >= lox && gx0 < hix;
-            p1 = plo.y > 0 && gx0 + 1 >= lox && gx0 + 1 < hix;
-            p2 = phi.x > 0 && gx0 + 2 >= lox && gx0 + 2 < hix;
-            p3 = phi.y > 0 && gx0 + 3 >= lox && gx0 + 3 < hix;
-            }
+            const bool p0 = plo.x > 0 && x0 && rowok, p1 = plo.y > 0 && x1 && rowok;
+            const bool p2 = phi.x > 0 && x2 && rowok, p3 = phi.y > 0 && x3 && rowok;
             // wave-aggregated queue append (queue order is irrelevant: k_select sorts)
-            const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1), m2 = __ballot(p2), m3 = __ballot(p3);
+            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(p0), m1 = __builtin_amdgcn_ballot_w64(p1);
+            const unsigned long long m2 = __builtin_amdgcn_ballot_w64(p2), m3 = __builtin_amdgcn_ballot_w64(p3);
             const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
             const int tot = n0 + n1 + n2 + n3;
             if (tot) {
-                int base = 0;
-                if ((tid & 63) == 0) base = atomicAdd(&qn, tot);
-                base = __shfl(base, 0);
-                const unsigned long long lt = (1ull << (tid & 63)) - 1ull;
+                int qb = 0;
+                if (lane == 0) qb = atomicAdd(&qn, tot);
+                qb = __builtin_amdgcn_readfirstlane(qb);
                 const int pos = sy * SC_W + 4 * q + 1;
-                if (p0) queue[base + __popcll(m0 & lt)] = (uint16_t)pos;
-                if (p1) queue[base + n0 + __popcll(m1 & lt)] = (uint16_t)(pos + 1);
-                if (p2) queue[base + n0 + n1 + __popcll(m2 & lt)] = (uint16_t)(pos + 2);
-                if (p3) queue[base + n0 + n1 + n2 + __popcll(m3 & lt)] = (uint16_t)(pos + 3);
+                // v_mbcnt: number of set mask bits below this lane, accumulated onto the running base
+                const uint32_t i0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, (uint32_t)qb));
+                const uint32_t i1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, (uint32_t)(qb + n0)));
+                const uint32_t i2 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, (uint32_t)(qb + n0 + n1)));
+                const uint32_t i3 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m3, (uint32_t)(qb + n0 + n1 + n2)));
+                if (p0) queue[i0] = (uint16_t)pos;
+                if (p1) queue[i1] = (uint16_t)(pos + 1);
+                if (p2) queue[i2] = (uint16_t)(pos + 2);
+                if (p3) queue[i3] = (uint16_t)(pos + 3);
             }
         }
         // halo score columns 0 and 65 (NMS neighbours of the first/last tile column): byte-wise test
