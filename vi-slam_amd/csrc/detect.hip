@@ -270,7 +270,8 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edg
     for (int l = 1; l < F.L; l++) if (gtile >= F.lv[l].tile_base) level = l;
     const FastLevel V = F.lv[level];
     const int tile = gtile - V.tile_base;
-    const int ox = (tile % V.tiles_x) * FT_W, oy = (tile / V.tiles_x) * FT_H;
+    // tile grid origin = (edge rounded down to 16, edge): see vis_compute_levels
+    const int ox = (edge & ~15) + (tile % V.tiles_x) * FT_W, oy = edge + (tile / V.tiles_x) * FT_H;
     const int w = V.w, h = V.h, stride = V.stride;
     // tiles that cannot emit (entirely inside the culled border) do nothing
     if (ox + FT_W <= edge || ox >= w - edge || oy + FT_H <= edge || oy >= h - edge) return;

@@ -23,8 +23,11 @@ int vis_compute_levels(const vis_params& p, int w, int h, int stride0, LevelInfo
         if (lv[l].w < 8 || lv[l].h < 8) return VIS_E_INVALID;
         lv[l].stride = (l == 0) ? stride0 : ((lv[l].w + 63) / 64) * 64;
         lv[l].frame_bytes = (size_t)lv[l].stride * lv[l].h;
-        lv[l].tiles_x = (lv[l].w + 127) / 128;
-        lv[l].tiles_y = (lv[l].h + 31) / 32;
+        // FAST tiles (128 x 32) cover only the region that can emit keypoints, [edge, w-edge) x [edge, h-edge);
+        // the x origin is rounded down to 16 so that k_fast's 16-byte tile loads stay aligned
+        const int e = p.edge_threshold, tx0 = e & ~15;
+        lv[l].tiles_x = std::max(1, (lv[l].w - e - tx0 + 127) / 128);
+        lv[l].tiles_y = std::max(1, (lv[l].h - 2 * e + 31) / 32);
         lv[l].cand_cap = lv[l].tiles_x * lv[l].tiles_y * 1024;
         lv[l].tile_base = l == 0 ? 0 : lv[l - 1].tile_base + lv[l - 1].tiles_x * lv[l - 1].tiles_y;
     }
