@@ -186,29 +186,33 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
 #define SC_H (FT_H + 2)
 #define SC_S (FT_W + 4)      // LDS score row stride
 
-// full cornerScore<16> without the early exit (callers have already thinned the candidates)
+// full cornerScore<16> without the early exit (callers have already thinned the candidates).  Both polarities
+// run in one v_pk_*_i16 chain: X[k] = (v - p_k, p_k - v); the minimum over 9 consecutive X picks the dark-arc
+// margin in the low half and minus the bright-arc maximum in the high half, so
+//   max_k min9(X).lo = A (cv::cornerScore's a0),  max_k min9(X).hi = -b0,  score = max(a0, -b0) - 1.
+typedef short pk16 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int fast_score16_full(const uint8_t* c, int t) {
     const int S = PX_W;
-    const int v = c[0];
-    int d[16];
-    d[0] = v - c[3 * S];       d[1] = v - c[3 * S + 1];   d[2] = v - c[2 * S + 2];   d[3] = v - c[S + 3];
-    d[4] = v - c[3];           d[5] = v - c[-S + 3];      d[6] = v - c[-2 * S + 2];  d[7] = v - c[-3 * S + 1];
-    d[8] = v - c[-3 * S];      d[9] = v - c[-3 * S - 1];  d[10] = v - c[-2 * S - 2]; d[11] = v - c[-S - 3];
-    d[12] = v - c[-3];         d[13] = v - c[S - 3];      d[14] = v - c[2 * S - 2];  d[15] = v - c[3 * S - 1];
-    int lo2[16], hi2[16], lo4[16], hi4[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
-#pragma unroll
-    for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
-    int A = -255, Bm = 255;
+    const uint32_t v = c[0];
+    const int off[16] = {3 * S, 3 * S + 1, 2 * S + 2, S + 3, 3, -S + 3, -2 * S + 2, -3 * S + 1,
+                         -3 * S, -3 * S - 1, -2 * S - 2, -S - 3, -3, S - 3, 2 * S - 2, 3 * S - 1};
+    pk16 X[16], m2[16], m4[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
-        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
-        A = max(A, lo9);
-        Bm = min(Bm, hi9);
+        const uint32_t w = v | ((uint32_t)c[off[k]] << 16);                             // (v, p_k)
+        uint32_t x;                                                                      // (v - p_k, p_k - v): the half swap is an operand modifier
+        asm("v_pk_sub_i16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(x) : "v"(w));
+        X[k] = __builtin_bit_cast(pk16, x);
     }
-    const int s = max(A, -Bm) - 1;
+#pragma unroll
+    for (int k = 0; k < 16; k++) m2[k] = __builtin_elementwise_min(X[k], X[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
+    pk16 acc = {(short)-255, (short)-255};
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        acc = __builtin_elementwise_max(acc, __builtin_elementwise_min(__builtin_elementwise_min(m4[k], m4[(k + 4) & 15]), X[(k + 8) & 15]));
+    const int s = max((int)acc.x, (int)acc.y) - 1;
     return s >= t ? s : 0;
 }
 
@@ -225,23 +229,17 @@ __device__ __forceinline__ bool fast_pretest(const uint8_t* c, int t) {
     return mn > t || mx < -t;
 }
 
-// ---- packed (2 x 16 bit) pretest on 4 horizontally adjacent pixels held as the 4 bytes of a dword
-typedef short pk16 __attribute__((ext_vector_type(2)));
+// ---- packed (2 x 16 bit) pretest on 4 horizontally adjacent pixels held as the 4 bytes of a dword.
+// Every operand (centre / ring pixel of two adjacent positions, widened to 2 x u16) is ONE v_perm_b32 that picks
+// two bytes out of a dword pair of the LDS tile.
 __device__ __forceinline__ pk16 as_pk(uint32_t v) { return __builtin_bit_cast(pk16, v); }
-__device__ __forceinline__ pk16 unpack_lo(uint32_t w) { return as_pk(__builtin_amdgcn_perm(0u, w, 0x0c010c00u)); }   // bytes 0,1 -> 2 x u16
-__device__ __forceinline__ pk16 unpack_hi(uint32_t w) { return as_pk(__builtin_amdgcn_perm(0u, w, 0x0c030c02u)); }   // bytes 2,3 -> 2 x u16
 __device__ __forceinline__ pk16 pmin(pk16 a, pk16 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ pk16 pmax(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
+// bytes (i, i+1) of the 8-byte string hi:lo as 2 x u16
+#define PICK2(hi, lo, i) as_pk(__builtin_amdgcn_perm((hi), (lo), 0x0c000c00u | (uint32_t)(i) | ((uint32_t)((i) + 1) << 16)))
 
 // the 4-pair necessary condition of fast_pretest() on two pixels at once: > 0 in a half <=> that pixel passes
-template <bool HI>
-__device__ __forceinline__ pk16 pretest_pk(uint32_t C, uint32_t N, uint32_t S, uint32_t E, uint32_t W,
-                                           uint32_t NE, uint32_t SW, uint32_t SE, uint32_t NW, pk16 T) {
-    const pk16 c = HI ? unpack_hi(C) : unpack_lo(C);
-    const pk16 n = HI ? unpack_hi(N) : unpack_lo(N), so = HI ? unpack_hi(S) : unpack_lo(S);
-    const pk16 e = HI ? unpack_hi(E) : unpack_lo(E), w = HI ? unpack_hi(W) : unpack_lo(W);
-    const pk16 ne = HI ? unpack_hi(NE) : unpack_lo(NE), sw = HI ? unpack_hi(SW) : unpack_lo(SW);
-    const pk16 se = HI ? unpack_hi(SE) : unpack_lo(SE), nw = HI ? unpack_hi(NW) : unpack_lo(NW);
+__device__ __forceinline__ pk16 pretest_pk(pk16 c, pk16 n, pk16 so, pk16 e, pk16 w, pk16 ne, pk16 sw, pk16 se, pk16 nw, pk16 T) {
     // dark arc: every pair has a ring pixel < c - t   <=>  max over pairs of min(pair) < c - t
     const pk16 mx = pmax(pmax(pmin(n, so), pmin(e, w)), pmax(pmin(ne, sw), pmin(se, nw)));
     // bright arc: min over pairs of max(pair) > c + t
@@ -325,11 +323,11 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edg
             const uint32_t N = r0[3 * (PX_W / 4) + 1], S = r0[-3 * (PX_W / 4) + 1];
             const uint32_t a0 = rp2[0], a1 = rp2[1], a2 = rp2[2];
             const uint32_t b0 = rm2[0], b1 = rm2[1], b2 = rm2[2];
-            const uint32_t E = __builtin_amdgcn_alignbyte(c2, C, 3), W = __builtin_amdgcn_alignbyte(C, c0, 1);
-            const uint32_t NE = __builtin_amdgcn_alignbyte(a2, a1, 2), NW = __builtin_amdgcn_alignbyte(a1, a0, 2);
-            const uint32_t SE = __builtin_amdgcn_alignbyte(b2, b1, 2), SW = __builtin_amdgcn_alignbyte(b1, b0, 2);
-            const pk16 plo = pretest_pk<false>(C, N, S, E, W, NE, SW, SE, NW, T);
-            const pk16 phi = pretest_pk<true>(C, N, S, E, W, NE, SW, SE, NW, T);
+            // positions 0,1 (low pair) and 2,3 (high pair) of the unit; ring offsets E/W = +-3 px, diagonals = +-2 px
+            const pk16 plo = pretest_pk(PICK2(0u, C, 0), PICK2(0u, N, 0), PICK2(0u, S, 0), PICK2(c2, C, 3), PICK2(C, c0, 1),
+                                        PICK2(a2, a1, 2), PICK2(b1, b0, 2), PICK2(b2, b1, 2), PICK2(a1, a0, 2), T);
+            const pk16 phi = pretest_pk(PICK2(0u, C, 2), PICK2(0u, N, 2), PICK2(0u, S, 2), PICK2(c2, C, 5), PICK2(C, c0, 3),
+                                        PICK2(a2, a1, 4), PICK2(b1, b0, 4), PICK2(b2, b1, 4), PICK2(a1, a0, 4), T);
             const bool p0 = plo.x > 0 && x0 && rowok, p1 = plo.y > 0 && x1 && rowok;
             const bool p2 = phi.x > 0 && x2 && rowok, p3 = phi.y > 0 && x3 && rowok;
             // wave-aggregated queue append (queue order is irrelevant: k_select sorts)
