@@ -191,7 +191,7 @@ void plan_destroy(Plan* pl) {
     for (int i = 0; i < 2; i++) { F(pl->d_pq[i]); F(pl->d_pt[i]); F(pl->d_pqn[i]); }
     F(pl->d_knn12); F(pl->d_knn21);
     F(pl->d_sym); F(pl->d_nsym); F(pl->d_good); F(pl->d_ngood); F(pl->d_p1); F(pl->d_p2); F(pl->d_hf); F(pl->d_wf);
-    F(pl->d_n1); F(pl->d_n2); F(pl->d_mask); F(pl->d_samples); F(pl->d_models); F(pl->d_counts); F(pl->d_rstate); F(pl->d_pose); F(pl->d_worklist);
+    F(pl->d_n1); F(pl->d_n2); F(pl->d_mask); F(pl->d_samples); F(pl->d_models); F(pl->d_counts); F(pl->d_rstate); F(pl->d_pose); F(pl->d_worklist); F(pl->d_hyp);
     delete pl;
 }
 
@@ -255,6 +255,7 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
     DALLOC(pl->d_rstate, (size_t)npairs * VIS_RSTATE_WORDS);
     DALLOC(pl->d_pose, npairs);
     DALLOC(pl->d_worklist, (size_t)npairs + 1);
+    DALLOC(pl->d_hyp, (size_t)npairs * pl->max_iters * VIS_HYP_DOUBLES);
     // defence in depth: nothing should read these before writing them, but a recycled allocation must never
     // turn a missed guard into an out-of-bounds index (see the inactive-lane fix in k_ransac_hyp)
     HIPCHK(ctx, hipMemset(pl->d_samples, 0, (size_t)npairs * pl->max_iters * 5 * sizeof(int32_t)));
@@ -305,7 +306,7 @@ int vis_build_sample_table(vis_ctx* ctx, int max_m) {
 int launch_pose(vis_ctx* ctx, Plan* pl, int npairs) {
     if (npairs <= 0) return VIS_OK;
     return pose_run(ctx, npairs, pl->root * pl->root, pl->max_iters, pl->d_p1, pl->d_p2, pl->d_ngood, pl->d_n1, pl->d_n2,
-                    pl->d_samples, pl->d_models, pl->d_counts, pl->d_rstate, nullptr, pl->d_mask, pl->d_pose, 1, 1, pl->d_worklist);
+                    pl->d_samples, pl->d_models, pl->d_counts, pl->d_rstate, nullptr, pl->d_mask, pl->d_pose, 1, 1, pl->d_worklist, pl->d_hyp);
 }
 
 static int ensure_scratch(vis_ctx* ctx, size_t bytes) {
@@ -572,7 +573,7 @@ static int pose_host(vis_ctx* ctx, const float* p1xy, const float* p2xy, int m, 
     if (m > VIS_RANSAC_MAX_M) return VIS_E_CAPACITY;
     const int mcap = std::max(m, 1);
     const int iters = ctx->p.ransac_max_iters;
-    size_t need = (size_t)mcap * (16 + 32 + 1) + (size_t)iters * (20 + 720 + 40) + 65536;
+    size_t need = (size_t)mcap * (16 + 32 + 1) + (size_t)iters * (20 + 720 + 40 + 8 * VIS_HYP_DOUBLES) + 65536;
     int rc = ensure_scratch(ctx, need);
     if (rc) return rc;
     Carver cv{(char*)ctx->d_scratch, 0};
@@ -587,6 +588,7 @@ static int pose_host(vis_ctx* ctx, const float* p1xy, const float* p2xy, int m, 
     uint8_t* d_mask = cv.take<uint8_t>(mcap);
     PoseOut* d_pose = cv.take<PoseOut>(1);
     int32_t* d_worklist = cv.take<int32_t>(2);
+    double* d_hyp = cv.take<double>((size_t)iters * VIS_HYP_DOUBLES);
     if (m) {
         HIPCHK(ctx, hipMemcpy(d_p1, p1xy, (size_t)m * 8, hipMemcpyHostToDevice));
         HIPCHK(ctx, hipMemcpy(d_p2, p2xy, (size_t)m * 8, hipMemcpyHostToDevice));
@@ -598,7 +600,7 @@ static int pose_host(vis_ctx* ctx, const float* p1xy, const float* p2xy, int m, 
     if (rc) return rc;
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[6], ctx->stream);
     rc = pose_run(ctx, 1, mcap, iters, d_p1, d_p2, d_npts, d_n1, d_n2, d_samples, d_models, d_counts, d_rstate,
-                  E_in ? d_E : nullptr, d_mask, d_pose, do_ransac, do_pose, d_worklist);
+                  E_in ? d_E : nullptr, d_mask, d_pose, do_ransac, do_pose, d_worklist, d_hyp);
     if (rc) return rc;
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[7], ctx->stream);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -94,96 +94,6 @@ DEV double poly_eval(const double* c, int deg, double x) {
 #define BISECT_INNER 40
 #define BISECT_FINAL 200
 
-// generic (rolled) derivative-interlacing root finder: identical steps to oracle/pose.cpp real_roots.
-// Only used when the degree-10 coefficient vanished (deg < 10) -- the unrolled fast path handles deg == 10.
-__device__ int real_roots_generic(const double* c, int deg, double B, double* roots) {
-    double prev[11]; int nprev = 0;
-    for (int d = 1; d <= deg; d++) {
-        const int k = deg - d;
-        double q[11];
-        for (int i = 0; i <= d; i++) {
-            double f = 1.0;
-            for (int j = 0; j < k; j++) f *= (double)(i + k - j);
-            q[i] = c[i + k] * f;
-        }
-        double cur[11]; int ncur = 0;
-        for (int j = 0; j <= nprev; j++) {
-            double lo = j == 0 ? -B : prev[j - 1];
-            double hi = j == nprev ? B : prev[j];
-            const double flo = poly_eval(q, d, lo), fhi = poly_eval(q, d, hi);
-            if ((flo < 0) == (fhi < 0)) continue;
-            const int nit = d == deg ? BISECT_FINAL : BISECT_INNER;
-            for (int it = 0; it < nit; it++) {
-                const double m = 0.5 * (lo + hi);
-                if (m <= lo || m >= hi) break;
-                const double fm = poly_eval(q, d, m);
-                if ((fm < 0) == (flo < 0)) lo = m; else hi = m;
-            }
-            cur[ncur++] = 0.5 * (lo + hi);
-        }
-        nprev = ncur;
-        for (int j = 0; j < ncur; j++) prev[j] = cur[j];
-    }
-    for (int j = 0; j < nprev; j++) roots[j] = prev[j];
-    return nprev;
-}
-
-// unrolled level of the same algorithm for deg == 10: q = (10-D)-th derivative (degree D), all D candidate
-// intervals bisected in lock step (independent Horner chains -> ILP), everything in registers.
-template <int D>
-DEV void interlace_level(const double (&c)[11], double B, double (&prev)[10], int& nprev) {
-    constexpr int K = 10 - D;
-    double q[D + 1];
-#pragma unroll
-    for (int i = 0; i <= D; i++) {
-        double f = 1.0;
-#pragma unroll
-        for (int j = 0; j < K; j++) f *= (double)(i + K - j);
-        q[i] = c[i + K] * f;
-    }
-    double lo[D], hi[D]; bool act[D], neg[D];
-#pragma unroll
-    for (int j = 0; j < D; j++) {
-        lo[j] = (j == 0) ? -B : prev[j > 0 ? j - 1 : 0];
-        hi[j] = (j == nprev) ? B : prev[j < 10 ? j : 9];
-        double flo = q[D], fhi = q[D];
-#pragma unroll
-        for (int i = D - 1; i >= 0; i--) { flo = flo * lo[j] + q[i]; fhi = fhi * hi[j] + q[i]; }
-        neg[j] = flo < 0;
-        act[j] = (j <= nprev) && ((flo < 0) != (fhi < 0));
-    }
-    constexpr int NIT = (D == 10) ? BISECT_FINAL : BISECT_INNER;
-    for (int it = 0; it < NIT; it++) {
-        bool progress = false;
-#pragma unroll
-        for (int j = 0; j < D; j++) {
-            const double m = 0.5 * (lo[j] + hi[j]);
-            double fm = q[D];
-#pragma unroll
-            for (int i = D - 1; i >= 0; i--) fm = fm * m + q[i];
-            const bool go = act[j] && (m > lo[j]) && (m < hi[j]);       // "break" of the reference loop == no-op from here on
-            const bool left = (fm < 0) == neg[j];
-            if (go && left) lo[j] = m;
-            if (go && !left) hi[j] = m;
-            progress |= go;
-        }
-        if (D == 10 && !__any(progress)) break;
-    }
-    double cur[10]; int ncur = 0;
-#pragma unroll
-    for (int t = 0; t < 10; t++) cur[t] = 0.0;
-#pragma unroll
-    for (int j = 0; j < D; j++) {
-        const double r = 0.5 * (lo[j] + hi[j]);
-#pragma unroll
-        for (int t = 0; t < D; t++) if (act[j] && t == ncur) cur[t] = r;
-        ncur += act[j] ? 1 : 0;
-    }
-#pragma unroll
-    for (int t = 0; t < 10; t++) prev[t] = cur[t];
-    nprev = ncur;
-}
-
 DEV void pmul(const double* a, int da, const double* b, int db, double* o) {
     for (int i = 0; i <= da + db; i++) o[i] = 0;
     for (int i = 0; i <= da; i++) for (int j = 0; j <= db; j++) o[i + j] += a[i] * b[j];
@@ -212,6 +122,17 @@ DEV void mul_ql_u(const double (&q)[10], const double (&l)[4], double (&c)[20], 
 #define LM(r, c) ldsM[((r) * 20 + (c)) * 64 + lane]
 #define LB(j, i) ldsB[((j) * 9 + (i)) * 64 + lane]
 #define HYP_LDS_BYTES ((200 + 36) * 64 * 8)
+// hypothesis record (doubles, element-major over all (pair, iteration) slots): det polynomial c[0..10], the three
+// B(z) row polynomials, the null-space basis, the real roots; then two int32 planes: flag, number of roots
+#define HR_BX 11
+#define HR_BY 23
+#define HR_B1 35
+#define HR_LB 50
+#define HR_ROOTS 86
+#define HR_DOUBLES 96
+// one wave per block: LDS accesses of a wave execute in order, only the compiler has to be kept from moving them
+#define HYP_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 DEV void load_El(const double* ldsB, int lane, int r, int c, double (&l)[4]) {
 #pragma unroll
@@ -310,7 +231,7 @@ __global__ __launch_bounds__(256) void k_pose_prep(PoseParams P, const float* __
 __device__ __forceinline__ void ransac_hyp_body(const PoseParams& P, int h0, int hc, int h_end, int npairs, int bx, int by,
                                              const double* __restrict__ n1, const double* __restrict__ n2,
                                              const int32_t* __restrict__ samples, const int32_t* __restrict__ rstate,
-                                             double* __restrict__ models, int32_t* __restrict__ hbest,
+                                             double* __restrict__ hyp, size_t S,
                                              double* ldsM, double* ldsB) {
     const int lane = threadIdx.x;
     const int ppb = 64 / hc;                                       // pairs per block
@@ -512,114 +433,43 @@ __device__ __forceinline__ void ransac_hyp_body(const PoseParams& P, int h0, int
         for (int i = 0; i <= 10; i++) c10[i] += o[i];
 #undef PMUL
     }
-    // ---- real roots (ascending) -> LDS slots reusing the M region (M is dead from here on)
-    int nr = 0;
-    {
-        double c[11]; double mx = 0;
+    // ---- hypothesis record -> global memory (element-major, slot-minor: lanes = consecutive slots)
+    if (active) {
+        const size_t slot = (size_t)pair * P.max_iters + h;
+        double* rec = hyp + slot;
+        double mx = 0;
 #pragma unroll
         for (int i = 0; i <= 10; i++) mx = fmax(mx, fabs(c10[i]));
-        if (mx == 0 || !ok) nr = 0;
-        else {
+        int flag = 0;                                              // 0: no model, 1: degree 10, 2: leading coefficient lost
+        if (!(mx == 0 || !ok)) {
+            double c[11];
 #pragma unroll
-            for (int i = 0; i <= 10; i++) c[i] = c10[i] / mx;
-            const bool full = !(fabs(c[10]) < 1e-15);
-            if (__all(full || !active)) {                          // fast path: every lane has degree 10
-                double B = 0;
-#pragma unroll
-                for (int i = 0; i < 10; i++) B = fmax(B, fabs(c[i] / c[10]));
-                B += 1.0;
-                double prev[10]; int np = 0;
-#pragma unroll
-                for (int t = 0; t < 10; t++) prev[t] = 0.0;
-                interlace_level<1>(c, B, prev, np); interlace_level<2>(c, B, prev, np);
-                interlace_level<3>(c, B, prev, np); interlace_level<4>(c, B, prev, np);
-                interlace_level<5>(c, B, prev, np); interlace_level<6>(c, B, prev, np);
-                interlace_level<7>(c, B, prev, np); interlace_level<8>(c, B, prev, np);
-                interlace_level<9>(c, B, prev, np); interlace_level<10>(c, B, prev, np);
-                nr = full ? np : 0;
-#pragma unroll
-                for (int t = 0; t < 10; t++) LM(0, t) = prev[t];
-            } else {                                               // rare: some lane lost the leading coefficient
-                int deg = 10;
-                while (deg > 0 && fabs(c[deg]) < 1e-15) deg--;
-                double rr[10];
-                for (int t = 0; t < 10; t++) rr[t] = 0;
-                if (deg > 0) {
-                    double B = 0;
-                    for (int i = 0; i < deg; i++) B = fmax(B, fabs(c[i] / c[deg]));
-                    B += 1.0;
-                    nr = real_roots_generic(c, deg, B, rr);
-                }
-                for (int t = 0; t < 10; t++) LM(0, t) = rr[t];
-            }
+            for (int i = 0; i <= 10; i++) { c[i] = c10[i] / mx; rec[(size_t)i * S] = c[i]; }
+            flag = !(fabs(c[10]) < 1e-15) ? 1 : 2;
         }
-    }
-    // ---- back-substitute each root, write the model, count inliers
-    const float thr2 = (float)(P.thr * P.thr);
-    double* mo = models + ((size_t)pair * P.max_iters + hh) * 90;
-    int count = 0, bestc = -1, bestm = 0;
-    int nr_max = nr;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) nr_max = max(nr_max, __shfl_xor(nr_max, o));
-    for (int ri = 0; ri < nr_max; ri++) {
-        if (ri >= nr) continue;
-        const double z = LM(0, ri);
-        double Bz[3][3];
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            double v = Bx[i][3];
 #pragma unroll
-            for (int k = 2; k >= 0; k--) v = v * z + Bx[i][k];
-            Bz[i][0] = v;
-            v = By[i][3];
+            for (int k = 0; k < 4; k++) { rec[(size_t)(HR_BX + 4 * i + k) * S] = Bx[i][k]; rec[(size_t)(HR_BY + 4 * i + k) * S] = By[i][k]; }
 #pragma unroll
-            for (int k = 2; k >= 0; k--) v = v * z + By[i][k];
-            Bz[i][1] = v;
-            v = B1[i][4];
-#pragma unroll
-            for (int k = 3; k >= 0; k--) v = v * z + B1[i][k];
-            Bz[i][2] = v;
+            for (int k = 0; k < 5; k++) rec[(size_t)(HR_B1 + 5 * i + k) * S] = B1[i][k];
         }
-        double c01[3], c02[3], c12[3];
-        cross3(Bz[0], Bz[1], c01); cross3(Bz[0], Bz[2], c02); cross3(Bz[1], Bz[2], c12);
-        const double n01 = dot3(c01, c01), n02 = dot3(c02, c02), n12 = dot3(c12, c12);
-        double nv0 = c01[0], nv1 = c01[1], nv2 = c01[2], nn = n01;
-        if (n02 > nn) { nv0 = c02[0]; nv1 = c02[1]; nv2 = c02[2]; nn = n02; }
-        if (n12 > nn) { nv0 = c12[0]; nv1 = c12[1]; nv2 = c12[2]; nn = n12; }
-        if (!(nn > 0)) continue;
-        const double inv = 1.0 / sqrt(nn);
-        const double w = nv2 * inv;
-        if (fabs(w) < 1e-10) continue;
-        const double x = (nv0 * inv) / w, y = (nv1 * inv) / w;
-        double E[9]; double fn = 0;
 #pragma unroll
-        for (int i = 0; i < 9; i++) {
-            E[i] = ((x * LB(0, i) + y * LB(1, i)) + z * LB(2, i)) + LB(3, i);
-            fn += E[i] * E[i];
-        }
-        fn = sqrt(fn);
-        if (!(fn > 0)) continue;
+        for (int j = 0; j < 4; j++)
 #pragma unroll
-        for (int i = 0; i < 9; i++) E[i] = E[i] / fn;
-        int good = 0;
-        for (int i = 0; i < M; i++) good += sampson_inlier(E, pa[2 * i], pa[2 * i + 1], pb[2 * i], pb[2 * i + 1], thr2);   // M is per lane (its pair)
-        if (active) {
-#pragma unroll
-            for (int k = 0; k < 9; k++) mo[9 * count + k] = E[k];
-        }
-        if (good > bestc) { bestc = good; bestm = count; }
-        count++;
+            for (int i = 0; i < 9; i++) rec[(size_t)(HR_LB + 9 * j + i) * S] = LB(j, i);
+        reinterpret_cast<int32_t*>(hyp + (size_t)HR_DOUBLES * S)[slot] = flag;
     }
-    if (active) hbest[(size_t)pair * P.max_iters + h] = count ? ((bestc << 4) | bestm) : -1;
+    HYP_SYNC();                                                   // k_ransac_hyp_list re-enters with the same LDS
 }
 
 __global__ __launch_bounds__(64) void k_ransac_hyp(PoseParams P, int h0, int hc, int h_end, int npairs,
                                                    const double* __restrict__ n1, const double* __restrict__ n2,
                                                    const int32_t* __restrict__ samples, const int32_t* __restrict__ rstate,
-                                                   double* __restrict__ models, int32_t* __restrict__ hbest) {
+                                                   double* __restrict__ hyp, size_t S) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* ldsM = reinterpret_cast<double*>(smem);
-    ransac_hyp_body(P, h0, hc, h_end, npairs, blockIdx.x, blockIdx.y, n1, n2, samples, rstate, models, hbest, ldsM, ldsM + 200 * 64);
+    ransac_hyp_body(P, h0, hc, h_end, npairs, blockIdx.x, blockIdx.y, n1, n2, samples, rstate, hyp, S, ldsM, ldsM + 200 * 64);
 }
 
 // Later chunks (h >= 16) are only needed for the pairs whose adaptive bound is still above 16 after the
@@ -629,14 +479,327 @@ __global__ __launch_bounds__(64) void k_ransac_hyp(PoseParams P, int h0, int hc,
 __global__ __launch_bounds__(64) void k_ransac_hyp_list(PoseParams P, int h0, int h_end, int npairs,
                                                         const double* __restrict__ n1, const double* __restrict__ n2,
                                                         const int32_t* __restrict__ samples, const int32_t* __restrict__ rstate,
-                                                        double* __restrict__ models, int32_t* __restrict__ hbest,
+                                                        double* __restrict__ hyp, size_t S,
                                                         const int32_t* __restrict__ worklist, int chunks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* ldsM = reinterpret_cast<double*>(smem);
     const int total = worklist[0] * chunks;
     for (int wi = blockIdx.x; wi < total; wi += gridDim.x)
-        ransac_hyp_body(P, h0, 64, h_end, npairs, wi % chunks, worklist[1 + wi / chunks], n1, n2, samples, rstate, models, hbest,
+        ransac_hyp_body(P, h0, 64, h_end, npairs, wi % chunks, worklist[1 + wi / chunks], n1, n2, samples, rstate, hyp, S,
                         ldsM, ldsM + 200 * 64);
+}
+
+// ---- sub-items: 16 consecutive hypotheses of one pair.  First chunk (worklist == nullptr): sub = pair, h in [0, 16).
+// Later chunks: sub -> work-list entry (sub / (4*chunks)), 64-hypothesis chunk, quarter.
+DEV bool sub_item(const int32_t* worklist, int chunks, int h0, int npairs, int sub, int& pair, int& hbase) {
+    if (!worklist) { pair = sub; hbase = h0; return sub < npairs; }
+    const int item = sub >> 2, q = sub & 3;
+    if (item >= worklist[0] * chunks) return false;
+    pair = worklist[1 + item / chunks];
+    hbase = h0 + (item % chunks) * 64 + q * 16;
+    return true;
+}
+
+// one bisection level of the derivative-interlacing root finder (oracle/pose.cpp real_roots), ONE candidate
+// interval per lane: lane j of a 16-lane group owns the interval (prev[j-1], prev[j]) of the degree-D derivative.
+// The arithmetic per interval is exactly the sequential algorithm's; only the mapping to lanes differs.
+template <int D>
+DEV void roots_level(const double (&c)[11], double B, int j, int gshift, double* prev, int& nprev) {
+    constexpr int K = 10 - D;
+    double q[D + 1];
+#pragma unroll
+    for (int i = 0; i <= D; i++) {
+        double f = 1.0;
+#pragma unroll
+        for (int jj = 0; jj < K; jj++) f *= (double)(i + K - jj);
+        q[i] = c[i + K] * f;
+    }
+    const bool mine = j < D && j <= nprev;
+    double lo = (j == 0) ? -B : prev[j > 0 ? (j <= 10 ? j - 1 : 9) : 0];
+    double hi = (j == nprev) ? B : prev[j < 10 ? j : 9];
+    double flo = q[D], fhi = q[D];
+#pragma unroll
+    for (int i = D - 1; i >= 0; i--) { flo = flo * lo + q[i]; fhi = fhi * hi + q[i]; }
+    const bool neg = flo < 0;
+    const bool act = mine && ((flo < 0) != (fhi < 0));
+    constexpr int NIT = (D == 10) ? BISECT_FINAL : BISECT_INNER;
+    for (int it = 0; it < NIT; it++) {
+        const double m = 0.5 * (lo + hi);
+        double fm = q[D];
+#pragma unroll
+        for (int i = D - 1; i >= 0; i--) fm = fm * m + q[i];
+        const bool go = act && (m > lo) && (m < hi);               // "break" of the reference loop == no-op from here on
+        const bool left = (fm < 0) == neg;
+        if (go && left) lo = m;
+        if (go && !left) hi = m;
+        if (D == 10 && !__any(go)) break;
+    }
+    const double r = 0.5 * (lo + hi);
+    const uint32_t mask = (uint32_t)(__builtin_amdgcn_ballot_w64(act) >> gshift) & 0xFFFFu;
+    HYP_SYNC();                                                    // every lane has read prev[]
+    if (act) prev[__popc(mask & ((1u << j) - 1u))] = r;
+    nprev = __popc(mask);
+    HYP_SYNC();
+}
+
+// the same level for a polynomial whose degree is only known at run time (the degree-10 coefficient vanished):
+// q is padded with zeros up to degree 10 -- Horner started on leading zeros reproduces the degree-d Horner chain
+// bit for bit (0*m + q[d] == q[d]) -- and its coefficients come from the group's LDS copy of c.
+DEV void roots_level_rt(const double* cl, int deg, int d, double B, int j, int gshift, double* prev, int& nprev) {
+    const int k = deg - d;
+    double q[11];
+#pragma unroll
+    for (int i = 0; i <= 10; i++) {
+        double f = 1.0;
+        for (int jj = 0; jj < k; jj++) f *= (double)(i + k - jj);
+        q[i] = i <= d ? cl[min(i + k, 10)] * f : 0.0;
+    }
+    const bool mine = j < d && j <= nprev;
+    double lo = (j == 0) ? -B : prev[j > 0 ? (j <= 10 ? j - 1 : 9) : 0];
+    double hi = (j == nprev) ? B : prev[j < 10 ? j : 9];
+    double flo = q[10], fhi = q[10];
+#pragma unroll
+    for (int i = 9; i >= 0; i--) { flo = flo * lo + q[i]; fhi = fhi * hi + q[i]; }
+    const bool neg = flo < 0;
+    const bool act = mine && ((flo < 0) != (fhi < 0));
+    const int nit = d == deg ? BISECT_FINAL : BISECT_INNER;
+    for (int it = 0; it < nit; it++) {
+        const double m = 0.5 * (lo + hi);
+        double fm = q[10];
+#pragma unroll
+        for (int i = 9; i >= 0; i--) fm = fm * m + q[i];
+        const bool go = act && (m > lo) && (m < hi);
+        const bool left = (fm < 0) == neg;
+        if (go && left) lo = m;
+        if (go && !left) hi = m;
+        if (!__any(go)) break;
+    }
+    const double r = 0.5 * (lo + hi);
+    const uint32_t mask = (uint32_t)(__builtin_amdgcn_ballot_w64(act) >> gshift) & 0xFFFFu;
+    HYP_SYNC();
+    if (act) prev[__popc(mask & ((1u << j) - 1u))] = r;
+    nprev = __popc(mask);
+    HYP_SYNC();
+}
+
+// real roots of every hypothesis polynomial: 16 lanes per hypothesis, 16 hypotheses (one sub-item) per block
+__global__ __launch_bounds__(256) void k_hyp_roots(PoseParams P, int h0, int h_end, int npairs, const int32_t* __restrict__ rstate,
+                                                   double* __restrict__ hyp, size_t S, const int32_t* __restrict__ worklist, int chunks) {
+    __shared__ double sh_prev[16][10];
+    __shared__ double sh_c[16][11];
+    const int g = threadIdx.x >> 4, j = threadIdx.x & 15, gshift = (threadIdx.x & 63) & ~15;
+    for (int sub = blockIdx.x; ; sub += gridDim.x) {
+        int pair, hbase;
+        if (!sub_item(worklist, chunks, h0, npairs, sub, pair, hbase)) return;
+        const int h = hbase + g;
+        const bool active = h < rstate[(size_t)pair * RS] && h < h_end && h < max(P.max_iters, 1);
+        const size_t slot = (size_t)pair * P.max_iters + (active ? h : hbase);
+        int32_t* flags = reinterpret_cast<int32_t*>(hyp + (size_t)HR_DOUBLES * S);
+        int32_t* nrs = flags + S;
+        const int flag = active ? flags[slot] : 0;
+        double c[11];
+#pragma unroll
+        for (int i = 0; i <= 10; i++) c[i] = flag ? hyp[slot + (size_t)i * S] : (i == 10 ? 1.0 : 0.0);
+        double* prev = sh_prev[g];
+        int np = 0;
+        if (__any(flag == 1)) {
+            double B = 0;
+#pragma unroll
+            for (int i = 0; i < 10; i++) B = fmax(B, fabs(c[i] / c[10]));
+            B += 1.0;
+            if (flag != 1) B = 1.0;                                // lanes of other groups: keep the arithmetic finite, results unused
+            roots_level<1>(c, B, j, gshift, prev, np); roots_level<2>(c, B, j, gshift, prev, np);
+            roots_level<3>(c, B, j, gshift, prev, np); roots_level<4>(c, B, j, gshift, prev, np);
+            roots_level<5>(c, B, j, gshift, prev, np); roots_level<6>(c, B, j, gshift, prev, np);
+            roots_level<7>(c, B, j, gshift, prev, np); roots_level<8>(c, B, j, gshift, prev, np);
+            roots_level<9>(c, B, j, gshift, prev, np); roots_level<10>(c, B, j, gshift, prev, np);
+        }
+        if (flag == 1) {
+            if (j < np) hyp[slot + (size_t)(HR_ROOTS + j) * S] = prev[j];
+            if (j == 0) nrs[slot] = np;
+        } else if (active && flag == 0 && j == 0) nrs[slot] = 0;
+        if (__any(flag == 2)) {                                    // rare: the degree-10 coefficient vanished somewhere in this wave
+            double* cl = sh_c[g];
+            if (j == 0) {
+#pragma unroll
+                for (int i = 0; i <= 10; i++) cl[i] = c[i];
+            }
+            HYP_SYNC();
+            int deg = 10;
+            while (deg > 0 && fabs(cl[deg]) < 1e-15) deg--;
+            if (flag != 2) deg = 0;
+            double B = 0;
+            for (int i = 0; i < deg; i++) B = fmax(B, fabs(cl[i] / cl[deg]));
+            B += 1.0;
+            int degmax = deg;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) degmax = max(degmax, __shfl_xor(degmax, o));
+            int nq = 0;
+            for (int d = 1; d <= degmax; d++) {
+                // groups of lower degree idle through the extra levels (d > deg: no interval is theirs)
+                int np2 = nq;
+                roots_level_rt(cl, deg, d <= deg ? d : 0, B, d <= deg ? j : 16, gshift, prev, np2);
+                if (d <= deg) nq = np2;
+            }
+            if (flag == 2) {
+                if (j < nq) hyp[slot + (size_t)(HR_ROOTS + j) * S] = prev[j];
+                if (j == 0) nrs[slot] = nq;
+            }
+        }
+        HYP_SYNC();
+        if (!worklist) return;
+    }
+}
+
+// models + scores of one sub-item (16 hypotheses of one pair): thread (hyp, root) back-substitutes its root, the
+// 256 threads then score every model of the sub-item against the pair's points (wave = model, lanes = points),
+// and thread hyp picks the first model with the largest count.  hbest[pair][h] = (best count << 4) | model, -1 = none.
+#define SC_CH 1024                                                 // points staged in LDS per pass
+__global__ __launch_bounds__(256) void k_hyp_score(PoseParams P, int h0, int h_end, int npairs, const int32_t* __restrict__ rstate,
+                                                   const double* __restrict__ n1, const double* __restrict__ n2,
+                                                   const double* __restrict__ hyp, size_t S, double* __restrict__ models,
+                                                   int32_t* __restrict__ hbest, const int32_t* __restrict__ worklist, int chunks) {
+    __shared__ double sE[160][9];
+    __shared__ double sX1[SC_CH], sY1[SC_CH], sX2[SC_CH], sY2[SC_CH];
+    __shared__ int32_t sValid[16][10], sBase[16], sCnt[16], sTag[160], sGood[160], sTotal;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float thr2 = (float)(P.thr * P.thr);
+    // division-free classification of (float)(num/den) <= thr2: mid = the double half way between thr2 and the next
+    // float; num <= kLo*den is certainly an inlier, num >= kHi*den certainly an outlier (margins 2^-40 >> the 2^-53
+    // rounding of the products), anything in between takes the exact division.  Same decisions as the oracle.
+    const double tmid = 0.5 * ((double)thr2 + (double)__uint_as_float(__float_as_uint(thr2) + 1u));
+    const double kLo = tmid * (1.0 - 0x1p-40), kHi = tmid * (1.0 + 0x1p-40);
+    for (int sub = blockIdx.x; ; sub += gridDim.x) {
+        int pair, hbase;
+        if (!sub_item(worklist, chunks, h0, npairs, sub, pair, hbase)) return;
+        const int niters = rstate[(size_t)pair * RS], M = rstate[(size_t)pair * RS + 6];
+        const int32_t* nrs = reinterpret_cast<const int32_t*>(hyp + (size_t)HR_DOUBLES * S) + S;
+        // ---- (hyp, root) threads: back-substitution
+        const int hy = tid / 10, ri = tid - hy * 10;
+        bool valid = false;
+        double E[9];
+        if (tid < 160) {
+            const int h = hbase + hy;
+            const bool active = h < niters && h < h_end && h < max(P.max_iters, 1);
+            const size_t slot = (size_t)pair * P.max_iters + h;
+            if (active && ri < nrs[slot]) {
+                const double* rec = hyp + slot;
+                const double z = rec[(size_t)(HR_ROOTS + ri) * S];
+                double Bz[3][3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    double v = rec[(size_t)(HR_BX + 4 * i + 3) * S];
+#pragma unroll
+                    for (int k = 2; k >= 0; k--) v = v * z + rec[(size_t)(HR_BX + 4 * i + k) * S];
+                    Bz[i][0] = v;
+                    v = rec[(size_t)(HR_BY + 4 * i + 3) * S];
+#pragma unroll
+                    for (int k = 2; k >= 0; k--) v = v * z + rec[(size_t)(HR_BY + 4 * i + k) * S];
+                    Bz[i][1] = v;
+                    v = rec[(size_t)(HR_B1 + 5 * i + 4) * S];
+#pragma unroll
+                    for (int k = 3; k >= 0; k--) v = v * z + rec[(size_t)(HR_B1 + 5 * i + k) * S];
+                    Bz[i][2] = v;
+                }
+                double c01[3], c02[3], c12[3];
+                cross3(Bz[0], Bz[1], c01); cross3(Bz[0], Bz[2], c02); cross3(Bz[1], Bz[2], c12);
+                const double n01 = dot3(c01, c01), n02 = dot3(c02, c02), n12 = dot3(c12, c12);
+                double nv0 = c01[0], nv1 = c01[1], nv2 = c01[2], nn = n01;
+                if (n02 > nn) { nv0 = c02[0]; nv1 = c02[1]; nv2 = c02[2]; nn = n02; }
+                if (n12 > nn) { nv0 = c12[0]; nv1 = c12[1]; nv2 = c12[2]; nn = n12; }
+                if (nn > 0) {
+                    const double inv = 1.0 / sqrt(nn);
+                    const double w = nv2 * inv;
+                    if (!(fabs(w) < 1e-10)) {
+                        const double x = (nv0 * inv) / w, y = (nv1 * inv) / w;
+                        double fn = 0;
+#pragma unroll
+                        for (int i = 0; i < 9; i++) {
+                            E[i] = ((x * rec[(size_t)(HR_LB + i) * S] + y * rec[(size_t)(HR_LB + 9 + i) * S]) + z * rec[(size_t)(HR_LB + 18 + i) * S]) +
+                                   rec[(size_t)(HR_LB + 27 + i) * S];
+                            fn += E[i] * E[i];
+                        }
+                        fn = sqrt(fn);
+                        if (fn > 0) {
+#pragma unroll
+                            for (int i = 0; i < 9; i++) E[i] = E[i] / fn;
+                            valid = true;
+                        }
+                    }
+                }
+            }
+            sValid[hy][ri] = valid ? 1 : 0;
+        }
+        __syncthreads();
+        if (tid < 16) {                                            // models per hypothesis and their base in the sub-item's list
+            int c = 0;
+            for (int r = 0; r < 10; r++) c += sValid[tid][r];
+            sCnt[tid] = c;
+        }
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int k = 0; k < 16; k++) { sBase[k] = t; t += sCnt[k]; } sTotal = t; }
+        __syncthreads();
+        if (valid) {
+            int m = 0;
+            for (int r = 0; r < ri; r++) m += sValid[hy][r];       // model index = rank among the hypothesis' valid roots
+            const int t = sBase[hy] + m;
+            double* mo = models + ((size_t)pair * P.max_iters + hbase + hy) * 90 + 9 * m;
+#pragma unroll
+            for (int k = 0; k < 9; k++) { mo[k] = E[k]; sE[t][k] = E[k]; }
+            sTag[t] = (hy << 4) | m; sGood[t] = 0;
+        }
+        const int T = sTotal;
+        const double* pa = n1 + (size_t)pair * P.mcap * 2;
+        const double* pb = n2 + (size_t)pair * P.mcap * 2;
+        for (int c0 = 0; c0 < (T > 0 ? M : 0); c0 += SC_CH) {
+            const int mc = min(M - c0, SC_CH);
+            __syncthreads();
+            for (int i = tid; i < mc; i += 256) {
+                sX1[i] = pa[2 * (c0 + i)]; sY1[i] = pa[2 * (c0 + i) + 1];
+                sX2[i] = pb[2 * (c0 + i)]; sY2[i] = pb[2 * (c0 + i) + 1];
+            }
+            __syncthreads();
+            for (int t = wv; t < T; t += 4) {
+                double Em[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) Em[k] = sE[t][k];
+                int good = 0;
+                for (int i = lane; i < mc; i += 64) {
+                    const double x1 = sX1[i], y1 = sY1[i], x2 = sX2[i], y2 = sY2[i];
+                    const double Ex0 = (Em[0] * x1 + Em[1] * y1) + Em[2];
+                    const double Ex1 = (Em[3] * x1 + Em[4] * y1) + Em[5];
+                    const double Ex2 = (Em[6] * x1 + Em[7] * y1) + Em[8];
+                    const double Et0 = (Em[0] * x2 + Em[3] * y2) + Em[6];
+                    const double Et1 = (Em[1] * x2 + Em[4] * y2) + Em[7];
+                    const double x2tEx1 = (x2 * Ex0 + y2 * Ex1) + Ex2;
+                    const double a = Ex0 * Ex0, b = Ex1 * Ex1, c = Et0 * Et0, d = Et1 * Et1;
+                    const double num = x2tEx1 * x2tEx1, den = ((a + b) + c) + d;
+                    int in;
+                    if (den > 0 && num <= kLo * den) in = 1;
+                    else if (num >= kHi * den) in = 0;
+                    else in = (float)(num / den) <= thr2 ? 1 : 0;
+                    good += in;
+                }
+                good += __builtin_amdgcn_update_dpp(0, good, 0xB1, 0xF, 0xF, false);
+                good += __builtin_amdgcn_update_dpp(0, good, 0x4E, 0xF, 0xF, false);
+                good += __builtin_amdgcn_update_dpp(0, good, 0x141, 0xF, 0xF, false);
+                good += __builtin_amdgcn_update_dpp(0, good, 0x140, 0xF, 0xF, false);
+                good = __builtin_amdgcn_readlane(good, 0) + __builtin_amdgcn_readlane(good, 16) +
+                       __builtin_amdgcn_readlane(good, 32) + __builtin_amdgcn_readlane(good, 48);
+                if (lane == 0) sGood[t] += good;
+            }
+        }
+        __syncthreads();
+        if (tid < 16) {
+            const int h = hbase + tid;
+            const bool active = h < niters && h < h_end && h < max(P.max_iters, 1);
+            int bestc = -1, bestm = 0;
+            for (int m = 0; m < sCnt[tid]; m++) { const int gd = sGood[sBase[tid] + m]; if (gd > bestc) { bestc = gd; bestm = m; } }
+            if (active) hbest[(size_t)pair * P.max_iters + h] = sCnt[tid] ? ((bestc << 4) | bestm) : -1;
+        }
+        __syncthreads();
+        if (!worklist) return;
+    }
 }
 
 DEV int update_num_iters(double p, double ep, int modelPoints, int maxIters) {
@@ -858,7 +1021,7 @@ static PoseParams make_pose_params(const vis_ctx* ctx, int max_iters, int mcap) 
 // d_p1/d_p2: npairs x mcap x 2 floats; d_npts: npairs
 int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p1, const float* d_p2, const int32_t* d_npts,
              double* d_n1, double* d_n2, int32_t* d_samples, double* d_models, int32_t* d_counts, int32_t* d_rstate,
-             const double* d_E_in, uint8_t* d_mask, PoseOut* d_pose, int do_ransac, int do_pose, int32_t* d_worklist) {
+             const double* d_E_in, uint8_t* d_mask, PoseOut* d_pose, int do_ransac, int do_pose, int32_t* d_worklist, double* d_hyp) {
     hipStream_t st = ctx->stream;
     PoseParams P = make_pose_params(ctx, max_iters, mcap);
     static bool attr_set = false;
@@ -869,16 +1032,28 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
     }
     hipLaunchKernelGGL(k_pose_prep, dim3(npairs), dim3(256), 0, st, P, d_p1, d_p2, d_npts, d_n1, d_n2, d_samples, d_rstate);
     if (do_ransac) {
+        // per chunk of hypotheses: (A) minimal solver up to the degree-10 polynomial, lane = hypothesis, 118 KB LDS per wave;
+        // (B) its real roots, 16 lanes per hypothesis; (C) models + inlier counts, 256 threads per 16 hypotheses;
+        // then the sequential accept/adaptive-bound rule is replayed by k_ransac_scan.
         const int first = std::min(16, std::max(max_iters, 1));
+        const size_t S = (size_t)npairs * max_iters;
         HIPCHK(ctx, hipMemsetAsync(d_worklist, 0, sizeof(int32_t), st));
         hipLaunchKernelGGL(k_ransac_hyp, dim3(1, (npairs + 3) / 4), dim3(64), HYP_LDS_BYTES, st, P, 0, 16, first, npairs, d_n1, d_n2,
-                           d_samples, d_rstate, d_models, d_counts);
+                           d_samples, d_rstate, d_hyp, S);
+        hipLaunchKernelGGL(k_hyp_roots, dim3(npairs), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_hyp, S, (const int32_t*)nullptr, 0);
+        hipLaunchKernelGGL(k_hyp_score, dim3(npairs), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_n1, d_n2, d_hyp, S, d_models,
+                           d_counts, (const int32_t*)nullptr, 0);
         hipLaunchKernelGGL(k_ransac_scan, dim3(npairs), dim3(64), 0, st, P, first, d_counts, d_rstate, d_worklist);
         if (max_iters > first) {
             const int chunks = (max_iters - first + 63) / 64;
             const int nb = std::min(256, npairs * chunks);
+            const int nsub = (int)std::min<long long>(2048, (long long)npairs * chunks * 4);
             hipLaunchKernelGGL(k_ransac_hyp_list, dim3(nb), dim3(64), HYP_LDS_BYTES, st, P, first, max_iters,
-                               npairs, d_n1, d_n2, d_samples, d_rstate, d_models, d_counts, (const int32_t*)d_worklist, chunks);
+                               npairs, d_n1, d_n2, d_samples, d_rstate, d_hyp, S, (const int32_t*)d_worklist, chunks);
+            hipLaunchKernelGGL(k_hyp_roots, dim3(nsub), dim3(256), 0, st, P, first, max_iters, npairs, d_rstate, d_hyp, S,
+                               (const int32_t*)d_worklist, chunks);
+            hipLaunchKernelGGL(k_hyp_score, dim3(nsub), dim3(256), 0, st, P, first, max_iters, npairs, d_rstate, d_n1, d_n2, d_hyp, S,
+                               d_models, d_counts, (const int32_t*)d_worklist, chunks);
             hipLaunchKernelGGL(k_ransac_scan, dim3(npairs), dim3(64), 0, st, P, max_iters, d_counts, d_rstate, (int32_t*)nullptr);
         }
     }

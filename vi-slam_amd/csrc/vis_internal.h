@@ -77,6 +77,7 @@ struct Plan {
     int32_t* d_rstate = nullptr;             // npairs x 4: niters, maxGood, bestIter, bestModel
     PoseOut* d_pose = nullptr;               // npairs
     int32_t* d_worklist = nullptr;           // 1 + npairs: pairs that need RANSAC chunks beyond the first
+    double* d_hyp = nullptr;                 // npairs x max_iters hypothesis records (VIS_HYP_DOUBLES each, element-major)
     int max_iters = 0;
     bool have_prev = false;                  // batch: record 0 holds the previous batch's last frame
     int last_n = 0;                          // frames in the last batch
@@ -130,9 +131,10 @@ int launch_match(vis_ctx* ctx, Plan* pl, int npairs);
 int launch_filter(vis_ctx* ctx, Plan* pl, int npairs);
 int launch_pose(vis_ctx* ctx, Plan* pl, int npairs);
 int launch_half_pyramid(vis_ctx* ctx, const uint8_t* d_img, int w, int h, int stride, uint8_t* d_out[5]);
+#define VIS_HYP_DOUBLES 97                // 96 doubles + 2 int32 per (pair, iteration): see pose.hip HR_*
 int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p1, const float* d_p2, const int32_t* d_npts,
              double* d_n1, double* d_n2, int32_t* d_samples, double* d_models, int32_t* d_counts, int32_t* d_rstate,
-             const double* d_E_in, uint8_t* d_mask, PoseOut* d_pose, int do_ransac, int do_pose, int32_t* d_worklist);
+             const double* d_E_in, uint8_t* d_mask, PoseOut* d_pose, int do_ransac, int do_pose, int32_t* d_worklist, double* d_hyp);
 int  vis_build_sample_table(vis_ctx* ctx, int max_m);
 int f2f_run(vis_ctx* ctx, const vis_keypoint* d_pts1, const vis_keypoint* d_pts2, int m, const float* d_rot,
             const int32_t* d_idx, int iters, double* d_nv, float* d_counts);
