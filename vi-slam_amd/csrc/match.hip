@@ -100,6 +100,18 @@ __global__ __launch_bounds__(256) void k_expand(const uint8_t* __restrict__ desc
 }
 
 #define KM_ROW 17            // uint4 per LDS row: 256 B of descriptor + 16 B pad
+// (a << 15) + s with the wave-uniform addend kept in an SGPR (one VALU instruction per key)
+__device__ __forceinline__ uint32_t lshl15_add(int a, uint32_t s) {
+    uint32_t d;
+    asm("v_lshl_add_u32 %0, %1, 15, %2" : "=v"(d) : "v"(a), "s"(s));
+    return d;
+}
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, const int32_t* __restrict__ nkp, int kcap,
                                                   const int32_t* __restrict__ pair_q, const int32_t* __restrict__ pair_t,
                                                   uint32_t* __restrict__ knn12, uint32_t* __restrict__ knn21) {
@@ -118,7 +130,12 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, 
     {
         const int8_t* xf = X + ((size_t)rf * kcap + min(fidx, nf - 1)) * 256 + 16 * h;
 #pragma unroll
-        for (int ks = 0; ks < 8; ks++) bf[ks] = *reinterpret_cast<const v4i*>(xf + 32 * ks);
+        for (int ks = 0; ks < 8; ks++) {
+            // the fixed operand is negated (+-1 bytes: x ^ 0xFE swaps 0x01 and 0xFF), so acc = -dot = 2*Hamming - 256
+            // and the key is one v_lshl_add_u32 of the accumulator
+            const v4i x = *reinterpret_cast<const v4i*>(xf + 32 * ks);
+            bf[ks] = v4i{x[0] ^ (int)0xFEFEFEFE, x[1] ^ (int)0xFEFEFEFE, x[2] ^ (int)0xFEFEFEFE, x[3] ^ (int)0xFEFEFEFE};
+        }
     }
     const int8_t* xs = X + (size_t)rs * kcap * 256;
     const int ntiles = (ns + 31) / 32;
@@ -131,6 +148,9 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, 
             tile[buf][row * KM_ROW + c16] = *reinterpret_cast<const uint4*>(xs + (size_t)srow * 256 + 16 * c16);
         }
     };
+    // running keys: (2*Hamming << 15) | (tile << 4) | accumulator register.  Inside a lane the register order is the
+    // row order, so (tile, register) breaks ties exactly like the row index; it is a wave-uniform addend (SGPR).  The
+    // true row index is restored before the two half-lanes of a column are merged.
     uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
     if (ntiles > 0) stage(0, 0);
     __syncthreads();
@@ -144,25 +164,32 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, 
             const v4i a = {(int)au.x, (int)au.y, (int)au.z, (int)au.w};
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[ks], acc, 0, 0, 0);
         }
-        const int toff = t * 32 + 4 * h;
+        const uint32_t kt = (256u << 15) + ((uint32_t)t << 4);
         if (t * 32 + 32 <= ns) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const uint32_t key = ((uint32_t)(256 - acc[r]) << 15) + (uint32_t)(toff + (r & 3) + 8 * (r >> 2));
-                k1 = min(k1, max(k0, key));
+                const uint32_t key = lshl15_add(acc[r], kt + (uint32_t)r);
+                k1 = umed3(k0, k1, key);            // k0 <= k1: second smallest of the three
                 k0 = min(k0, key);
             }
         } else {
+            const int toff = t * 32 + 4 * h;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int trow = toff + (r & 3) + 8 * (r >> 2);
-                const uint32_t key = trow < ns ? (((uint32_t)(256 - acc[r]) << 15) + (uint32_t)trow) : 0xFFFFFFFFu;
-                k1 = min(k1, max(k0, key));
+                const uint32_t key = trow < ns ? lshl15_add(acc[r], kt + (uint32_t)r) : 0xFFFFFFFFu;
+                k1 = umed3(k0, k1, key);
                 k0 = min(k0, key);
             }
         }
         __syncthreads();
     }
+    auto true_key = [&](uint32_t k) {
+        const uint32_t lo = k & 0x7FFFu, r = lo & 15u;
+        const uint32_t row = (lo >> 4) * 32u + 4u * (uint32_t)h + (r & 3u) + 8u * (r >> 2);
+        return k == 0xFFFFFFFFu ? k : ((k & ~0x7FFFu) | row);
+    };
+    k0 = true_key(k0); k1 = true_key(k1);
     // lanes l and l+32 hold the two row halves of the same column
     const uint32_t o0 = __shfl_xor(k0, 32), o1 = __shfl_xor(k1, 32);
     const uint32_t m0 = min(k0, o0), m1 = min(max(k0, o0), min(k1, o1));
