@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=512, help="frames per step (per GPU)")
+    ap.add_argument("--batch", type=int, default=1024, help="frames per step (per GPU)")
     ap.add_argument("--ring", type=int, default=2, help="distinct batches resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", type=int, default=vislam.STAGE_ALL, help="debug: bitmask of stages (1 detect, 2 match, 4 pose); the reported metric needs all 7")
