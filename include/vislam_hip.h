@@ -179,6 +179,29 @@ int  vis_f2f_ransac(vis_ctx* ctx, const vis_keypoint* pts1, const vis_keypoint* 
                     const float rot[9], const int32_t* sample_idx, int iters,
                     float scale, float out_t[3], int* count_max);
 
+/* ---- the step after matching in CameraGPU::addGPUKeyframe (src/CameraGPU.cpp:154-157) ---- */
+/* Camera::Update's half pyramid (src/Camera.cpp:63-72) + Camera::computeGradient (src/Camera.cpp:167-184) for n
+ * frames resident in HBM.  Per frame and per level l = 0..4 of (w>>l) x (h>>l) pixels: Scharr dx and dy as
+ * CV_16S with OpenCV's `scale` argument (the reference call Scharr(img, g, CV_16S, 1, 0, 3, 0, BORDER_DEFAULT)
+ * passes scale = 3, delta = 0), and gradient = addWeighted(|dx| sat u8, 0.5, |dy| sat u8, 0.5, 0).
+ * All outputs are caller-owned DEVICE buffers of n * vis_gradient_frame_elems(w, h) elements: inside a frame the
+ * levels are dense and back to back (level l starts at sum_{k<l} (w>>k)(h>>k)); d_gray receives levels 1..4 of
+ * the half pyramid (its level-0 part is left untouched: level 0 is the frame itself).  w, h multiples of 16,
+ * stride % 4 == 0, 1 <= scale <= 8 (int16 cannot overflow), buffers 16-byte aligned. */
+size_t vis_gradient_frame_elems(int w, int h);
+int  vis_gradient_batch(vis_ctx* ctx, const uint8_t* d_frames, int w, int h, int stride, int n, int scale,
+                        uint8_t* d_gray, int16_t* d_gx, int16_t* d_gy, uint8_t* d_g);
+/* one host frame; out pointers per level may be NULL; each receives (w>>l)*(h>>l) elements */
+int  vis_compute_gradient(vis_ctx* ctx, const uint8_t* img, int w, int h, int stride, int scale,
+                          int16_t* const gx[5], int16_t* const gy[5], uint8_t* const g[5]);
+/* Camera::ObtainPatchesPointsPreviousFrame (src/Camera.cpp:358-410) and ObtainDebugPointsPreviousFrame
+ * (:413-445): per level l the candidate list as rows (x, y, 1, 1) in the reference's push_back order, built from
+ * at most 200 matched keypoints of the previous keyframe.  patch[l] / debug[l] receive up to `cap` rows
+ * (VIS_E_CAPACITY if a level has more; n_patch[l] then holds the required count).  Level sizes come from
+ * params.w_size >> l, params.h_size >> l (CameraModel w_size[lvl], h_size[lvl]). */
+int  vis_patch_points(vis_ctx* ctx, const vis_keypoint* good, int n, int cap,
+                      float* const patch[5], int n_patch[5], float* const debug[5], int n_debug[5]);
+
 /* ---- batched stream API (throughput path) --------------------------------- */
 /* Plan device buffers for batches of up to `max_frames` w x h frames.  Frames in a
  * batch are consecutive frames of ONE camera stream: frame i is matched against frame

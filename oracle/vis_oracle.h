@@ -72,6 +72,17 @@ int orc_f2f_ransac(const vis_params* p, const vis_keypoint* pts1, const vis_keyp
 /* the sample sequence cv::RNG((uint64)-1) + getSubset would draw: idx5[iters*5] */
 int orc_ransac_samples(uint64_t seed, int count, int iters, int32_t* idx5);
 
+/* Camera::computeGradient on ONE level, src/Camera.cpp:171-181: Scharr dx/dy (CV_16S, scale as the reference
+ * passes it: 3), |.| saturated to u8, 0.5/0.5 blend rounded half to even.  Outputs dense w x h; any may be NULL */
+int orc_scharr_gradient(const uint8_t* img, int w, int h, int stride, int scale,
+                        int16_t* gx, int16_t* gy, uint8_t* g);
+/* Camera::ObtainPatchesPointsPreviousFrame, src/Camera.cpp:358-410: candidate pixel list of one level
+ * (rows x,y,1,1); lw/lh = the 5 half-pyramid level sizes.  n_out = full count even when cap is smaller */
+int orc_patch_points(const vis_keypoint* good, int n, const int32_t* lw, const int32_t* lh, int level,
+                     float* xyzw, int cap, int* n_out);
+/* Camera::ObtainDebugPointsPreviousFrame, src/Camera.cpp:413-445 */
+int orc_debug_points(const vis_keypoint* good, int n, int level, float* xyzw, int cap, int* n_out);
+
 /* unit-test hooks */
 void orc_sincos_det(double x, double* s, double* c);
 float orc_fast_atan2(float y, float x);

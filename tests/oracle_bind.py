@@ -28,6 +28,9 @@ lib.orc_fast_detect.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
 lib.orc_gaussian_blur7.argtypes = [vp, ci, ci, ci, vp, ci]
 lib.orc_orb_detect_compute.argtypes = [C.POINTER(Params), vp, ci, ci, ci, vp, vp, ci, ip]
 lib.orc_knn2_hamming.argtypes = [vp, ci, vp, ci, vp, vp]
+lib.orc_scharr_gradient.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp]
+lib.orc_patch_points.argtypes = [vp, ci, vp, vp, ci, vp, ci, ip]
+lib.orc_debug_points.argtypes = [vp, ci, ci, vp, ci, ip]
 lib.orc_good_matches.argtypes = [C.POINTER(Params), vp, ci, vp, ci, vp, vp, vp, ci, ip, vp, ci, ip]
 lib.orc_five_point.argtypes = [vp, vp, vp]
 lib.orc_essential_ransac.argtypes = [C.POINTER(Params), vp, vp, ci, vp, vp, ip, ip]
@@ -64,6 +67,35 @@ def half_pyramid(img):
     rc = lib.orc_half_pyramid(_p(img), w, h, img.strides[0], arr)
     assert rc == 0, rc
     return levels
+
+
+def scharr_gradient(img, scale=3):
+    """Camera::computeGradient on one level: (gx int16, gy int16, gradient u8)"""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    gx = np.empty((h, w), np.int16); gy = np.empty((h, w), np.int16); g = np.empty((h, w), np.uint8)
+    rc = lib.orc_scharr_gradient(_p(img), w, h, img.strides[0], scale, _p(gx), _p(gy), _p(g))
+    assert rc == 0, rc
+    return gx, gy, g
+
+
+def patch_points(good, w, h, level, cap=200 * 121):
+    good = np.ascontiguousarray(good)
+    lw = np.array([w >> l for l in range(5)], np.int32); lh = np.array([h >> l for l in range(5)], np.int32)
+    out = np.zeros((cap, 4), np.float32)
+    n = C.c_int(0)
+    rc = lib.orc_patch_points(_p(good), len(good), _p(lw), _p(lh), level, _p(out), cap, C.byref(n))
+    assert rc == 0, rc
+    return out[:n.value].copy()
+
+
+def debug_points(good, level, cap=200):
+    good = np.ascontiguousarray(good)
+    out = np.zeros((cap, 4), np.float32)
+    n = C.c_int(0)
+    rc = lib.orc_debug_points(_p(good), len(good), level, _p(out), cap, C.byref(n))
+    assert rc == 0, rc
+    return out[:n.value].copy()
 
 
 def fast_detect(img, threshold=20):

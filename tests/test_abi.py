@@ -67,7 +67,7 @@ def test_no_product_code_touches_the_oracle():
         for f in fn:
             if f.endswith((".hip", ".cpp", ".h", ".hpp", ".py", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
-                assert "libvis_oracle" not in txt and "oracle_bind" not in txt and 'oracle/' not in txt.replace("oracle/pose.cpp", "").replace("oracle/orb.cpp", "").replace("oracle/match.cpp", "").replace("never includes or links anything under oracle/", ""), (dp, f)
+                assert "libvis_oracle" not in txt and "oracle_bind" not in txt and 'oracle/' not in txt.replace("oracle/pose.cpp", "").replace("oracle/orb.cpp", "").replace("oracle/match.cpp", "").replace("oracle/gradient.cpp", "").replace("never includes or links anything under oracle/", ""), (dp, f)
 
 
 def test_pattern_tables_identical():

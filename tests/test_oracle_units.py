@@ -253,3 +253,59 @@ def test_f2f_ransac_pure_translation(vislam, orc):
     assert abs(abs(d @ (tv / np.linalg.norm(tv))) - 1) < 1e-3 and cm == n
     z, c0 = orc.f2f_ransac(p, a[:1], b[:1], np.eye(3, dtype=np.float32), idx[:0], 1.0)
     assert (z == 0).all()
+
+
+# ---------------------------------------------------------------- Camera::computeGradient / patch builders
+def test_scharr_gradient_known_values(orc):
+    # constant image: no gradient anywhere (BORDER_REFLECT_101 keeps it constant)
+    gx, gy, g = orc.scharr_gradient(np.full((12, 20), 99, np.uint8))
+    assert not gx.any() and not gy.any() and not g.any()
+    # horizontal ramp I = 2x: dx = (3+10+3) * (I(x+1) - I(x-1)) * scale = 16 * 4 * 3 = 192 in the interior, dy = 0;
+    # reflect-101 makes the two border columns see I(x+1) - I(x-1) = 0
+    ramp = np.tile((2 * np.arange(20)).astype(np.uint8), (12, 1))
+    gx, gy, g = orc.scharr_gradient(ramp, 3)
+    assert (gx[:, 1:-1] == 192).all() and (gx[:, 0] == 0).all() and (gx[:, -1] == 0).all()
+    assert not gy.any()
+    assert (g[:, 1:-1] == 96).all()                       # (192 + 0) / 2
+    # vertical step: sign of dy (below minus above) and saturation of |.| before the blend
+    img = np.zeros((10, 16), np.uint8); img[5:] = 255
+    gx, gy, g = orc.scharr_gradient(img, 3)
+    assert (gy[4] == 16 * 255 * 3).all() and (gy[5] == 16 * 255 * 3).all() and (gy[3] == 0).all()
+    assert (g[4] == 128).all()                            # (255 + 0) / 2 = 127.5 -> round half to even = 128
+
+
+def test_gradient_blend_rounds_half_to_even(orc):
+    # |dx| = 1*scale... build values whose half sums hit .5 with even and odd floors: use scale 1 and tiny steps
+    img = np.zeros((8, 16), np.uint8)
+    img[:, 8:] = 1                                         # dx = 16 at the step columns, 0 elsewhere -> g = 8
+    gx, gy, g = orc.scharr_gradient(img, 1)
+    assert gx[4, 7] == 16 and gx[4, 8] == 16 and g[4, 7] == 8
+    img = np.zeros((8, 16), np.uint8); img[3, 5] = 1       # a single bright pixel: |dx| = 3 / 10, |dy| = 3 / 10 around it
+    gx, gy, g = orc.scharr_gradient(img, 1)
+    assert gx[3, 4] == 10 and gy[3, 4] == 0 and g[3, 4] == 5
+    assert abs(gx[2, 4]) == 3 and abs(gy[2, 4]) == 3 and g[2, 4] == 3
+    assert abs(gx[2, 5]) == 0 and abs(gy[2, 5]) == 10 and g[2, 5] == 5
+    # 3 and 0 -> 1.5 -> 2 (even); 3 and 10 -> 6.5 -> 6 (even)
+    img = np.zeros((8, 16), np.uint8); img[3, 5] = 1; img[3, 9] = 1
+    gx, gy, g = orc.scharr_gradient(img, 1)
+    assert g[2, 4] == 3
+
+
+def test_patch_points_reference_quirks(orc):
+    from vislam import KEYPOINT_DTYPE
+    good = np.zeros(1, KEYPOINT_DTYPE); good["x"] = 400.0; good["y"] = 300.0
+    # `patch_size - 1 / 2` is integer arithmetic: start_point == patch_size (5, 3, 2, 5, 5) -> (2*sp+1)^2 points
+    for l, sp in enumerate((5, 3, 2, 5, 5)):
+        pts = orc.patch_points(good, 752, 480, l)
+        assert len(pts) == (2 * sp + 1) ** 2, l
+        x = (400.0 + 0.5) / 2 ** l - 0.5
+        assert pts[0, 0] == int(x - sp) and pts[0, 2] == 1.0 and pts[0, 3] == 1.0
+        assert (pts[1, 0] == pts[0, 0]) and (pts[1, 1] == pts[0, 1] + 1)          # inner loop runs over y
+    # points with i <= 0 or j <= 0 are dropped (strict comparisons in the reference)
+    good["x"] = 1.0; good["y"] = 1.0
+    pts = orc.patch_points(good, 752, 480, 0)
+    assert (pts[:, 0] > 0).all() and (pts[:, 1] > 0).all() and len(pts) == 6 * 6
+    # at most 200 keypoints are used
+    many = np.zeros(300, KEYPOINT_DTYPE); many["x"] = 300; many["y"] = 200
+    assert len(orc.debug_points(many, 2)) == 200
+    assert orc.debug_points(many, 2)[0, 0] == np.float32((300 + 0.5) * 0.25 - 0.5)

@@ -367,6 +367,76 @@ extern "C" int vis_camera_update(vis_ctx* ctx, const uint8_t* img, int w, int h,
     return VIS_OK;
 }
 
+extern "C" size_t vis_gradient_frame_elems(int w, int h) { return (w < 16 || h < 16) ? 0 : vis_grad_frame_elems(w, h); }
+
+extern "C" int vis_gradient_batch(vis_ctx* ctx, const uint8_t* d_frames, int w, int h, int stride, int n, int scale,
+                                  uint8_t* d_gray, int16_t* d_gx, int16_t* d_gy, uint8_t* d_g) {
+    if (!ctx || !d_frames || !d_gray || !d_gx || !d_gy || !d_g) return VIS_E_INVALID;
+    if (w < 16 || h < 16 || (w & 15) || (h & 15) || stride < w || (stride & 3) || n < 1 || scale < 1 || scale > 8) return VIS_E_INVALID;
+    if (((uintptr_t)d_gx | (uintptr_t)d_gy | (uintptr_t)d_g | (uintptr_t)d_gray) & 15) return VIS_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    const size_t frame_bytes = (size_t)stride * h;
+    int rc = launch_half_pyramid_batch(ctx, d_frames, w, h, stride, frame_bytes, n, d_gray);
+    if (rc) return rc;
+    return launch_gradient(ctx, d_frames, w, h, stride, frame_bytes, n, d_gray, scale, d_gx, d_gy, d_g);
+}
+
+extern "C" int vis_compute_gradient(vis_ctx* ctx, const uint8_t* img, int w, int h, int stride, int scale,
+                                    int16_t* const gx[5], int16_t* const gy[5], uint8_t* const g[5]) {
+    if (!ctx || !img || !gx || !gy || !g || w < 16 || h < 16 || (w & 15) || (h & 15) || stride < w || scale < 1 || scale > 8) return VIS_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    const size_t fe = vis_grad_frame_elems(w, h);
+    int rc = ensure_scratch(ctx, (size_t)w * h + fe * 6 + 4096);
+    if (rc) return rc;
+    Carver cv{(char*)ctx->d_scratch, 0};
+    uint8_t* d_img = cv.take<uint8_t>((size_t)w * h);
+    uint8_t* d_gray = cv.take<uint8_t>(fe);
+    int16_t* d_gx = cv.take<int16_t>(fe); int16_t* d_gy = cv.take<int16_t>(fe);
+    uint8_t* d_g = cv.take<uint8_t>(fe);
+    HIPCHK(ctx, hipMemcpy2DAsync(d_img, w, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+    rc = vis_gradient_batch(ctx, d_img, w, h, w, 1, scale, d_gray, d_gx, d_gy, d_g);
+    if (rc) return rc;
+    size_t off = 0;
+    for (int l = 0; l < 5; l++) {
+        const size_t cnt = (size_t)(w >> l) * (h >> l);
+        if (gx[l]) HIPCHK(ctx, hipMemcpyAsync(gx[l], d_gx + off, cnt * 2, hipMemcpyDeviceToHost, ctx->stream));
+        if (gy[l]) HIPCHK(ctx, hipMemcpyAsync(gy[l], d_gy + off, cnt * 2, hipMemcpyDeviceToHost, ctx->stream));
+        if (g[l]) HIPCHK(ctx, hipMemcpyAsync(g[l], d_g + off, cnt, hipMemcpyDeviceToHost, ctx->stream));
+        off += cnt;
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return VIS_OK;
+}
+
+extern "C" int vis_patch_points(vis_ctx* ctx, const vis_keypoint* good, int n, int cap,
+                                float* const patch[5], int n_patch[5], float* const debug[5], int n_debug[5]) {
+    if (!ctx || (n > 0 && !good) || n < 0 || cap < 0 || !patch || !debug || !n_patch || !n_debug) return VIS_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    const int m = std::min(n, 200);
+    int rc = ensure_scratch(ctx, (size_t)200 * sizeof(vis_keypoint) + (size_t)2 * 5 * std::max(cap, 1) * 16 + 4096);
+    if (rc) return rc;
+    Carver cv{(char*)ctx->d_scratch, 0};
+    vis_keypoint* d_good = cv.take<vis_keypoint>(200);
+    float* d_patch = cv.take<float>((size_t)5 * std::max(cap, 1) * 4);
+    float* d_debug = cv.take<float>((size_t)5 * std::max(cap, 1) * 4);
+    int32_t* d_cnt = cv.take<int32_t>(10);
+    if (m) HIPCHK(ctx, hipMemcpyAsync(d_good, good, (size_t)m * sizeof(vis_keypoint), hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_patch_points(ctx, d_good, m, ctx->p.w_size, ctx->p.h_size, d_patch, d_debug, cap, d_cnt);
+    if (rc) return rc;
+    int32_t cnt[10];
+    HIPCHK(ctx, hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    bool over = false;
+    for (int l = 0; l < 5; l++) {
+        n_patch[l] = cnt[l]; n_debug[l] = cnt[5 + l];
+        over = over || cnt[l] > cap || cnt[5 + l] > cap;
+        const int np = std::min(cnt[l], cap), nd = std::min(cnt[5 + l], cap);
+        if (patch[l] && np) HIPCHK(ctx, hipMemcpy(patch[l], d_patch + (size_t)l * cap * 4, (size_t)np * 16, hipMemcpyDeviceToHost));
+        if (debug[l] && nd) HIPCHK(ctx, hipMemcpy(debug[l], d_debug + (size_t)l * cap * 4, (size_t)nd * 16, hipMemcpyDeviceToHost));
+    }
+    return over ? VIS_E_CAPACITY : VIS_OK;
+}
+
 static void collect_detect_timings(vis_ctx* ctx) {
     if (!ctx->ev_ok) return;
     float a = 0;

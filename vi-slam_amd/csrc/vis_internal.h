@@ -131,6 +131,13 @@ int launch_match(vis_ctx* ctx, Plan* pl, int npairs);
 int launch_filter(vis_ctx* ctx, Plan* pl, int npairs);
 int launch_pose(vis_ctx* ctx, Plan* pl, int npairs);
 int launch_half_pyramid(vis_ctx* ctx, const uint8_t* d_img, int w, int h, int stride, uint8_t* d_out[5]);
+// gradient.hip: Camera::Update / computeGradient / patch builders, batched
+size_t vis_grad_frame_elems(int w, int h);
+int launch_half_pyramid_batch(vis_ctx* ctx, const uint8_t* d_frames, int w, int h, int stride, size_t frame_bytes, int n, uint8_t* d_pyr);
+int launch_gradient(vis_ctx* ctx, const uint8_t* d_frames, int w, int h, int stride, size_t frame_bytes, int n,
+                    const uint8_t* d_pyr, int scale, int16_t* d_gx, int16_t* d_gy, uint8_t* d_g);
+int launch_patch_points(vis_ctx* ctx, const vis_keypoint* d_good, int n, int w, int h, float* d_patch, float* d_debug, int cap,
+                        int32_t* d_counts);
 #define VIS_HYP_DOUBLES 97                // 96 doubles + 2 int32 per (pair, iteration): see pose.hip HR_*
 int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p1, const float* d_p2, const int32_t* d_npts,
              double* d_n1, double* d_n2, int32_t* d_samples, double* d_models, int32_t* d_counts, int32_t* d_rstate,

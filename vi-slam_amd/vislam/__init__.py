@@ -77,6 +77,7 @@ ABI_SYMBOLS = [
     "vis_recover_pose", "vis_f2f_ransac", "vis_batch_plan", "vis_batch_reset", "vis_batch_run",
     "vis_batch_sync", "vis_batch_get_keypoints", "vis_batch_get_knn", "vis_batch_get_matches",
     "vis_batch_get_pose", "vis_batch_status", "vis_synth_canvas", "vis_synth_frame",
+    "vis_gradient_frame_elems", "vis_gradient_batch", "vis_compute_gradient", "vis_patch_points",
 ]
 
 
@@ -122,6 +123,11 @@ def _load():
     lib.vis_batch_status.argtypes = [vp, ip]
     lib.vis_synth_canvas.argtypes = [vp, ci, C.c_uint64]
     lib.vis_synth_frame.argtypes = [vp, ci, C.c_uint64, ci, ci, ci, vp, ci]
+    lib.vis_gradient_frame_elems.argtypes = [ci, ci]
+    lib.vis_gradient_frame_elems.restype = C.c_size_t
+    lib.vis_gradient_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp]
+    lib.vis_compute_gradient.argtypes = [vp, vp, ci, ci, ci, ci, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    lib.vis_patch_points.argtypes = [vp, vp, ci, ci, C.POINTER(C.c_void_p), ip, C.POINTER(C.c_void_p), ip]
     return lib
 
 
@@ -151,6 +157,10 @@ def _ptr(a):
 
 
 # ---- synthetic stream (host-side utility of the library; integer-only, bit-reproducible) ----------
+def gradient_frame_elems(w, h):
+    return int(lib.vis_gradient_frame_elems(w, h))
+
+
 def synth_canvas(dim=4096, seed=0xE0C00001):
     cv = np.empty((dim, dim), np.uint8)
     rc = lib.vis_synth_canvas(_ptr(cv), dim, C.c_uint64(seed))
@@ -223,6 +233,36 @@ class Context:
         arr = (C.c_void_p * 5)(*[l.ctypes.data for l in levels])
         self._chk(lib.vis_camera_update(self._h, _ptr(img), w, h, img.strides[0], arr), "vis_camera_update")
         return levels
+
+    # -- Camera::computeGradient (src/Camera.cpp:167-184) ------------------------------------------------
+    def compute_gradient(self, img, scale=3):
+        """one host frame -> per level (gx int16, gy int16, gradient u8) of the 5 half-pyramid levels"""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        gx = [np.empty((h >> l, w >> l), np.int16) for l in range(5)]
+        gy = [np.empty((h >> l, w >> l), np.int16) for l in range(5)]
+        g = [np.empty((h >> l, w >> l), np.uint8) for l in range(5)]
+        ax = (C.c_void_p * 5)(*[a.ctypes.data for a in gx])
+        ay = (C.c_void_p * 5)(*[a.ctypes.data for a in gy])
+        ag = (C.c_void_p * 5)(*[a.ctypes.data for a in g])
+        self._chk(lib.vis_compute_gradient(self._h, _ptr(img), w, h, img.strides[0], scale, ax, ay, ag), "vis_compute_gradient")
+        return gx, gy, g
+
+    def gradient_batch(self, d_frames_ptr, w, h, stride, n, d_gray_ptr, d_gx_ptr, d_gy_ptr, d_g_ptr, scale=3):
+        """device pointers in, device buffers out (n * gradient_frame_elems(w, h) elements each); asynchronous"""
+        self._chk(lib.vis_gradient_batch(self._h, C.c_void_p(d_frames_ptr), w, h, stride, n, scale, C.c_void_p(d_gray_ptr),
+                                         C.c_void_p(d_gx_ptr), C.c_void_p(d_gy_ptr), C.c_void_p(d_g_ptr)), "vis_gradient_batch")
+
+    # -- Camera::ObtainPatchesPointsPreviousFrame / ObtainDebugPointsPreviousFrame (src/Camera.cpp:358-445) --
+    def patch_points(self, good, cap=200 * 121):
+        good = np.ascontiguousarray(good, KEYPOINT_DTYPE)
+        patch = [np.zeros((cap, 4), np.float32) for _ in range(5)]
+        debug = [np.zeros((cap, 4), np.float32) for _ in range(5)]
+        ap = (C.c_void_p * 5)(*[a.ctypes.data for a in patch])
+        ad = (C.c_void_p * 5)(*[a.ctypes.data for a in debug])
+        npt = (C.c_int * 5)(); ndb = (C.c_int * 5)()
+        self._chk(lib.vis_patch_points(self._h, _ptr(good), len(good), cap, ap, npt, ad, ndb), "vis_patch_points")
+        return [patch[l][:npt[l]].copy() for l in range(5)], [debug[l][:ndb[l]].copy() for l in range(5)]
 
     # -- CameraGPU::detectAndComputeGPUFeatures ---------------------------------------------------------
     def orb_detect_compute(self, img, slot=0, cap=None):
