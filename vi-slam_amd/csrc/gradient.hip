@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_half4(const uint8_t* __restrict__ src, 
 }
 
 // ---- Camera::computeGradient ---------------------------------------------------------------------------------
-#define GR_ROWS 8
+#define GR_ROWS 16
 static __device__ __forceinline__ int reflect101(int i, int n) {      // one reflection is enough for |overshoot| <= 1, n >= 2
     return n == 1 ? 0 : (i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i));
 }
@@ -68,9 +68,9 @@ static __device__ __forceinline__ int reflect101(int i, int n) {      // one ref
 // pixels x0-1 .. x0+8 of one row as five (u16, u16) pairs, columns reflected at the image border
 static __device__ __forceinline__ void load_row(const uint8_t* __restrict__ row, int x0, int w, bool fast, uint32_t (&U)[5]) {
     if (fast) {                                                      // bytes x0-4 .. x0+11 are inside the row
-        typedef uint32_t __attribute__((aligned(1))) u32u;
-        const uint32_t b0 = *reinterpret_cast<const u32u*>(row + x0 - 4), b1 = *reinterpret_cast<const u32u*>(row + x0);
-        const uint32_t b2 = *reinterpret_cast<const u32u*>(row + x0 + 4), b3 = *reinterpret_cast<const u32u*>(row + x0 + 8);
+        typedef uint32_t v4u1 __attribute__((ext_vector_type(4), aligned(1)));
+        const v4u1 q = *reinterpret_cast<const v4u1*>(row + x0 - 4);  // one (possibly unaligned) 16-byte load
+        const uint32_t b0 = q[0], b1 = q[1], b2 = q[2], b3 = q[3];
         U[0] = __builtin_amdgcn_perm(b1, b0, 0x0c040c03u);           // (x0-1, x0)
         U[1] = __builtin_amdgcn_perm(0u, b1, 0x0c020c01u);           // (x0+1, x0+2)
         U[2] = __builtin_amdgcn_perm(b2, b1, 0x0c040c03u);           // (x0+3, x0+4)
@@ -143,8 +143,10 @@ __global__ __launch_bounds__(256) void k_gradient(GradArgs G, const uint8_t* __r
             if (x0 + 8 <= w) {
                 // rows of odd-width levels are not 16-byte aligned: dword stores (x0 is a multiple of 8, w may be odd)
                 if (((o * 2) & 15) == 0) {
-                    *reinterpret_cast<uint4*>(gx + o) = make_uint4(vx[0], vx[1], vx[2], vx[3]);
-                    *reinterpret_cast<uint4*>(gy + o) = make_uint4(vy[0], vy[1], vy[2], vy[3]);
+                    // write-once streams: non-temporal stores keep them from displacing the source rows in L2
+                    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(v4u{vx[0], vx[1], vx[2], vx[3]}, reinterpret_cast<v4u*>(gx + o));
+                    __builtin_nontemporal_store(v4u{vy[0], vy[1], vy[2], vy[3]}, reinterpret_cast<v4u*>(gy + o));
                 } else if ((o & 1) == 0) {
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
@@ -158,7 +160,10 @@ __global__ __launch_bounds__(256) void k_gradient(GradArgs G, const uint8_t* __r
                     }
                 }
                 const uint32_t g0 = __builtin_amdgcn_perm(vg[1], vg[0], 0x06040200u), g1 = __builtin_amdgcn_perm(vg[3], vg[2], 0x06040200u);
-                if ((o & 7) == 0) *reinterpret_cast<uint2*>(gout + o) = make_uint2(g0, g1);
+                if ((o & 7) == 0) {
+                    typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+                    __builtin_nontemporal_store(v2u{g0, g1}, reinterpret_cast<v2u*>(gout + o));
+                }
                 else {
 #pragma unroll
                     for (int k = 0; k < 4; k++) { gout[o + k] = (uint8_t)(g0 >> (8 * k)); gout[o + 4 + k] = (uint8_t)(g1 >> (8 * k)); }
