@@ -25,19 +25,23 @@ struct DMatch { int queryIdx, trainIdx, imgIdx; float distance;
                 DMatch(int q, int t, float d) : queryIdx(q), trainIdx(t), imgIdx(-1), distance(d) {}
                 bool operator<(const DMatch& m) const { return distance < m.distance; } };
 static_assert(sizeof(KeyPoint) == 28 && sizeof(DMatch) == 16, "layout must match the C ABI");
-enum { CV_8U = 0 };
-// minimal 8-bit single-channel matrix with shared storage (enough for grayImage / descriptors)
+enum { CV_8U = 0, CV_16S = 3, CV_32F = 5 };               // OpenCV depth codes
+// minimal single-channel matrix with shared storage (enough for grayImage / descriptors / gradients / point lists)
 struct Mat {
-    int rows = 0, cols = 0; size_t step = 0; uint8_t* data = nullptr;
+    int rows = 0, cols = 0, depth = CV_8U; size_t step = 0; uint8_t* data = nullptr;
     std::shared_ptr<std::vector<uint8_t>> store;
     Mat() {}
-    Mat(int r, int c, int /*type*/) { create(r, c, CV_8U); }
-    void create(int r, int c, int /*type*/) { rows = r; cols = c; step = (size_t)c; store = std::make_shared<std::vector<uint8_t>>((size_t)r * c); data = store->data(); }
+    Mat(int r, int c, int type) { create(r, c, type); }
+    static size_t esz(int type) { return type == CV_16S ? 2 : (type == CV_32F ? 4 : 1); }
+    size_t elemSize() const { return esz(depth); }
+    void create(int r, int c, int type) { rows = r; cols = c; depth = type; step = (size_t)c * esz(type); store = std::make_shared<std::vector<uint8_t>>((size_t)r * step); data = store->data(); }
     bool empty() const { return rows == 0 || cols == 0; }
     void release() { rows = cols = 0; step = 0; data = nullptr; store.reset(); }
-    Mat clone() const { Mat m; if (!empty()) { m.create(rows, cols, CV_8U); for (int y = 0; y < rows; y++) std::memcpy(m.data + (size_t)y * m.step, data + (size_t)y * step, (size_t)cols); } return m; }
+    Mat clone() const { Mat m; if (!empty()) { m.create(rows, cols, depth); for (int y = 0; y < rows; y++) std::memcpy(m.data + (size_t)y * m.step, data + (size_t)y * step, (size_t)cols * esz(depth)); } return m; }
     void copyTo(Mat& m) const { m = clone(); }
     Mat rowRange(int a, int b) const { Mat m = *this; m.data = data + (size_t)a * step; m.rows = b - a; return m; }
+    template <class T> T& at(int y, int x) { return *reinterpret_cast<T*>(data + (size_t)y * step + (size_t)x * sizeof(T)); }
+    template <class T> const T& at(int y, int x) const { return *reinterpret_cast<const T*>(data + (size_t)y * step + (size_t)x * sizeof(T)); }
 };
 template <class T> using Ptr = std::shared_ptr<T>;
 }  // namespace cv

@@ -23,6 +23,18 @@ int main(int argc, char** argv) {
         Frame* f = visystem.cameraGPU.frameList.back();
         std::printf("FRAME %d kps %d sym %d good %d inliers %d posegood %d\n", j, (int)f->keypoints.size(),
                     visystem.cameraGPU.matcherGPU.nSymMatches, (int)f->prevGoodMatches.size(), visystem.lastInliers, visystem.lastPoseGood);
+        // the step after matching (computeGradient + patch builders): checksums of what addGPUKeyframe stored
+        unsigned long long gsum = 0; long long gxsum = 0;
+        for (int l = 0; l < 5; l++) {
+            const Mat& g = f->gradient[l]; const Mat& gx = f->gradientX[l];
+            for (int y = 0; y < g.rows; y++) for (int x = 0; x < g.cols; x++) { gsum += g.at<uint8_t>(y, x); gxsum += gx.at<int16_t>(y, x) * (long long)(1 + ((x + y) & 3)); }
+        }
+        int npatch = 0, ndebug = 0;
+        if (visystem.cameraGPU.frameList.size() > 1) {
+            Frame* prev = visystem.cameraGPU.frameList[visystem.cameraGPU.frameList.size() - 2];
+            for (int l = 0; l < 5; l++) { npatch += prev->candidatePoints[l].rows; ndebug += prev->candidateDebugPoints[l].rows; }
+        }
+        std::printf("GRAD %d g %llu gx %lld patch %d debug %d\n", j, gsum, gxsum, npatch, ndebug);
     }
     return 0;
 }

@@ -134,6 +134,51 @@ void Camera::Update(Mat _grayImage) {                                           
         if (rc) VisDevice::fail(rc, "Camera::Update");
     }
 }
+void Camera::computeGradient() {                                                  // src/Camera.cpp:167-184
+    const Mat& img = currentFrame->grayImage[0];
+    if ((img.cols & 15) || (img.rows & 15)) return;                               // same restriction as Update's half pyramid
+    int16_t* gx[5]; int16_t* gy[5]; uint8_t* g[5];
+    for (int lvl = 0; lvl < 5; lvl++) {
+        currentFrame->gradientX[lvl].create(img.rows >> lvl, img.cols >> lvl, CV_16S);
+        currentFrame->gradientY[lvl].create(img.rows >> lvl, img.cols >> lvl, CV_16S);
+        currentFrame->gradient[lvl].create(img.rows >> lvl, img.cols >> lvl, CV_8U);
+        gx[lvl] = reinterpret_cast<int16_t*>(currentFrame->gradientX[lvl].data);
+        gy[lvl] = reinterpret_cast<int16_t*>(currentFrame->gradientY[lvl].data);
+        g[lvl] = currentFrame->gradient[lvl].data;
+    }
+    // Scharr(img, g, CV_16S, 1, 0, 3, 0, BORDER_DEFAULT): the "3" is cv::Scharr's scale argument
+    int rc = vis_compute_gradient(VisDevice::get(), img.data, img.cols, img.rows, (int)img.step, 3, gx, gy, g);
+    if (rc) VisDevice::fail(rc, "Camera::computeGradient");
+    currentFrame->obtainedGradients = true;
+}
+static void patch_lists(Frame* last, bool patches, bool debug) {
+    const vector<KeyPoint>& good = last->nextGoodMatches;
+    const int cap = 200 * 121;
+    vector<vector<float> > pb(5, vector<float>((size_t)cap * 4)), db(5, vector<float>((size_t)cap * 4));
+    float* pp[5]; float* dp[5]; int np[5], nd[5];
+    for (int l = 0; l < 5; l++) { pp[l] = pb[l].data(); dp[l] = db[l].data(); }
+    int rc = vis_patch_points(VisDevice::get(), reinterpret_cast<const vis_keypoint*>(good.data()), (int)good.size(), cap, pp, np, dp, nd);
+    if (rc) VisDevice::fail(rc, "Camera::ObtainPatchesPointsPreviousFrame");
+    for (int l = 0; l < 5; l++) {
+        // the reference push_backs 1x4 rows onto candidatePoints[lvl]: an N x 4 CV_32F matrix, appended call after call
+        if (patches) {
+            Mat old = last->candidatePoints[l], m;
+            m.create(old.rows + np[l], 4, CV_32F);
+            if (old.rows) std::memcpy(m.data, old.data, (size_t)old.rows * 16);
+            if (np[l]) std::memcpy(m.data + (size_t)old.rows * 16, pp[l], (size_t)np[l] * 16);
+            last->candidatePoints[l] = m;
+        }
+        if (debug) {
+            Mat old = last->candidateDebugPoints[l], m;
+            m.create(old.rows + nd[l], 4, CV_32F);
+            if (old.rows) std::memcpy(m.data, old.data, (size_t)old.rows * 16);
+            if (nd[l]) std::memcpy(m.data + (size_t)old.rows * 16, dp[l], (size_t)nd[l] * 16);
+            last->candidateDebugPoints[l] = m;
+        }
+    }
+}
+void Camera::ObtainPatchesPointsPreviousFrame() { patch_lists(frameList[frameList.size() - 1], true, false); }   // :358-410
+void Camera::ObtainDebugPointsPreviousFrame() { patch_lists(frameList[frameList.size() - 1], false, true); }     // :413-445
 void Camera::saveFrame() { currentFrame->isKeyFrame = true; frameList.push_back(currentFrame); }   // :188-193
 void Camera::printStatistics() {                                                  // :325-356
     cout << "\nESTADISTICAS\tTdetect: " << elapsed_detect * 1000 << " ms\tTmatch: " << elapsed_computeGoodMatches * 1000
@@ -190,23 +235,31 @@ void CameraGPU::computeGPUGoodMatches() {                                       
     matcherGPU.getGoodMatches(last->nextGoodMatches, currentFrame->prevGoodMatches);
     currentFrame->obtainedGoodMatches = true;
 }
-bool CameraGPU::addGPUKeyframe() {                                                // :138-202 (gradient/patch steps are out of scope)
+bool CameraGPU::addGPUKeyframe() {                                                // :138-202
     clock_t cbegin = clock();
     nPointsDetect = detectAndComputeGPUFeatures();
     clock_t cdetect = clock();
     if ((nPointsDetect > 1) && (frameList.size() != 0)) {
         computeGPUGoodMatches();
         clock_t cgood = clock();
+        computeGradient();
+        clock_t cgradient = clock();
+        ObtainPatchesPointsPreviousFrame();
+        ObtainDebugPointsPreviousFrame();
+        clock_t cpatches = clock();
         saveFrame();
         nBestMatches = (int)matcherGPU.goodMatches.size();
         elapsed_detect = double(cdetect - cbegin) / CLOCKS_PER_SEC;
         elapsed_computeGoodMatches = double(cgood - cdetect) / CLOCKS_PER_SEC;
+        elapsed_computeGradient = double(cgradient - cgood) / CLOCKS_PER_SEC;
+        elapsed_computePatches = double(cpatches - cgradient) / CLOCKS_PER_SEC;
         elapsed_detect_sum += elapsed_detect; elapsed_computeGoodMatches_sum += elapsed_computeGoodMatches;
         nPointsDetect_sum += nPointsDetect; nBestMatches_sum += nBestMatches;
         const double nn = double(frameList.size() - 1);
         elapsed_detect_mean = elapsed_detect_sum / nn; elapsed_computeGoodMatches_mean = elapsed_computeGoodMatches_sum / nn;
         nPointsDetect_mean = nPointsDetect_sum / nn; nBestMatches_mean = nBestMatches_sum / nn;
     } else if ((nPointsDetect > 1) && (frameList.size() == 0)) {
+        computeGradient();
         saveFrame();
         cout << "First Image detected" << "list = " << frameList.size() << endl;
     }

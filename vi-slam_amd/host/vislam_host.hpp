@@ -6,7 +6,7 @@
 //   MatcherGPU         /root/reference/include/MatcherGPU.hpp:14-28
 //   CameraGPU          /root/reference/include/CameraGPU.hpp:15-34
 //   vi::VISystemGPU    /root/reference/include/VISystemGPU.hpp:14-36 (+ EstimatePoseFeaturesRansac of VISystem)
-// Out of scope members (gradients, patches, IMU, ROS, Sophus poses, GUI) are not reproduced.
+// Gradients and the patch point lists are included; IMU, ROS, Sophus poses, GUI are not.
 #ifndef VISLAM_HOST_HPP_
 #define VISLAM_HOST_HPP_
 #include <iostream>
@@ -31,6 +31,8 @@ class Frame {                                            // include/Camera.hpp:3
 public:
     Frame(); ~Frame();
     vector<Mat> grayImage = vector<Mat>(5);
+    vector<Mat> gradientX = vector<Mat>(5), gradientY = vector<Mat>(5), gradient = vector<Mat>(5);   // :47-49 (CV_16S, CV_16S, CV_8U)
+    vector<Mat> candidatePoints = vector<Mat>(5), candidateDebugPoints = vector<Mat>(5);               // :57,59 (N x 4 CV_32F rows)
     vector<KeyPoint> keypoints, prevGoodMatches, nextGoodMatches;
     Mat descriptors;
     int idFrame = 0; double imageTime = 0;
@@ -76,6 +78,9 @@ class Camera {                                           // include/Camera.hpp:7
 public:
     Camera();
     void Update(Mat _grayImage);
+    void computeGradient();                              // src/Camera.cpp:167-184
+    void ObtainPatchesPointsPreviousFrame();             // src/Camera.cpp:358-410
+    void ObtainDebugPointsPreviousFrame();               // src/Camera.cpp:413-445
     void saveFrame();
     void printStatistics();
     vector<Frame*> frameList;
@@ -84,7 +89,7 @@ public:
     int detectorType = 0, matcherType = 0, nPointsDetect = 0, nBestMatches = 0, n_cells = 0;
     vector<int> w_size = vector<int>(5), h_size = vector<int>(5);
     int w_patch = 0, h_patch = 0;
-    double elapsed_detect = 0, elapsed_descriptors = 0, elapsed_computeGoodMatches = 0;
+    double elapsed_detect = 0, elapsed_descriptors = 0, elapsed_computeGoodMatches = 0, elapsed_computeGradient = 0, elapsed_computePatches = 0;
     double elapsed_detect_mean = 0, elapsed_computeGoodMatches_mean = 0, nPointsDetect_mean = 0, nBestMatches_mean = 0;
     double elapsed_detect_sum = 0, elapsed_computeGoodMatches_sum = 0, nPointsDetect_sum = 0, nBestMatches_sum = 0;
     int num_images = 0;
