@@ -184,6 +184,35 @@ def main():
         except Exception as e:                            # never let the side measurement break the contract line
             aux = {"gradient_batch": {"error": str(e)}}
 
+    # ---- SURVEY 8(f) N3 (outside the timed region, never `value`): the same pipeline fed from pinned HOST memory through
+    # the double-buffered feeder -- the PCIe-inclusive rate
+    if rank == 0 and aux is not None:
+        try:
+            feed = vislam.Feeder(ctx, W, H, B)
+            for k in range(2):
+                feed.host_buffer(k)[:] = frames[(k % R) * B:(k % R + 1) * B]
+            def fed_step(i):
+                k = i & 1
+                feed.host_buffer(k)                       # waits until the previous copy out of this buffer is done
+                d = feed.submit(k, B)
+                ctx.batch_run(d, B, a.stages)
+                feed.release(k)
+            ctx.batch_reset()
+            for i in range(4):
+                fed_step(i)
+            ctx.batch_sync(); torch.cuda.synchronize()
+            tf = time.perf_counter()
+            KF = 20
+            for i in range(KF):
+                fed_step(i)
+            ctx.batch_sync(); torch.cuda.synchronize()
+            tf = (time.perf_counter() - tf) / KF
+            aux["host_fed_pipeline"] = {"what": "same step, frames copied from pinned host memory by the double-buffered feeder (H2D overlapped with compute)",
+                                        "frames_per_s": B / tf, "ms_per_step": tf * 1e3, "h2d_GBps": B * W * H / tf / 1e9}
+            feed.close()
+        except Exception as e:
+            aux["host_fed_pipeline"] = {"error": str(e)}
+
     if rank == 0:
         px = level_pixels(ctx)
         alg = algorithmic_bytes(px, NFEAT)

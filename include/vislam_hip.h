@@ -202,6 +202,28 @@ int  vis_compute_gradient(vis_ctx* ctx, const uint8_t* img, int w, int h, int st
 int  vis_patch_points(vis_ctx* ctx, const vis_keypoint* good, int n, int cap,
                       float* const patch[5], int n_patch[5], float* const debug[5], int n_debug[5]);
 
+/* ---- frame ingest (src/ImageReader.cpp) ------------------------------------- */
+/* ImageReader::searchImages (src/ImageReader.cpp:49-74): the .pgm / .raw files of `dir` in byte order, names
+ * separated by '\n' in names_out (cap_bytes); *count = number of files.  names_out may be NULL to only count.
+ * ("." and ".." are skipped by name; the reference erases the first two sorted entries.) */
+int  vis_image_list(const char* dir, char* names_out, int cap_bytes, int* count);
+/* ImageReader::getImageTime (:41-47): atol of the file name's stem (EuRoC names its images <timestamp ns>.ext) */
+long vis_image_time(const char* file_name);
+/* stand-in for imread(..., CV_LOAD_IMAGE_GRAYSCALE) (:80-82) on the formats this build reads: binary PGM
+ * (P5, maxval <= 255, '#' comments allowed) and headerless raw (w*h bytes) */
+int  vis_pgm_info(const char* path, int* w, int* h);
+int  vis_image_read(const char* path, uint8_t* out, int out_stride, int w, int h);
+/* Pinned-host double-buffered H2D feeder for vis_batch_run: fill vis_feeder_host_buffer(f, k) (batch x h x w,
+ * dense; blocks while an earlier copy out of it is in flight), vis_feeder_submit(f, k, n, &d) enqueues the copy on a
+ * copy stream and orders the context's detect stream after it, run vis_batch_run(ctx, d, n, ...), then
+ * vis_feeder_release(f, k).  Alternating k = 0, 1 overlaps the copy of batch i+1 with the processing of batch i. */
+typedef struct vis_feeder vis_feeder;
+int  vis_feeder_create(vis_ctx* ctx, int w, int h, int batch, vis_feeder** out);
+void vis_feeder_destroy(vis_feeder* f);
+uint8_t* vis_feeder_host_buffer(vis_feeder* f, int which);
+int  vis_feeder_submit(vis_feeder* f, int which, int n, const uint8_t** d_frames);
+int  vis_feeder_release(vis_feeder* f, int which);
+
 /* ---- batched stream API (throughput path) --------------------------------- */
 /* Plan device buffers for batches of up to `max_frames` w x h frames.  Frames in a
  * batch are consecutive frames of ONE camera stream: frame i is matched against frame

@@ -1,0 +1,104 @@
+"""frame ingest.  CPU part (no GPU needed): directory listing / timestamp stems as
+/root/reference/src/ImageReader.cpp:22-78 does them, PGM (P5) and raw decode in place of cv::imread.
+GPU part: the pinned double-buffered feeder feeds the pipeline through files -> reader -> pinned buffer -> device and
+the result is identical to running on frames that were resident all along."""
+import os
+
+import numpy as np
+import pytest
+
+
+def _write_pgm(path, img, comment=None, maxval=255):
+    with open(path, "wb") as f:
+        f.write(b"P5\n")
+        if comment:
+            f.write(b"# " + comment.encode() + b"\n")
+        f.write(f"{img.shape[1]} {img.shape[0]}\n{maxval}\n".encode())
+        f.write(img.tobytes())
+
+
+def test_listing_order_and_timestamps(vislam, tmp_path):
+    rng = np.random.default_rng(3)
+    names = ["1403636579763555584.pgm", "1403636579813555456.pgm", "1403636579713555456.pgm", "0000000000000000100.raw"]
+    for n in names:
+        (tmp_path / n).write_bytes(rng.integers(0, 256, 64, dtype=np.uint8).tobytes())
+    (tmp_path / "notes.txt").write_text("not an image")
+    (tmp_path / "sub.pgm").mkdir()                       # a directory that looks like an image is not listed
+    got = vislam.image_list(str(tmp_path))
+    assert got == sorted(names)                          # byte order, as std::sort on the names
+    # EuRoC stems are nanosecond timestamps: getImageTime = atol(stem); computeTimeStep = difference of the first two
+    assert vislam.image_time(got[1]) == 1403636579713555456
+    assert vislam.image_time("/data/cam0/" + got[2]) == 1403636579763555584
+    assert vislam.image_time(got[2]) - vislam.image_time(got[1]) == 50000128
+    assert vislam.image_time("frame.pgm") == 0           # atol of a non-numeric stem
+    with pytest.raises(vislam.VisError):
+        vislam.image_list(str(tmp_path / "missing"))
+
+
+def test_pgm_and_raw_decode(vislam, tmp_path):
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (48, 80), dtype=np.uint8)
+    p = str(tmp_path / "a.pgm")
+    _write_pgm(p, img, comment="EuRoC cam0 frame")
+    assert (vislam.image_read(p) == img).all()
+    # whitespace variants of the header and a pixel byte that looks like whitespace right after it
+    img2 = img.copy(); img2[0, 0] = 10                   # '\n' as first pixel must not be eaten by the header parser
+    with open(str(tmp_path / "b.pgm"), "wb") as f:
+        f.write(b"P5 80\t48 # size\n255\n" + img2.tobytes())
+    assert (vislam.image_read(str(tmp_path / "b.pgm")) == img2).all()
+    # raw: headerless
+    (tmp_path / "c.raw").write_bytes(img.tobytes())
+    assert (vislam.image_read(str(tmp_path / "c.raw"), 80, 48) == img).all()
+    # errors: truncated payload, 16-bit PGM, ASCII PGM, wrong size, missing file
+    with open(str(tmp_path / "t.pgm"), "wb") as f:
+        f.write(b"P5\n80 48\n255\n" + img.tobytes()[:-5])
+    with pytest.raises(vislam.VisError):
+        vislam.image_read(str(tmp_path / "t.pgm"))
+    _write_pgm(str(tmp_path / "w.pgm"), img, maxval=65535)
+    with pytest.raises(vislam.VisError):
+        vislam.image_read(str(tmp_path / "w.pgm"))
+    (tmp_path / "p2.pgm").write_bytes(b"P2\n2 2\n255\n1 2 3 4\n")
+    with pytest.raises(vislam.VisError):
+        vislam.image_read(str(tmp_path / "p2.pgm"))
+    with pytest.raises(vislam.VisError):
+        vislam.image_read(p, 64, 48)
+    with pytest.raises(vislam.VisError):
+        vislam.image_read(str(tmp_path / "nope.pgm"))
+
+
+@pytest.mark.gpu
+def test_feeder_round_trip_and_pipeline_equality(vislam, ctx, canvas, tmp_path):
+    import torch
+    W, H, B = 752, 480, 6
+    frames = np.stack([vislam.synth_frame(canvas, t, W, H) for t in range(2 * B)])
+    # frames go through files -> reader -> pinned buffer -> device
+    for t in range(2 * B):
+        _write_pgm(str(tmp_path / f"{1403636579763555584 + 50000000 * t}.pgm"), frames[t])
+    names = vislam.image_list(str(tmp_path))
+    assert len(names) == 2 * B
+    p = vislam.default_params(); p.fy = p.fx
+    ctx.set_params(p)
+    ctx.batch_plan(W, H, W, B)
+    feed = vislam.Feeder(ctx, W, H, B)
+    got = []
+    for k in range(2):
+        hb = feed.host_buffer(k)
+        for i in range(B):
+            hb[i] = vislam.image_read(os.path.join(str(tmp_path), names[k * B + i]))
+        d = feed.submit(k, B)
+        ctx.batch_run(d, B)
+        feed.release(k)
+        ctx.batch_sync()
+        got.append([ctx.batch_keypoints(i) for i in range(B)] + [ctx.batch_pose(i) for i in range(B)])
+    feed.close()
+    # same stream with resident frames (fresh plan state)
+    ctx.batch_reset()
+    d_all = torch.from_numpy(frames).cuda()
+    for k in range(2):
+        ctx.batch_run(d_all.data_ptr() + k * B * H * W, B)
+        ctx.batch_sync()
+        for i in range(B):
+            k1, d1 = ctx.batch_keypoints(i)
+            k0, d0 = got[k][i]
+            assert (k1 == k0).all() and (d1 == d0).all(), (k, i)
+            assert str(ctx.batch_pose(i)) == str(got[k][B + i]), (k, i)

@@ -1,0 +1,191 @@
+// ingest.hip -- frame ingest for the throughput path: image directory listing and timestamp
+// stems as /root/reference/src/ImageReader.cpp:22-78 does them, a PGM (P5) / raw 8-bit reader in place of
+// cv::imread(..., CV_LOAD_IMAGE_GRAYSCALE) (:80-82), and a pinned-host double-buffered H2D feeder so that batch k+1
+// is copied while batch k is processed.  No kernels here: host code + HIP runtime copies.
+#include "vis_internal.h"
+#include <dirent.h>
+#include <sys/stat.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+// ---- directory listing (ImageReader::searchImages, :49-74) -------------------------------------------------------
+// The reference sorts ALL directory entries and drops the first two, assuming they are "." and ".."; here the two
+// entries are dropped by name and only regular files whose extension is .pgm / .raw are kept, still in byte order.
+extern "C" int vis_image_list(const char* dir, char* names_out, int cap_bytes, int* count) {
+    if (!dir || !count || cap_bytes < 0 || (cap_bytes > 0 && !names_out)) return VIS_E_INVALID;
+    DIR* d = opendir(dir);
+    if (!d) return VIS_E_STATE;
+    std::vector<std::string> names;
+    std::string base(dir);
+    if (!base.empty() && base.back() != '/') base += '/';
+    while (struct dirent* ent = readdir(d)) {
+        const std::string n(ent->d_name);
+        if (n == "." || n == "..") continue;
+        const size_t dot = n.rfind('.');
+        if (dot == std::string::npos) continue;
+        std::string ext = n.substr(dot);
+        for (auto& c : ext) c = (char)tolower((unsigned char)c);
+        if (ext != ".pgm" && ext != ".raw") continue;
+        struct stat st;
+        if (stat((base + n).c_str(), &st) != 0 || !S_ISREG(st.st_mode)) continue;
+        names.push_back(n);
+    }
+    closedir(d);
+    std::sort(names.begin(), names.end());
+    *count = (int)names.size();
+    size_t need = 0;
+    for (auto& n : names) need += n.size() + 1;
+    if (need > (size_t)cap_bytes) return names_out ? VIS_E_CAPACITY : VIS_OK;
+    char* o = names_out;
+    for (auto& n : names) { std::memcpy(o, n.c_str(), n.size()); o += n.size(); *o++ = '\n'; }
+    if (need < (size_t)cap_bytes) *o = 0;
+    return VIS_OK;
+}
+
+// ImageReader::getImageName + getImageTime (:22-47): strip the directory, cut at the FIRST '.', atol
+extern "C" long vis_image_time(const char* file_name) {
+    if (!file_name) return 0;
+    const char* s = std::strrchr(file_name, '/');
+    s = s ? s + 1 : file_name;
+    std::string stem(s);
+    const size_t dot = stem.find('.');
+    if (dot != std::string::npos && dot != 0) stem = stem.substr(0, dot);
+    return std::atol(stem.c_str());
+}
+
+// ---- PGM (P5, maxval <= 255) -------------------------------------------------------------------------------------
+static bool pgm_token(FILE* f, int* v) {               // next unsigned integer of the header, '#' comments skipped
+    int c;
+    for (;;) {
+        c = fgetc(f);
+        if (c == '#') { while (c != '\n' && c != EOF) c = fgetc(f); continue; }
+        if (c == EOF) return false;
+        if (c == ' ' || c == '\t' || c == '\n' || c == '\r') continue;
+        break;
+    }
+    if (c < '0' || c > '9') return false;
+    long x = 0;
+    while (c >= '0' && c <= '9') { x = x * 10 + (c - '0'); if (x > 1 << 24) return false; c = fgetc(f); }
+    *v = (int)x;                                       // the single whitespace after the token has been consumed
+    return c == ' ' || c == '\t' || c == '\n' || c == '\r';
+}
+
+static int pgm_open(const char* path, FILE** out, int* w, int* h) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return VIS_E_STATE;
+    int maxv = 0;
+    if (fgetc(f) != 'P' || fgetc(f) != '5' || !pgm_token(f, w) || !pgm_token(f, h) || !pgm_token(f, &maxv) ||
+        *w < 1 || *h < 1 || maxv < 1 || maxv > 255) { std::fclose(f); return VIS_E_INVALID; }
+    *out = f;
+    return VIS_OK;
+}
+
+extern "C" int vis_pgm_info(const char* path, int* w, int* h) {
+    if (!path || !w || !h) return VIS_E_INVALID;
+    FILE* f = nullptr;
+    const int rc = pgm_open(path, &f, w, h);
+    if (f) std::fclose(f);
+    return rc;
+}
+
+// reads a w x h image into out (row stride out_stride); a .raw file is w*h bytes without header
+extern "C" int vis_image_read(const char* path, uint8_t* out, int out_stride, int w, int h) {
+    if (!path || !out || w < 1 || h < 1 || out_stride < w) return VIS_E_INVALID;
+    const char* dot = std::strrchr(path, '.');
+    const bool raw = dot && (std::strcmp(dot, ".raw") == 0 || std::strcmp(dot, ".RAW") == 0);
+    FILE* f = nullptr;
+    if (raw) { f = std::fopen(path, "rb"); if (!f) return VIS_E_STATE; }
+    else {
+        int fw = 0, fh = 0;
+        const int rc = pgm_open(path, &f, &fw, &fh);
+        if (rc) return rc;
+        if (fw != w || fh != h) { std::fclose(f); return VIS_E_INVALID; }
+    }
+    for (int y = 0; y < h; y++)
+        if (std::fread(out + (size_t)y * out_stride, 1, (size_t)w, f) != (size_t)w) { std::fclose(f); return VIS_E_INVALID; }   // truncated
+    std::fclose(f);
+    return VIS_OK;
+}
+
+// ---- pinned double-buffered H2D feeder -----------------------------------------------------------------------------
+struct vis_feeder {
+    vis_ctx* ctx; int w, h, batch; size_t frame_bytes;
+    uint8_t* h_buf[2]; uint8_t* d_buf[2];
+    hipStream_t copy_stream; hipEvent_t copied[2]; hipEvent_t consumed[2]; bool busy[2];
+};
+
+extern "C" int vis_feeder_create(vis_ctx* ctx, int w, int h, int batch, vis_feeder** out) {
+    if (!ctx || !out || w < 16 || h < 16 || (w & 3) || batch < 1) return VIS_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    vis_feeder* f = new vis_feeder();
+    f->ctx = ctx; f->w = w; f->h = h; f->batch = batch; f->frame_bytes = (size_t)w * h;
+    for (int k = 0; k < 2; k++) { f->h_buf[k] = nullptr; f->d_buf[k] = nullptr; f->copied[k] = nullptr; f->consumed[k] = nullptr; f->busy[k] = false; }
+    f->copy_stream = nullptr;
+    bool ok = hipStreamCreateWithFlags(&f->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < 2 && ok; k++) {
+        ok = ok && hipHostMalloc((void**)&f->h_buf[k], f->frame_bytes * batch, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipMalloc((void**)&f->d_buf[k], f->frame_bytes * batch) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&f->copied[k], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&f->consumed[k], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) {
+        ctx->err = "vis_feeder_create: allocation failed";
+        for (int k = 0; k < 2; k++) {
+            if (f->h_buf[k]) (void)hipHostFree(f->h_buf[k]);
+            if (f->d_buf[k]) (void)hipFree(f->d_buf[k]);
+            if (f->copied[k]) (void)hipEventDestroy(f->copied[k]);
+            if (f->consumed[k]) (void)hipEventDestroy(f->consumed[k]);
+        }
+        if (f->copy_stream) (void)hipStreamDestroy(f->copy_stream);
+        delete f;
+        return VIS_E_NOMEM;
+    }
+    *out = f;
+    return VIS_OK;
+}
+
+extern "C" void vis_feeder_destroy(vis_feeder* f) {
+    if (!f) return;
+    (void)hipSetDevice(f->ctx->device);
+    (void)hipStreamSynchronize(f->copy_stream);
+    for (int k = 0; k < 2; k++) {
+        (void)hipHostFree(f->h_buf[k]); (void)hipFree(f->d_buf[k]);
+        (void)hipEventDestroy(f->copied[k]); (void)hipEventDestroy(f->consumed[k]);
+    }
+    (void)hipStreamDestroy(f->copy_stream);
+    delete f;
+}
+
+// the pinned staging buffer the caller's reader fills (batch x h x w, dense).  Blocks until the previous copy out of
+// this buffer has finished, so the buffer can be overwritten.
+extern "C" uint8_t* vis_feeder_host_buffer(vis_feeder* f, int which) {
+    if (!f || which < 0 || which > 1) return nullptr;
+    if (f->busy[which]) (void)hipEventSynchronize(f->copied[which]);
+    return f->h_buf[which];
+}
+
+// enqueue the H2D copy of the first n frames of buffer `which` and make the context's detect stream wait for it:
+// a following vis_batch_run(ctx, *d_frames, n, ...) is ordered after the copy; the copy of the OTHER buffer overlaps
+// the processing of this one.  The device buffer is reused only after the work queued on it so far has finished.
+extern "C" int vis_feeder_submit(vis_feeder* f, int which, int n, const uint8_t** d_frames) {
+    if (!f || which < 0 || which > 1 || n < 1 || n > f->batch || !d_frames) return VIS_E_INVALID;
+    vis_ctx* ctx = f->ctx;
+    (void)hipSetDevice(ctx->device);
+    if (f->busy[which]) HIPCHK(ctx, hipStreamWaitEvent(f->copy_stream, f->consumed[which], 0));    // detect of the batch that used d_buf[which]
+    HIPCHK(ctx, hipMemcpyAsync(f->d_buf[which], f->h_buf[which], f->frame_bytes * n, hipMemcpyHostToDevice, f->copy_stream));
+    HIPCHK(ctx, hipEventRecord(f->copied[which], f->copy_stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, f->copied[which], 0));
+    f->busy[which] = true;
+    *d_frames = f->d_buf[which];
+    return VIS_OK;
+}
+
+// call after the vis_batch_run that consumes buffer `which`: marks the point on the detect stream after which the
+// device buffer may be overwritten by the next copy into it
+extern "C" int vis_feeder_release(vis_feeder* f, int which) {
+    if (!f || which < 0 || which > 1) return VIS_E_INVALID;
+    HIPCHK(f->ctx, hipEventRecord(f->consumed[which], f->ctx->stream));
+    return VIS_OK;
+}

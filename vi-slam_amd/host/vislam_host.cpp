@@ -266,6 +266,45 @@ bool CameraGPU::addGPUKeyframe() {                                              
     return currentFrame->isKeyFrame;                      // SPEC: the reference function has no return statement
 }
 
+// ---------------------------------------------------------------- ImageReader (src/ImageReader.cpp)
+ImageReader::ImageReader() { setPath(""); TimeStep = 0.0; }
+ImageReader::ImageReader(string _directory) { setPath(_directory); searchImages(); computeTimeStep(); }   // :9-14
+void ImageReader::setPath(string _directory) { path = _directory; if (!path.empty() && path.back() != '/') path += '/'; }
+void ImageReader::setRawSize(int w, int h) { raw_w = w; raw_h = h; }
+string ImageReader::getImageName(int index) {                                     // :22-39: file name up to the first '.'
+    string n = file_names[(size_t)index];
+    const size_t slash = n.rfind('/');
+    if (slash != string::npos) n = n.substr(slash + 1);
+    const size_t dot = n.find('.');
+    return (dot != string::npos && dot != 0) ? n.substr(0, dot) : n;
+}
+long int ImageReader::getImageTime(int index) { return vis_image_time(file_names[(size_t)index].c_str()); }   // :41-47
+void ImageReader::searchImages() {                                                // :49-74
+    cout << "Searching images files in directory ... ";
+    int count = 0;
+    int rc = vis_image_list(path.c_str(), nullptr, 0, &count);
+    if (rc) { cout << "Could not open directory of images: " << path << endl << "Exiting..." << endl; exit(0); }
+    vector<char> buf((size_t)count * 300 + 1);
+    rc = vis_image_list(path.c_str(), buf.data(), (int)buf.size(), &count);
+    if (rc) VisDevice::fail(rc, "ImageReader::searchImages");
+    file_names.clear();
+    for (char* s = buf.data(); *s;) { char* e = std::strchr(s, '\n'); if (!e) break; file_names.push_back(path + string(s, e)); s = e + 1; }
+    if (file_names.size() < 15) { cout << "\nInsufficient number of images found. Please use a larger dataset" << endl << "Exiting..." << endl; exit(0); }
+    cout << file_names.size() << " found" << endl;
+}
+Mat ImageReader::getImage(int index) {                                            // :80-82
+    const string& f = file_names[(size_t)index];
+    int w = raw_w, h = raw_h;
+    const bool raw = f.size() > 4 && f.compare(f.size() - 4, 4, ".raw") == 0;
+    if (!raw && vis_pgm_info(f.c_str(), &w, &h) != 0) return Mat();               // imread returns an empty Mat on failure
+    if (w < 1 || h < 1) return Mat();
+    Mat m(h, w, CV_8U);
+    if (vis_image_read(f.c_str(), m.data, (int)m.step, w, h) != 0) return Mat();
+    return m;
+}
+size_t ImageReader::getSize() { return file_names.size(); }
+void ImageReader::computeTimeStep() { TimeStep = (double)getImageTime(1) - (double)getImageTime(0); }   // :107-112
+
 // ---------------------------------------------------------------- vi::VISystemGPU (src/VISystemGPU.cpp, src/VISystem.cpp)
 namespace vi {
 VISystemGPU::VISystemGPU() {}

@@ -112,6 +112,25 @@ private:
     int nextSlot = 0;
 };
 
+class ImageReader {                                      // include/ImageReader.hpp:15-37 over vis_image_list / vis_image_read
+public:
+    ImageReader();
+    ImageReader(string _directory);
+    void setPath(string _directory);
+    void setRawSize(int w, int h);                       // needed for headerless .raw files only
+    string getImageName(int index);
+    long int getImageTime(int index);
+    void searchImages();
+    Mat getImage(int index);                             // imread(.., CV_LOAD_IMAGE_GRAYSCALE) for P5 PGM / raw
+    size_t getSize();
+    void computeTimeStep();
+    double TimeStep = 0.0;
+private:
+    string path;
+    vector<string> file_names;
+    int raw_w = 0, raw_h = 0;
+};
+
 namespace vi {
 class VISystemGPU {                                      // include/VISystemGPU.hpp:14-36 (hot path only)
 public:

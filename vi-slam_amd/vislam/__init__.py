@@ -78,6 +78,8 @@ ABI_SYMBOLS = [
     "vis_batch_sync", "vis_batch_get_keypoints", "vis_batch_get_knn", "vis_batch_get_matches",
     "vis_batch_get_pose", "vis_batch_status", "vis_synth_canvas", "vis_synth_frame",
     "vis_gradient_frame_elems", "vis_gradient_batch", "vis_compute_gradient", "vis_patch_points",
+    "vis_image_list", "vis_image_time", "vis_pgm_info", "vis_image_read",
+    "vis_feeder_create", "vis_feeder_destroy", "vis_feeder_host_buffer", "vis_feeder_submit", "vis_feeder_release",
 ]
 
 
@@ -128,6 +130,18 @@ def _load():
     lib.vis_gradient_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp]
     lib.vis_compute_gradient.argtypes = [vp, vp, ci, ci, ci, ci, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     lib.vis_patch_points.argtypes = [vp, vp, ci, ci, C.POINTER(C.c_void_p), ip, C.POINTER(C.c_void_p), ip]
+    lib.vis_image_list.argtypes = [C.c_char_p, vp, ci, ip]
+    lib.vis_image_time.argtypes = [C.c_char_p]
+    lib.vis_image_time.restype = C.c_long
+    lib.vis_pgm_info.argtypes = [C.c_char_p, ip, ip]
+    lib.vis_image_read.argtypes = [C.c_char_p, vp, ci, ci, ci]
+    lib.vis_feeder_create.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_void_p)]
+    lib.vis_feeder_destroy.argtypes = [vp]
+    lib.vis_feeder_destroy.restype = None
+    lib.vis_feeder_host_buffer.argtypes = [vp, ci]
+    lib.vis_feeder_host_buffer.restype = C.c_void_p
+    lib.vis_feeder_submit.argtypes = [vp, ci, ci, C.POINTER(C.c_void_p)]
+    lib.vis_feeder_release.argtypes = [vp, ci]
     return lib
 
 
@@ -159,6 +173,64 @@ def _ptr(a):
 # ---- synthetic stream (host-side utility of the library; integer-only, bit-reproducible) ----------
 def gradient_frame_elems(w, h):
     return int(lib.vis_gradient_frame_elems(w, h))
+
+
+# -- ImageReader (src/ImageReader.cpp): directory listing, timestamp stems, PGM / raw decode; no GPU involved --------
+def image_list(directory):
+    n = C.c_int(0)
+    rc = lib.vis_image_list(directory.encode(), None, 0, C.byref(n))
+    if rc != 0:
+        raise VisError(rc, "vis_image_list")
+    buf = C.create_string_buffer(max(1, n.value * 300))
+    rc = lib.vis_image_list(directory.encode(), buf, len(buf), C.byref(n))
+    if rc != 0:
+        raise VisError(rc, "vis_image_list")
+    return [x for x in buf.value.decode().split("\n") if x]
+
+
+def image_time(name):
+    return int(lib.vis_image_time(name.encode()))
+
+
+def image_read(path, w=None, h=None):
+    if w is None:
+        cw, ch = C.c_int(0), C.c_int(0)
+        rc = lib.vis_pgm_info(path.encode(), C.byref(cw), C.byref(ch))
+        if rc != 0:
+            raise VisError(rc, "vis_pgm_info")
+        w, h = cw.value, ch.value
+    out = np.empty((h, w), np.uint8)
+    rc = lib.vis_image_read(path.encode(), _ptr(out), w, w, h)
+    if rc != 0:
+        raise VisError(rc, "vis_image_read")
+    return out
+
+
+class Feeder:
+    """pinned-host double-buffered H2D feeder (vis_feeder_*)"""
+
+    def __init__(self, ctx, w, h, batch):
+        self.ctx, self.w, self.h, self.batch = ctx, w, h, batch
+        self._f = C.c_void_p()
+        ctx._chk(lib.vis_feeder_create(ctx._h, w, h, batch, C.byref(self._f)), "vis_feeder_create")
+
+    def host_buffer(self, which):
+        p = lib.vis_feeder_host_buffer(self._f, which)
+        arr = (C.c_uint8 * (self.batch * self.h * self.w)).from_address(p)
+        return np.frombuffer(arr, np.uint8).reshape(self.batch, self.h, self.w)
+
+    def submit(self, which, n):
+        d = C.c_void_p()
+        self.ctx._chk(lib.vis_feeder_submit(self._f, which, n, C.byref(d)), "vis_feeder_submit")
+        return d.value
+
+    def release(self, which):
+        self.ctx._chk(lib.vis_feeder_release(self._f, which), "vis_feeder_release")
+
+    def close(self):
+        if self._f:
+            lib.vis_feeder_destroy(self._f)
+            self._f = C.c_void_p()
 
 
 def synth_canvas(dim=4096, seed=0xE0C00001):
