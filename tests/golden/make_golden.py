@@ -56,6 +56,20 @@ def main():
     np.savez_compressed(os.path.join(HERE, "pose_80.npz"), x1=x1, x2=x2, R_true=R, t_true=t, E=E, mask=mask, ninl=ninl, iters=iters,
                         R=Rr, t=tr, ngood=ng, f2f_idx=idx, f2f_rot=R.T.astype(np.float32), f2f_t=ft, f2f_count=fc,
                         samples49=orc.ransac_samples(0xFFFFFFFFFFFFFFFF, 49, 20))
+    # Camera::computeGradient (Scharr scale 3) on the 5 half-pyramid levels of a 160x112 crop + the patch point lists of
+    # a hand-made keypoint set
+    crop = np.ascontiguousarray(f0[:112, :])
+    gxs, gys, gs = [], [], []
+    for lv in orc.half_pyramid(crop):
+        ox, oy, og = orc.scharr_gradient(lv, 3)
+        gxs.append(ox.ravel()); gys.append(oy.ravel()); gs.append(og.ravel())
+    kp = np.zeros(6, vislam.KEYPOINT_DTYPE)
+    kp["x"] = [80.0, 3.25, 158.5, 41.75, 0.0, 120.0]
+    kp["y"] = [56.0, 2.5, 110.0, 77.125, 0.0, 9.5]
+    pts = [orc.patch_points(kp, 160, 112, l) for l in range(5)]
+    dbg = [orc.debug_points(kp, l) for l in range(5)]
+    np.savez_compressed(os.path.join(HERE, "gradient_160x112.npz"), img=crop, gx=np.concatenate(gxs), gy=np.concatenate(gys), g=np.concatenate(gs),
+                        kp=kp, patch=np.concatenate(pts), patch_counts=np.array([len(x) for x in pts]), debug=np.concatenate(dbg))
     print("golden fixtures written:", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
 
 
