@@ -483,14 +483,25 @@ __global__ __launch_bounds__(256) void k_select(DetLevels D, const int32_t* __re
         atomicAdd(&lhist[cand[(size_t)t * TILE_CAND_CAP + (j - tpre[t])] >> 24], 1);
     }
     __syncthreads();
-    if (tid == 0) {
+    {
+        // KeyPointsFilter::retainBest(2*quota) on the FAST score: cut = largest score s with #(score >= s) >= n.
+        // Suffix sums of the 256 bins by a Hillis-Steele scan (8 steps) instead of one thread walking the bins.
         const int n = 2 * A.quota;
-        int cut = 0;
-        if (C > n) {                                  // KeyPointsFilter::retainBest(2*quota) on FAST score
-            cut = 256;
-            if (n > 0) { int acc = 0; for (int sidx = 255; sidx >= 0; sidx--) { acc += lhist[sidx]; if (acc >= n) { cut = sidx; break; } } }
+        int* suf = lhist + 256 + A.ntiles + 2;                     // 256 entries behind the tile prefix
+        int v = lhist[tid];
+        suf[tid] = v;
+        __syncthreads();
+#pragma unroll
+        for (int o = 1; o < 256; o <<= 1) {
+            const int u = tid + o < 256 ? suf[tid + o] : 0;
+            __syncthreads();
+            v += u; suf[tid] = v;
+            __syncthreads();
         }
-        s_cut = cut;
+        if (tid == 0) s_cut = C > n ? (n > 0 ? 0 : 256) : 0;       // defaults: everything kept (C <= n) / nothing (n == 0)
+        __syncthreads();
+        // v = number of candidates with score >= tid; the cut is the unique bin where the count crosses n from above
+        if (C > n && n > 0 && v >= n && (tid == 255 || suf[tid + 1] < n)) s_cut = tid;
     }
     __syncthreads();
     const int cut = s_cut;
@@ -508,6 +519,7 @@ __global__ __launch_bounds__(256) void k_select(DetLevels D, const int32_t* __re
     if (S > A.surv_cap) { S = A.surv_cap; if (tid == 0) atomicOr(flags, 2); }
     int P2 = 2; while (P2 < S) P2 <<= 1;
     const uint8_t* img = A.img + (size_t)f * A.frame_bytes;
+#pragma unroll 2
     for (int i = tid; i < P2; i += 256) {
         uint64_t key = ~0ull;
         if (i < S) {
@@ -890,7 +902,7 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[2], st);
     int max_surv = 0; for (int l = 0; l < L; l++) max_surv = std::max(max_surv, pl->lv[l].surv_cap);
     int max_nt = 0; for (int l = 0; l < L; l++) max_nt = std::max(max_nt, pl->lv[l].tiles_x * pl->lv[l].tiles_y);
-    const size_t sel_lds = (size_t)max_surv * 8 + 16 + 1024 + ((size_t)max_nt + 1) * 4;
+    const size_t sel_lds = (size_t)max_surv * 8 + 16 + 1024 + ((size_t)max_nt + 2) * 4 + 1024;   // keys | flags | hist | tile prefix | suffix sums
     if (sel_lds > 65536) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (160 KiB per CU on gfx950)
         HIPCHK(ctx, hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
     }
