@@ -12,7 +12,7 @@ out_dir, B = sys.argv[1], int(sys.argv[2])
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].split("(")[0]
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]      # "void k_resize<true>(..." -> "k_resize"
         acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summary = {}
 for k, cs in acc.items():
@@ -32,7 +32,8 @@ res = {"batch_frames": B, "raw": summary,
                                "WRITE_SIZE (KB) is exact; the factors here are measured on a 256 MiB copy in the same run"}}
 fb = res["calibration"]["fetch_bytes_per_unit"] or 2048.0
 wb = res["calibration"]["write_bytes_per_unit"] or 1024.0
-for k in ("k_fast", "k_resize", "k_describe", "k_knn2", "k_select", "k_filter", "k_ransac_hyp"):
+for k in ("k_fast", "k_resize", "k_describe", "k_knn2", "k_knn_mfma", "k_expand", "k_select", "k_filter", "k_ransac_hyp", "k_hyp_roots", "k_hyp_score",
+          "k_pose_final", "k_gradient", "k_half4"):
     if k in summary and "FETCH_SIZE" in summary[k]:
         f = summary[k]["FETCH_SIZE"]["mean"]
         w = summary[k].get("WRITE_SIZE", {}).get("mean", 0.0)

@@ -17,5 +17,8 @@ g = torch.empty(B * fe, dtype=torch.uint8, device="cuda")
 for _ in range(int(os.environ.get("VIS_PROFILE_STEPS", "4"))):
     ctx.gradient_batch(d.data_ptr(), W, H, W, B, gray.data_ptr(), gx.data_ptr(), gy.data_ptr(), g.data_ptr())
     torch.cuda.synchronize()
+# calibration copy of known size (see tools/profile_workload.py)
+cal_src = torch.empty(256 << 20, dtype=torch.uint8, device="cuda"); cal_dst = torch.empty_like(cal_src)
+torch.cuda.synchronize(); cal_dst.copy_(cal_src); torch.cuda.synchronize()
 print("done", B)
 ctx.close()

@@ -114,14 +114,21 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
 
 __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, const int32_t* __restrict__ nkp, int kcap,
                                                   const int32_t* __restrict__ pair_q, const int32_t* __restrict__ pair_t,
-                                                  uint32_t* __restrict__ knn12, uint32_t* __restrict__ knn21) {
+                                                  uint32_t* __restrict__ knn12, uint32_t* __restrict__ knn21, int npairs, int nchunks) {
     __shared__ __attribute__((aligned(16))) uint4 tile[2][32 * KM_ROW];
-    const int pair = blockIdx.y, dir = blockIdx.z;
+    // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (private L2 each).  All chunks and both
+    // directions of one frame pair go to ONE XCD, so the pair's two descriptor sets are fetched into one L2 once
+    // (rocprofv3 FETCH_SIZE was 2.3 GB per 512 pairs with a plain (chunk, pair, dir) grid: every chunk re-fetched the
+    // swept set through a different L2).
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, per_pair = 2 * nchunks;
+    const int pair = (jb / per_pair) * 8 + xcd;
+    if (pair >= npairs) return;
+    const int inner = jb % per_pair, dir = inner / nchunks, chunk = inner - dir * nchunks;
     const int rf = dir == 0 ? pair_q[pair] : pair_t[pair];        // fixed set: top-2 tracked per descriptor
     const int rs = dir == 0 ? pair_t[pair] : pair_q[pair];        // swept set
     if (rf < 0 || rs < 0) return;
     const int nf = min(nkp[rf], kcap), ns = min(nkp[rs], kcap);
-    const int fbase = blockIdx.x * 128;
+    const int fbase = chunk * 128;
     if (fbase >= nf) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
@@ -341,9 +348,10 @@ int launch_match(vis_ctx* ctx, Plan* pl, int npairs) {
     if (npairs <= 0) return VIS_OK;
     static const bool force_popcount = getenv("VIS_KNN_POPCOUNT") != nullptr;     // A/B measurements only
     if (pl->d_descx && pl->kcap < 32768 && !force_popcount) {
-        dim3 grid((pl->kcap + 127) / 128, npairs, 2);
+        const int nchunks = (pl->kcap + 127) / 128;
+        dim3 grid(8 * ((npairs + 7) / 8) * 2 * nchunks);
         hipLaunchKernelGGL(k_knn_mfma, grid, dim3(256), 0, ctx->stream, pl->d_descx, pl->d_nkp, pl->kcap,
-                           pl->d_pair_q, pl->d_pair_t, pl->d_knn12, pl->d_knn21);
+                           pl->d_pair_q, pl->d_pair_t, pl->d_knn12, pl->d_knn21, npairs, nchunks);
         HIPCHK(ctx, hipGetLastError());
         return VIS_OK;
     }
