@@ -146,23 +146,21 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, 
     }
     const int8_t* xs = X + (size_t)rs * kcap * 256;
     const int ntiles = (ns + 31) / 32;
-    auto stage = [&](int t, int buf) {
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int idx = tid + 256 * k;
-            const int row = idx >> 4, c16 = idx & 15;
-            const int srow = min(t * 32 + row, ns - 1);
-            tile[buf][row * KM_ROW + c16] = *reinterpret_cast<const uint4*>(xs + (size_t)srow * 256 + 16 * c16);
-        }
-    };
+    // staging of the next swept tile: global loads are issued before the MFMA chain of the current tile, the LDS
+    // writes after it (the load latency is covered by the wave's own compute, not only by other waves)
+    const int st_row0 = tid >> 4, st_row1 = (tid + 256) >> 4, st_c = tid & 15;
+    uint4 pre0, pre1;
+#define STAGE_LOAD(t_) do { pre0 = *reinterpret_cast<const uint4*>(xs + (size_t)min((t_) * 32 + st_row0, ns - 1) * 256 + 16 * st_c); \
+                            pre1 = *reinterpret_cast<const uint4*>(xs + (size_t)min((t_) * 32 + st_row1, ns - 1) * 256 + 16 * st_c); } while (0)
+#define STAGE_STORE(buf_) do { tile[buf_][st_row0 * KM_ROW + st_c] = pre0; tile[buf_][st_row1 * KM_ROW + st_c] = pre1; } while (0)
     // running keys: (2*Hamming << 15) | (tile << 4) | accumulator register.  Inside a lane the register order is the
     // row order, so (tile, register) breaks ties exactly like the row index; it is a wave-uniform addend (SGPR).  The
     // true row index is restored before the two half-lanes of a column are merged.
     uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
-    if (ntiles > 0) stage(0, 0);
+    if (ntiles > 0) { STAGE_LOAD(0); STAGE_STORE(0); }
     __syncthreads();
     for (int t = 0; t < ntiles; t++) {
-        if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
+        if (t + 1 < ntiles) STAGE_LOAD(t + 1);
         const uint4* tb = tile[t & 1] + col * KM_ROW + h;
         v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -189,6 +187,7 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, 
                 k0 = min(k0, key);
             }
         }
+        if (t + 1 < ntiles) STAGE_STORE((t + 1) & 1);
         __syncthreads();
     }
     auto true_key = [&](uint32_t k) {
