@@ -7,16 +7,16 @@
 //
 // Kernel chain per batch of B frames (all on one stream, no host sync):
 //   k_resize   (per level l>=1)  cv::resize INTER_LINEAR 8-bit fixed point, level l-1 -> l
-//   k_fast     (per level)       FAST-9/16 score into an LDS tile + 3x3 NMS + border cull;
-//                                packed candidates + per-(frame,level) score histogram
-//   k_select   (1 launch)        block per (frame,level): histogram cut = retainBest(2*quota)
-//                                on the FAST score, Harris on survivors, LDS bitonic sort by
-//                                (response desc, y, x) = canonical order, retainBest(quota)
-//   k_describe (1 launch)        wave per keypoint: 43x43 raw patch -> LDS, IC angle, 7-tap
-//                                fixed-point blur evaluated only where rBRIEF samples, 256
-//                                tests packed with wave ballots
+//   k_fast     (1 launch)        all levels, all frames: 128x32 tile of the emit region + halo -> LDS, packed 16-bit
+//                                pretest on every position, dense FAST-9/16 cornerScore on the survivors, 3x3 NMS +
+//                                border cull; candidates into the tile's own slot (no global atomics)
+//   k_select   (1 launch)        block per (frame,level): 256-bin score histogram = retainBest(2*quota) cut,
+//                                Harris on survivors, LDS bitonic sort by (response desc, y, x) = canonical order,
+//                                retainBest(quota)
+//   k_describe (1 launch)        wave per keypoint: 43x43 raw patch -> LDS, IC angle, 7-tap fixed-point blur
+//                                evaluated only where rBRIEF samples, 256 tests packed with wave ballots
 // HBM traffic model: every pyramid pixel is read once by k_fast and once as the
-// next level's resize source; candidates/keypoints are O(N) and tiny.
+// next level's resize source; candidates/keypoints are O(N) and tiny.  All kernels are bound by vector-ALU issue.
 #include "vis_internal.h"
 #include <cfloat>
 #include <cmath>

@@ -1,8 +1,9 @@
 // match.hip -- brute-force Hamming 2-NN (both directions) and the reference's match filters on gfx950.
 //
-// k_knn2   replaces descriptorsGPU[0/1].upload + 2 x cuda::DescriptorMatcher::knnMatch(k=2)
-//          (/root/reference/src/MatcherGPU.cpp:49-56; CPU twin Matcher::computeMatches,
-//          /root/reference/src/Matcher.cpp:83-94).  Descriptors never leave HBM between detect and match.
+// k_expand + k_knn_mfma (default) / k_knn2 (popcount fallback) replace descriptorsGPU[0/1].upload +
+//          2 x cuda::DescriptorMatcher::knnMatch(k=2) (/root/reference/src/MatcherGPU.cpp:49-56; CPU twin
+//          Matcher::computeMatches, /root/reference/src/Matcher.cpp:83-94).  Descriptors never leave HBM between
+//          detect and match.
 // k_filter fuses Matcher::computeBestMatches (/root/reference/src/Matcher.cpp:353-367):
 //          nnFilter :148-169, computeSymMatches :96-144, sortMatches :329-352,
 //          bestMatchesFilter :171-244 and getGoodMatches :295-303 -- O(N) instead of the

@@ -9,12 +9,14 @@
 // Parallelisation: RANSAC is sequential only in (a) its cv::RNG sample stream and (b) the
 // "first strictly better model wins / adaptive iteration count" scan.  Both are O(iters) scalar work;
 // everything expensive (minimal solver, M Sampson errors per model) is independent per hypothesis:
-//   k_pose_prep   block/pair : normalise points, thread 0 replays cv::RNG -> sample table
-//   k_ransac_hyp  lane/hypothesis : 5-point solve (<=10 E) + inlier count per E
-//   k_ransac_scan thread/pair : replays RANSACPointSetRegistrator::run's accept/update rule in order
-//   k_pose_final  block/pair : inlier mask of the winner, SVD, 4x M DLT triangulations, cheirality vote
-// The first 64 hypotheses are evaluated and scanned first; the remaining ones exit immediately when
-// the adaptive iteration count already stopped (the common case on good matches).
+//   k_pose_prep    block/pair : normalise points, copy (or replay) the cv::RNG sample table
+//   k_ransac_hyp   lane/hypothesis : minimal solver up to the degree-10 polynomial -> hypothesis record
+//   k_hyp_roots    16 lanes/hypothesis : real roots, one bisection interval per lane
+//   k_hyp_score    256 threads/16 hypotheses : back-substitution (<=10 E each) + inlier counts of every E
+//   k_ransac_scan  wave/pair : replays RANSACPointSetRegistrator::run's accept/update rule in order
+//   k_pose_final   block/pair : inlier mask of the winner, SVD, 4x M DLT triangulations, cheirality vote
+// The first 16 hypotheses of every pair are evaluated and scanned first; later chunks run only for the pairs whose
+// adaptive iteration count is still above 16 (device work list) -- the rare case on good matches.
 // Algorithm and operation order mirror oracle/pose.cpp; compared with a stated tolerance
 // (tests/test_pose_gpu.py), not bit-exactly.
 #include "vis_internal.h"
