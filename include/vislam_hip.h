@@ -233,8 +233,11 @@ int  vis_feeder_release(vis_feeder* f, int which);
 int  vis_batch_plan(vis_ctx* ctx, int w, int h, int stride, int max_frames);
 int  vis_batch_reset(vis_ctx* ctx);
 enum { VIS_STAGE_DETECT = 1, VIS_STAGE_MATCH = 2, VIS_STAGE_POSE = 4, VIS_STAGE_ALL = 7 };
-/* async on the context stream: d_frames = n_frames images resident in HBM (dev ptr,
- * row stride from the plan, frame stride = stride*h). */
+/* Asynchronous: d_frames = n_frames images resident in HBM (dev ptr, row stride from the plan, frame stride =
+ * stride*h).  The context runs three streams: the detect chain (the stream set with vis_set_stream / the context's
+ * own), the matcher, and the RANSAC/pose stage; consecutive calls overlap (detect of batch i+1 with match and pose of
+ * batch i).  d_frames may be reused once the detect chain of this call has finished (vis_batch_sync, or an event
+ * recorded on the detect stream after the call; vis_feeder_release does exactly that). */
 int  vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n_frames, int stages);
 int  vis_batch_sync(vis_ctx* ctx);
 /* copy results of the last batch to host (synchronises). Any pointer may be NULL. */
