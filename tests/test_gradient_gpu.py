@@ -22,10 +22,14 @@ def test_gradient_s752(vislam, orc, ctx, canvas):
     _check_levels(vislam, orc, ctx, vislam.synth_frame(canvas, 5, 752, 480))
 
 
-@pytest.mark.parametrize("w,h", [(64, 48), (96, 32), (160, 112), (1920, 1088)])
+@pytest.mark.parametrize("w,h", [(64, 48), (96, 32), (160, 112), (1920, 1088), (3840, 2160)])
 def test_gradient_sizes(vislam, orc, ctx, canvas, w, h):
     # 64x48: level 4 is 4x3 (narrower than one thread's 8 pixels); 1920x1088: levels of every alignment class
-    _check_levels(vislam, orc, ctx, vislam.synth_frame(canvas, 3, w, h))
+    if w > 2048:        # the 4K configuration: textured random image (the 4096^2 fixture canvas is too small to crop it at t = 3)
+        img = np.random.default_rng(21).integers(0, 256, (h, w), dtype=np.uint8)
+    else:
+        img = vislam.synth_frame(canvas, 3, w, h)
+    _check_levels(vislam, orc, ctx, img)
 
 
 @pytest.mark.parametrize("scale", [1, 3, 8])
@@ -36,6 +40,16 @@ def test_gradient_scale_and_extremes(vislam, orc, ctx, scale):
     _check_levels(vislam, orc, ctx, img, scale)
     rng = np.random.default_rng(7)
     _check_levels(vislam, orc, ctx, rng.integers(0, 256, (80, 144), dtype=np.uint8), scale)
+
+
+def test_gradient_transpose_property_full_size(vislam, ctx):
+    """size-independent property at the 4K configuration: the Scharr pair and the blend are symmetric under transposition
+    (gx of the transposed image is gy transposed), level by level -- the half pyramid's 2x2 box mean is symmetric too"""
+    img = np.random.default_rng(22).integers(0, 256, (2144, 2144), dtype=np.uint8)   # 2144 = 16 * 134
+    gx, gy, g = ctx.compute_gradient(img)
+    tx, ty, tg = ctx.compute_gradient(np.ascontiguousarray(img.T))
+    for l in range(5):
+        assert (tx[l] == gy[l].T).all() and (ty[l] == gx[l].T).all() and (tg[l] == g[l].T).all(), l
 
 
 def test_gradient_invalid_arguments(vislam, ctx):
