@@ -263,6 +263,17 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, frames)
+            # the same port frame-parallel on the host cores this GPU's share allows (OpenCV itself would
+            # run TBB inside its calls); informational, `cpu_baseline` stays the single-thread figure of the reference's own code
+            try:
+                import oracle_bind as orc
+                th = max(1, min(16, os.cpu_count() or 1))
+                ns = min(len(frames), 24 * th)
+                sec, _ = orc.pipeline_stream_mt(p, frames[:ns], th)
+                out["cpu_baseline_multicore"] = {"value": ns / sec, "unit": "frames/s", "cores": th, "kind": "port",
+                                                 "sample": f"{ns} consecutive S-752 frames, frame-parallel std::thread pool over the same oracle pipeline"}
+            except Exception as e:
+                out["cpu_baseline_multicore"] = {"error": str(e)}
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:

@@ -615,3 +615,59 @@ extern "C" int orc_pipeline_frame(const vis_params* p, const uint8_t* img, int w
         recover_pose(*p, res->E, a.data(), b.data(), (int)good.size(), res->R, res->t, &res->n_pose_good);
     return VIS_OK;
 }
+
+
+// Frame-parallel run of the same per-frame pipeline over a resident stream, for the "all host cores" CPU figure that
+// SURVEY section 8(d) asks for beside the single-thread one (OpenCV itself would use TBB inside its calls).
+// Phase 1: frames are detected in parallel; phase 2: consecutive pairs are matched + posed in parallel.  Per-frame
+// results are identical to calling orc_pipeline_frame frame after frame.  Returns the wall seconds of both phases.
+#include <atomic>
+#include <chrono>
+#include <thread>
+extern "C" int orc_pipeline_stream_mt(const vis_params* p, const uint8_t* frames, int n, int w, int h, int stride,
+                                      int threads, double* seconds, orc_frame_result* results /* n, may be NULL */) {
+    if (!p || !frames || n < 1 || threads < 1 || !seconds) return VIS_E_INVALID;
+    std::vector<std::vector<vis_keypoint> > K((size_t)n);
+    std::vector<std::vector<uint8_t> > D((size_t)n);
+    std::vector<orc_frame_result> R((size_t)n);
+    std::atomic<int> next(0), err(0);
+    const size_t fbytes = (size_t)stride * h;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto run = [&](auto fn) {
+        next = 0;
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; t++) pool.emplace_back([&]() { for (int i; (i = next.fetch_add(1)) < n;) fn(i); });
+        for (auto& th : pool) th.join();
+    };
+    run([&](int i) {
+        std::memset(&R[(size_t)i], 0, sizeof(orc_frame_result));
+        const uint8_t* img = frames + (size_t)i * fbytes;
+        std::vector<uint8_t> lv[5]; uint8_t* lp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        for (int l = 1; l < 5; l++) { lv[l].resize((size_t)(w >> l) * (h >> l) + 16); lp[l] = lv[l].data(); }
+        orc_half_pyramid(img, w, h, stride, lp);
+        if (orb_detect_compute(*p, img, w, h, stride, K[(size_t)i], D[(size_t)i])) err = 1;
+        R[(size_t)i].n_kp = (int)K[(size_t)i].size();
+    });
+    run([&](int i) {
+        if (i == 0 || K[(size_t)i].empty() || K[(size_t)i - 1].empty()) return;
+        const std::vector<vis_keypoint>& pk = K[(size_t)i - 1]; const std::vector<vis_keypoint>& k = K[(size_t)i];
+        const std::vector<uint8_t>& pd = D[(size_t)i - 1]; const std::vector<uint8_t>& d = D[(size_t)i];
+        orc_frame_result& res = R[(size_t)i];
+        std::vector<vis_dmatch> k12(2 * pk.size()), k21(2 * k.size());
+        knn2_hamming(pd.data(), (int)pk.size(), d.data(), (int)k.size(), k12.data());
+        knn2_hamming(d.data(), (int)k.size(), pd.data(), (int)pk.size(), k21.data());
+        std::vector<vis_dmatch> sym, good;
+        good_matches(*p, pk.data(), (int)pk.size(), k.data(), (int)k.size(), k12.data(), k21.data(), sym, good);
+        res.n_sym = (int)sym.size(); res.n_good = (int)good.size();
+        std::vector<float> a(2 * good.size()), b(2 * good.size());
+        for (size_t j = 0; j < good.size(); j++) {
+            a[2 * j] = pk[good[j].queryIdx].x; a[2 * j + 1] = pk[good[j].queryIdx].y;
+            b[2 * j] = k[good[j].trainIdx].x; b[2 * j + 1] = k[good[j].trainIdx].y;
+        }
+        essential_ransac(*p, a.data(), b.data(), (int)good.size(), res.E, nullptr, &res.n_inliers, &res.iters_run);
+        if (res.n_inliers > 0) recover_pose(*p, res.E, a.data(), b.data(), (int)good.size(), res.R, res.t, &res.n_pose_good);
+    });
+    *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (results) std::memcpy(results, R.data(), (size_t)n * sizeof(orc_frame_result));
+    return err ? VIS_E_INVALID : VIS_OK;
+}

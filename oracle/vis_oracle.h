@@ -99,6 +99,10 @@ int orc_pipeline_frame(const vis_params* p, const uint8_t* img, int w, int h, in
                        const vis_keypoint* prev_kps, const uint8_t* prev_desc, int n_prev,
                        vis_keypoint* kps, uint8_t* desc, int cap, orc_frame_result* res);
 
+/* the same pipeline over n resident frames, frame-parallel on `threads` host threads (the 'all cores' CPU baseline) */
+int orc_pipeline_stream_mt(const vis_params* p, const uint8_t* frames, int n, int w, int h, int stride,
+                           int threads, double* seconds, orc_frame_result* results);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,7 @@ lib.orc_knn2_hamming.argtypes = [vp, ci, vp, ci, vp, vp]
 lib.orc_scharr_gradient.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp]
 lib.orc_patch_points.argtypes = [vp, ci, vp, vp, ci, vp, ci, ip]
 lib.orc_debug_points.argtypes = [vp, ci, ci, vp, ci, ip]
+lib.orc_pipeline_stream_mt.argtypes = [C.POINTER(Params), vp, ci, ci, ci, ci, ci, C.POINTER(C.c_double), vp]
 lib.orc_good_matches.argtypes = [C.POINTER(Params), vp, ci, vp, ci, vp, vp, vp, ci, ip, vp, ci, ip]
 lib.orc_five_point.argtypes = [vp, vp, vp]
 lib.orc_essential_ransac.argtypes = [C.POINTER(Params), vp, vp, ci, vp, vp, ip, ip]
@@ -218,6 +219,17 @@ lib.orc_umax.argtypes = [ci, vp]
 lib.orc_umax.restype = None
 lib.orc_gaussian_kernel7_q8.argtypes = [vp]
 lib.orc_gaussian_kernel7_q8.restype = None
+
+
+def pipeline_stream_mt(p, frames, threads):
+    """frame-parallel oracle pipeline over frames (n, h, w): (seconds, per-frame FrameResult array)"""
+    frames = np.ascontiguousarray(frames, np.uint8)
+    n, h, w = frames.shape
+    res = (FrameResult * n)()
+    sec = C.c_double(0)
+    rc = lib.orc_pipeline_stream_mt(C.byref(p), _p(frames), n, w, h, w, threads, C.byref(sec), res)
+    assert rc == 0, rc
+    return sec.value, res
 
 
 def sincos_det(x):

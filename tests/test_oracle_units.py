@@ -309,3 +309,20 @@ def test_patch_points_reference_quirks(orc):
     many = np.zeros(300, KEYPOINT_DTYPE); many["x"] = 300; many["y"] = 200
     assert len(orc.debug_points(many, 2)) == 200
     assert orc.debug_points(many, 2)[0, 0] == np.float32((300 + 0.5) * 0.25 - 0.5)
+
+
+def test_pipeline_stream_mt_equals_sequential(vislam, orc):
+    """the frame-parallel CPU baseline runs exactly the per-frame pipeline (bench.py cpu_baseline_multicore)"""
+    p = vislam.default_params(); p.fy = p.fx
+    p.nfeatures, p.w_size, p.h_size = 300, 320, 240
+    cv = vislam.synth_canvas(1024, 9)
+    fr = np.stack([vislam.synth_frame(cv, t, 320, 240, 9) for t in range(6)])
+    prev, ref = None, []
+    for t in range(6):
+        k, d, r = orc.pipeline_frame(p, fr[t], prev)
+        prev = (k, d)
+        ref.append((r.n_kp, r.n_sym, r.n_good, r.n_inliers, r.n_pose_good, r.iters_run, tuple(r.E)))
+    for th in (1, 3):
+        sec, res = orc.pipeline_stream_mt(p, fr, th)
+        assert sec > 0
+        assert [(r.n_kp, r.n_sym, r.n_good, r.n_inliers, r.n_pose_good, r.iters_run, tuple(r.E)) for r in res] == ref
