@@ -257,7 +257,7 @@ struct FastArgs { FastLevel lv[VIS_MAX_LEVELS]; int L, total_tiles; };
 // (D) 3x3 NMS + border cull on the scored survivors -> packed candidates in the tile's own slot.
 __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edge, int32_t* __restrict__ tile_cnt, int nframes) {
     __shared__ __attribute__((aligned(16))) uint32_t px[PX_H * PX_W / 4];
-    __shared__ uint8_t sc[SC_H * SC_S];
+    __shared__ __attribute__((aligned(16))) uint8_t sc[(SC_H * SC_S + 15) / 16 * 16];
     __shared__ uint16_t queue[SC_H * SC_W];
     __shared__ int lcount, qn;
     const int tid = threadIdx.x;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edg
             px[wv] = v;
         }
     }
-    for (int i = tid; i < SC_H * SC_S / 4; i += 256) reinterpret_cast<uint32_t*>(sc)[i] = 0;
+    for (int i = tid; i < (SC_H * SC_S + 15) / 16; i += 256) reinterpret_cast<uint4*>(sc)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     const uint8_t* pxb = reinterpret_cast<const uint8_t*>(px);
     // real scores are needed one pixel beyond the emit region (NMS neighbours), nowhere else
