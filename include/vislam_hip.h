@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VIS_ABI_VERSION 1
+#define VIS_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -91,7 +91,13 @@ typedef struct vis_params {
     /* F2FRansac -- src/VISystem.cpp:709 (1000 iterations), :523 (threshold 370) */
     int32_t f2f_iters;        /* 1000 */
     double  f2f_threshold;    /* 370  */
+    /* which correspondences the batched pose stage consumes: the reference pipeline feeds the grid-filtered good
+     * matches (Frame::next/prevGoodMatches, src/VISystem.cpp:1673-1674); BASELINE config 3 asks for RANSAC on the
+     * un-gridded symmetric matches (M up to N) */
+    int32_t pose_input;       /* VIS_POSE_GOOD */
+    int32_t reserved_;
 } vis_params;
+enum { VIS_POSE_GOOD = 0, VIS_POSE_SYM = 1 };
 
 /* wall-clock of the last call's device work, from hipEvents on the context stream
  * (mirrors the elapsed_* members, include/Camera.hpp:121-126, include/Matcher.hpp:63-66) */
@@ -201,6 +207,52 @@ int  vis_compute_gradient(vis_ctx* ctx, const uint8_t* img, int w, int h, int st
  * params.w_size >> l, params.h_size >> l (CameraModel w_size[lvl], h_size[lvl]). */
 int  vis_patch_points(vis_ctx* ctx, const vis_keypoint* good, int n, int cap,
                       float* const patch[5], int n_patch[5], float* const debug[5], int n_debug[5]);
+
+/* ---- the pose step the GPU main calls: VISystem::EstimatePoseFeatures (src/VISystem.cpp:1113-1448), called from
+ * VISystemGPU::AddFrameGPU (src/VISystemGPU.cpp:167) -- SURVEY 8(f) N4 --------------------------------------- */
+/* Gauss-Newton photometric alignment of the candidate points of the previous keyframe (ObtainPatchesPoints...) to the
+ * current frame, coarse to fine over the half pyramid; pose = Sophus::SE3f (unit quaternion + translation). */
+typedef struct vis_se3f { float qx, qy, qz, qw; float tx, ty, tz; } vis_se3f;   /* Sophus::SE3f storage order */
+typedef struct vis_align_params {
+    float fx, fy, cx, cy;        /* level-0 intrinsics, the float members of VISystem (include/VISystem.hpp:82) */
+    int32_t first_level;         /* 3      src/VISystem.cpp:1119 */
+    int32_t last_level;          /* 0      :1120 */
+    int32_t max_iterations;      /* 10     :1117 */
+    float   epsilon;             /* 0.001f :1115 */
+    float   z_factor;            /* 0.002f :1121 */
+} vis_align_params;
+typedef struct vis_align_result {
+    vis_se3f pose;               /* current_pose after the last level (Frame::rigid_transformation_, :1445) */
+    float matrix[16];            /* pose.matrix(), row-major 4x4 */
+    float error[5];              /* last mean squared residual per level */
+    float initial_error;
+    int32_t iterations[5];       /* iteration index k at which the level stopped */
+    int32_t n_residuals[5];      /* valid residuals in the last iteration of the level */
+} vis_align_result;
+void vis_default_align_params(vis_align_params* ap);
+/* One pair, HOST pointers.  Level l images are dense (w>>l) x (h>>l): gray1/gx1/gy1 of the previous keyframe
+ * (Frame::grayImage / gradientX / gradientY), gray2 of the current frame, cand1[l] = n_cand[l] rows (x, y, z, 1) as
+ * Frame::candidatePoints[l] holds them.  Levels outside [last_level, first_level] may be NULL.  init may be NULL
+ * (identity); the reference seeds it from the IMU rotation residual and the ground-truth translation (:1133-1166). */
+int  vis_estimate_pose_features(vis_ctx* ctx, const vis_align_params* ap, int w, int h,
+                                const uint8_t* const gray1[5], const uint8_t* const gray2[5],
+                                const int16_t* const gx1[5], const int16_t* const gy1[5],
+                                const float* const cand1[5], const int32_t n_cand[5],
+                                const vis_se3f* init, vis_align_result* out);
+/* Batched, DEVICE pointers: n consecutive frames resident in HBM and the outputs of vis_gradient_batch for the same
+ * frames (d_gray levels 1..4, d_gx, d_gy).  Pair i = (frame i-1 -> frame i), i = 1..n-1; d_out[0] is zeroed.  The
+ * candidate points of pair i are generated on the fly from d_pts: max_pts (x, y) floats per pair = the matched
+ * keypoints of frame i-1 (Frame::nextGoodMatches, at most 200 are used like the reference), d_npts[i] of them valid.
+ * d_init: n poses or NULL.  Asynchronous on the context's stream.  w, h multiples of 16. */
+int  vis_align_batch(vis_ctx* ctx, const vis_align_params* ap, const uint8_t* d_frames, int w, int h, int stride, int n,
+                     const uint8_t* d_gray, const int16_t* d_gx, const int16_t* d_gy,
+                     const float* d_pts, const int32_t* d_npts, int max_pts,
+                     const vis_se3f* d_init, vis_align_result* d_out);
+/* the same on the pairs of the last vis_batch_run (stages must have included MATCH): the matched points come from the
+ * plan (the grid-filtered good matches of every pair).  Pair 0 (frame 0 against the carried frame) is skipped. */
+int  vis_batch_align(vis_ctx* ctx, const vis_align_params* ap, const uint8_t* d_frames, int n,
+                     const uint8_t* d_gray, const int16_t* d_gx, const int16_t* d_gy,
+                     const vis_se3f* d_init, vis_align_result* d_out);
 
 /* ---- frame ingest (src/ImageReader.cpp) ------------------------------------- */
 /* ImageReader::searchImages (src/ImageReader.cpp:49-74): the .pgm / .raw files of `dir` in byte order, names

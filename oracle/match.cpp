@@ -133,7 +133,7 @@ extern "C" int orc_good_matches(const vis_params* p, const vis_keypoint* kps1, i
     good_matches(*p, kps1, n1, kps2, n2, knn12, knn21, sym, g);
     if (n_good) *n_good = (int)g.size();
     if (n_sym) *n_sym = (int)sym.size();
-    if (good) { if ((int)g.size() > cap) return VIS_E_CAPACITY; std::memcpy(good, g.data(), g.size() * sizeof(vis_dmatch)); }
-    if (sym_out) { if ((int)sym.size() > sym_cap) return VIS_E_CAPACITY; std::memcpy(sym_out, sym.data(), sym.size() * sizeof(vis_dmatch)); }
+    if (good) { if ((int)g.size() > cap) return VIS_E_CAPACITY; if (!g.empty()) std::memcpy(good, g.data(), g.size() * sizeof(vis_dmatch)); }
+    if (sym_out) { if ((int)sym.size() > sym_cap) return VIS_E_CAPACITY; if (!sym.empty()) std::memcpy(sym_out, sym.data(), sym.size() * sizeof(vis_dmatch)); }
     return VIS_OK;
 }

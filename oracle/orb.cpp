@@ -482,8 +482,8 @@ extern "C" int orc_orb_detect_compute(const vis_params* p, const uint8_t* img, i
     if (rc) return rc;
     *n_out = (int)k.size();
     if ((int)k.size() > cap) return VIS_E_CAPACITY;
-    if (kps) std::memcpy(kps, k.data(), k.size() * sizeof(vis_keypoint));
-    if (desc) std::memcpy(desc, d.data(), d.size());
+    if (kps && !k.empty()) std::memcpy(kps, k.data(), k.size() * sizeof(vis_keypoint));
+    if (desc && !d.empty()) std::memcpy(desc, d.data(), d.size());
     return VIS_OK;
 }
 

@@ -417,7 +417,7 @@ int essential_ransac(const vis_params& p, const float* p1xy, const float* p2xy, 
             }
         }
     }
-    if (mask_out && maxGood > 0) std::memcpy(mask_out, best.data(), m);
+    if (mask_out && maxGood > 0 && m > 0) std::memcpy(mask_out, best.data(), m);
     if (n_inl) *n_inl = maxGood;
     if (iters_run) *iters_run = iter;
     return VIS_OK;
@@ -596,8 +596,8 @@ extern "C" int orc_pipeline_frame(const vis_params* p, const uint8_t* img, int w
     if (rc) return rc;
     res->n_kp = (int)k.size();
     if ((int)k.size() > cap) return VIS_E_CAPACITY;
-    if (kps) std::memcpy(kps, k.data(), k.size() * sizeof(vis_keypoint));
-    if (desc) std::memcpy(desc, d.data(), d.size());
+    if (kps && !k.empty()) std::memcpy(kps, k.data(), k.size() * sizeof(vis_keypoint));
+    if (desc && !d.empty()) std::memcpy(desc, d.data(), d.size());
     if (!prev_kps || n_prev <= 0 || k.empty()) return VIS_OK;
     std::vector<vis_dmatch> k12(2 * (size_t)n_prev), k21(2 * k.size());
     knn2_hamming(prev_desc, n_prev, d.data(), (int)k.size(), k12.data());   // both directions, like
@@ -668,6 +668,6 @@ extern "C" int orc_pipeline_stream_mt(const vis_params* p, const uint8_t* frames
         if (res.n_inliers > 0) recover_pose(*p, res.E, a.data(), b.data(), (int)good.size(), res.R, res.t, &res.n_pose_good);
     });
     *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (results) std::memcpy(results, R.data(), (size_t)n * sizeof(orc_frame_result));
+    if (results && n > 0) std::memcpy(results, R.data(), (size_t)n * sizeof(orc_frame_result));
     return err ? VIS_E_INVALID : VIS_OK;
 }

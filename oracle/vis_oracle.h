@@ -83,6 +83,23 @@ int orc_patch_points(const vis_keypoint* good, int n, const int32_t* lw, const i
 /* Camera::ObtainDebugPointsPreviousFrame, src/Camera.cpp:413-445 */
 int orc_debug_points(const vis_keypoint* good, int n, int level, float* xyzw, int cap, int* n_out);
 
+/* VISystem::EstimatePoseFeatures, src/VISystem.cpp:1113-1448 (+ WarpFunctionSE3 :1495-1558, InitializePyramid
+ * :1451-1493): same arguments as vis_estimate_pose_features; see align.cpp for what is restated and what is SPEC */
+void orc_default_align_params(vis_align_params* ap);
+int orc_estimate_pose_features(const vis_align_params* ap, int w, int h,
+                               const uint8_t* const gray1[5], const uint8_t* const gray2[5],
+                               const int16_t* const gx1[5], const int16_t* const gy1[5],
+                               const float* const cand1[5], const int32_t n_cand[5],
+                               const vis_se3f* init, vis_align_result* out);
+/* Sophus::SE3f pieces (thirdparty/sophus/se3.hpp:723-744, :317-321, :253-259), Mat::inv on 6x6 float (LU),
+ * VISystem::TukeyFunctionWeights (:1797-1825, not on the live path) */
+void orc_se3_exp(const float a[6], vis_se3f* out);
+void orc_se3_mul(const vis_se3f* a, const vis_se3f* b, vis_se3f* out);
+void orc_se3_from_rt(const float R[9], const float t[3], vis_se3f* out);
+void orc_se3_matrix(const vis_se3f* a, float M[16]);
+int orc_lu_invert6(const float A[36], float inv[36]);
+int orc_tukey_weights(const float* residuals, int n, float* w);
+
 /* unit-test hooks */
 void orc_sincos_det(double x, double* s, double* c);
 float orc_fast_atan2(float y, float x);

@@ -70,6 +70,21 @@ def main():
     dbg = [orc.debug_points(kp, l) for l in range(5)]
     np.savez_compressed(os.path.join(HERE, "gradient_160x112.npz"), img=crop, gx=np.concatenate(gxs), gy=np.concatenate(gys), g=np.concatenate(gs),
                         kp=kp, patch=np.concatenate(pts), patch_counts=np.array([len(x) for x in pts]), debug=np.concatenate(dbg))
+    # VISystem::EstimatePoseFeatures (Gauss-Newton photometric alignment) on a 320x240 two-view case: second view = the
+    # first shifted by (4, 3) px, 12 keypoints, gradients divided by 8 so that several iterations run per
+    # level (7, 4, 1, 1): with the reference's scale-3 Scharr the steps are so small that most levels stop at k = 1
+    import align_cases
+    cv2 = vislam.synth_canvas(1024, 77)
+    c = align_cases.case(vislam, orc, cv2, w=320, h=240, dx=4, dy=3, n=12, grad_div=8, seed=77)
+    ap = orc.default_align_params()
+    ap.fx, ap.fy, ap.cx, ap.cy = 200.0, 200.0, 160.0, 120.0
+    r = orc.estimate_pose_features(ap, 320, 240, c["gray1"], c["gray2"], c["gx"], c["gy"], c["cand"])
+    d = {}
+    for l in range(5):
+        d[f"gray1_{l}"] = c["gray1"][l]; d[f"gray2_{l}"] = c["gray2"][l]; d[f"gx_{l}"] = c["gx"][l]; d[f"gy_{l}"] = c["gy"][l]
+        d[f"cand_{l}"] = c["cand"][l]
+    np.savez_compressed(os.path.join(HERE, "align_320x240.npz"), iterations=np.array(list(r.iterations)), n_residuals=np.array(list(r.n_residuals)),
+                        error=np.array(r.error, np.float32), pose=r.pose.as_array(), matrix=np.array(r.matrix, np.float32), **d)
     print("golden fixtures written:", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
 
 

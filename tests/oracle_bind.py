@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "oracle", "_build", "libvis_oracle.so")
+LIB = os.environ.get("VIS_ORACLE_LIB") or os.path.join(ROOT, "oracle", "_build", "libvis_oracle.so")   # the env override is the sanitizer build (tests/test_oracle_asan.py)
 lib = C.CDLL(LIB)
 
 import sys
@@ -252,3 +252,86 @@ def gaussian_kernel7_q8():
     k = np.zeros(7, np.int32)
     lib.orc_gaussian_kernel7_q8(_p(k))
     return k
+
+
+# ---- VISystem::EstimatePoseFeatures (oracle/align.cpp) -----------------------------------------------------------
+from vislam import AlignParams, AlignResult, Se3f  # noqa: E402
+
+lib.orc_default_align_params.argtypes = [C.POINTER(AlignParams)]
+lib.orc_default_align_params.restype = None
+lib.orc_estimate_pose_features.argtypes = [C.POINTER(AlignParams), ci, ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                           C.POINTER(vp), ip, C.POINTER(Se3f), C.POINTER(AlignResult)]
+lib.orc_se3_exp.argtypes = [vp, C.POINTER(Se3f)]
+lib.orc_se3_exp.restype = None
+lib.orc_se3_mul.argtypes = [C.POINTER(Se3f), C.POINTER(Se3f), C.POINTER(Se3f)]
+lib.orc_se3_mul.restype = None
+lib.orc_se3_from_rt.argtypes = [vp, vp, C.POINTER(Se3f)]
+lib.orc_se3_from_rt.restype = None
+lib.orc_se3_matrix.argtypes = [C.POINTER(Se3f), vp]
+lib.orc_se3_matrix.restype = None
+lib.orc_lu_invert6.argtypes = [vp, vp]
+lib.orc_tukey_weights.argtypes = [vp, ci, vp]
+
+
+def default_align_params():
+    ap = AlignParams()
+    lib.orc_default_align_params(C.byref(ap))
+    return ap
+
+
+def _level_ptrs(arrs, dtype):
+    keep = [None if a is None else np.ascontiguousarray(a, dtype) for a in arrs]
+    keep += [None] * (5 - len(keep))
+    return keep, (vp * 5)(*[None if a is None else a.ctypes.data for a in keep])
+
+
+def estimate_pose_features(ap, w, h, gray1, gray2, gx1, gy1, cand1, init=None):
+    """lists of per-level arrays (None for unused levels) -> AlignResult"""
+    k1, a1 = _level_ptrs(gray1, np.uint8); k2, a2 = _level_ptrs(gray2, np.uint8)
+    k3, a3 = _level_ptrs(gx1, np.int16); k4, a4 = _level_ptrs(gy1, np.int16)
+    k5, a5 = _level_ptrs(cand1, np.float32)
+    n = (C.c_int * 5)(*[0 if c is None else len(c) for c in k5])
+    res = AlignResult()
+    rc = lib.orc_estimate_pose_features(C.byref(ap), w, h, a1, a2, a3, a4, a5, n, None if init is None else C.byref(init), C.byref(res))
+    assert rc == 0, rc
+    return res
+
+
+def se3_exp(a):
+    a = np.ascontiguousarray(a, np.float32)
+    o = Se3f()
+    lib.orc_se3_exp(_p(a), C.byref(o))
+    return o
+
+
+def se3_mul(a, b):
+    o = Se3f()
+    lib.orc_se3_mul(C.byref(a), C.byref(b), C.byref(o))
+    return o
+
+
+def se3_from_rt(R, t):
+    R = np.ascontiguousarray(R, np.float32).reshape(9); t = np.ascontiguousarray(t, np.float32)
+    o = Se3f()
+    lib.orc_se3_from_rt(_p(R), _p(t), C.byref(o))
+    return o
+
+
+def se3_matrix(a):
+    M = np.zeros(16, np.float32)
+    lib.orc_se3_matrix(C.byref(a), _p(M))
+    return M.reshape(4, 4)
+
+
+def lu_invert6(A):
+    A = np.ascontiguousarray(A, np.float32).reshape(36)
+    inv = np.zeros(36, np.float32)
+    ok = lib.orc_lu_invert6(_p(A), _p(inv))
+    return ok, inv.reshape(6, 6)
+
+
+def tukey_weights(r):
+    r = np.ascontiguousarray(r, np.float32)
+    w = np.zeros(len(r), np.float32)
+    assert lib.orc_tukey_weights(_p(r), len(r), _p(w)) == 0
+    return w

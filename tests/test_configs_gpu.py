@@ -1,4 +1,5 @@
-"""GPU: the larger BASELINE.json configurations.
+"""GPU: the BASELINE.json configurations beside the headline one.
+ config 1: the reference CPU path's own ORB::create(200) (src/Camera.cpp:127) at 752x480, on the HIP path
  config 3: 1920x1080, 4 levels, 4000 kps + essential RANSAC with a fixed 2000 iterations
  config 5: 3840x2160, 8000 kps, 8000x8000 all-pairs
 Parity against the oracle where it finishes in seconds, size-independent properties otherwise."""
@@ -6,6 +7,53 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+def test_config1_cpu_default_orb200_752x480(vislam, orc, canvas):
+    """BASELINE config 1 (stand-in for EuRoC MH_01: the dataset is not in the image): the CPU main's detector
+    setting nfeatures = 200, first frames of S-752, single-frame API and the batched stream path, both
+    bit-exact against the oracle's per-frame pipeline (keypoints, descriptors, matches) and pose within 1e-7."""
+    import torch
+    p = vislam.default_params()
+    p.nfeatures = 200
+    p.fy = p.fx
+    c = vislam.Context(0, p)
+    ws, hs, sc, q = c.level_geometry(752, 480)
+    assert list(q) == [43, 36, 30, 25, 21, 17, 15, 13]               # SURVEY 8(a) a4 quotas @200
+    n = 8
+    frames = np.stack([vislam.synth_frame(canvas, t, 752, 480) for t in range(n)])
+    dev = torch.from_numpy(frames).cuda()
+    c.batch_plan(752, 480, 752, n)
+    c.batch_run(dev.data_ptr(), n)
+    c.batch_sync()
+    assert c.batch_status() == 0
+    prev = None
+    for t in range(n):
+        ok, od, r = orc.pipeline_frame(p, frames[t], prev)
+        assert 180 <= len(ok) <= 260
+        k, d = c.batch_keypoints(t)
+        assert k.tobytes() == ok.tobytes() and (d == od).all(), t
+        if t in (0, 5):                                                # the single-frame entry point on the same frames
+            k1, d1 = c.orb_detect_compute(frames[t], slot=t)
+            assert k1.tobytes() == ok.tobytes() and (d1 == od).all()
+        g, nsym = c.batch_matches(t)
+        pose = c.batch_pose(t)
+        assert nsym == r.n_sym and len(g) == r.n_good
+        if prev is not None:
+            o12, o21 = orc.knn2_hamming(prev[1], od)
+            og, osym = orc.good_matches(p, prev[0], ok, o12, o21)
+            assert g.tobytes() == og.tobytes()
+            g12, g21 = c.batch_knn(t)
+            assert g12.tobytes() == o12.tobytes() and g21.tobytes() == o21.tobytes()
+        assert pose["n_inliers"] == r.n_inliers and pose["iters_run"] == r.iters_run, t
+        if r.n_inliers:
+            oE = np.array(r.E).reshape(3, 3)
+            s = 1.0 if float((pose["E"] * oE).sum()) >= 0 else -1.0
+            assert np.abs(pose["E"] - s * oE).max() <= 1e-9
+            assert pose["n_pose_good"] == r.n_pose_good
+            assert np.abs(pose["R"] - np.array(r.R).reshape(3, 3)).max() <= 1e-7
+        prev = (ok, od)
+    c.close()
 
 
 @pytest.fixture(scope="module")
@@ -71,4 +119,39 @@ def test_config5_2160p_8000kps_properties(vislam, orc, big_canvas):
     assert k0.tobytes() == ok0.tobytes() and (d0 == od0).all()
     good, sym = c.good_matches(0, 1)
     assert len(sym) > 7000 and len(good) == 49
+    c.close()
+
+
+def test_batched_pose_on_symmetric_matches(vislam, orc, canvas):
+    """BASELINE config 3 runs RANSAC on the un-gridded symmetric matches (M in the hundreds or thousands, where the
+    reference pipeline feeds at most root^2 = 49): vis_params.pose_input = VIS_POSE_SYM in the batched path, fixed
+    iteration count, checked per pair against the oracle's findEssentialMat / recoverPose on the same matches."""
+    import torch
+    p = vislam.default_params()
+    p.fy = p.fx
+    p.pose_input = 1                                                  # VIS_POSE_SYM
+    p.ransac_adaptive, p.ransac_max_iters = 0, 150
+    c = vislam.Context(0, p)
+    n = 4
+    frames = np.stack([vislam.synth_frame(canvas, t, 752, 480) for t in range(n)])
+    dev = torch.from_numpy(frames).cuda()
+    c.batch_plan(752, 480, 752, n)
+    c.batch_run(dev.data_ptr(), n)
+    c.batch_sync()
+    assert c.batch_status() == 0
+    kd = [c.batch_keypoints(t) for t in range(n)]
+    for t in range(1, n):
+        o12, o21 = orc.knn2_hamming(kd[t - 1][1], kd[t][1])
+        og, osym = orc.good_matches(p, kd[t - 1][0], kd[t][0], o12, o21)
+        g, nsym = c.batch_matches(t)
+        assert nsym == len(osym) > 300 and g.tobytes() == og.tobytes()
+        p1 = np.stack([kd[t - 1][0]["x"][osym["queryIdx"]], kd[t - 1][0]["y"][osym["queryIdx"]]], 1)
+        p2 = np.stack([kd[t][0]["x"][osym["trainIdx"]], kd[t][0]["y"][osym["trainIdx"]]], 1)
+        oE, omask, oninl, oiters = orc.essential_ransac(p, p1, p2)
+        pose = c.batch_pose(t)
+        assert pose["iters_run"] == oiters == 150 and pose["n_inliers"] == oninl, t
+        s = 1.0 if float((pose["E"] * oE).sum()) >= 0 else -1.0
+        assert np.abs(pose["E"] - s * oE).max() <= 1e-9
+        oR, ot, ong = orc.recover_pose(p, oE, p1, p2)
+        assert pose["n_pose_good"] == ong and np.abs(pose["R"] - oR).max() <= 1e-7
     c.close()

@@ -46,26 +46,44 @@ def test_smallest_image_and_huge_quota(vislam, orc, ctx):
     assert 0 < len(k) < 400
 
 
-def test_heavy_ties_checkerboard(vislam, orc, ctx):
-    """a periodic pattern gives hundreds of identical FAST scores and identical Harris responses: the
-    retainBest tie rule (keep every response >= the cut) and the canonical order are both exercised"""
+def _checkerboard():
     img = np.full((240, 320), 100, np.uint8)
     for y in range(40, 200, 20):
         for x in range(40, 280, 20):
             img[y:y + 7, x:x + 7] = 220                            # 96 identical squares -> 384 identical corners
             for cy, cx in ((y, x), (y, x + 6), (y + 6, x), (y + 6, x + 6)):
                 img[cy, cx] = 240                                  # unique local maximum at every corner (NMS is strict)
+    return img
+
+
+def test_heavy_ties_checkerboard(vislam, orc, ctx):
+    """a periodic pattern gives 384 identical FAST scores and 384 identical Harris responses: the retainBest tie
+    rule (keep every response >= the cut) and the canonical order are both exercised.  nfeatures = 360 keeps the
+    24 ties beyond the quota inside the plan's slack (keep_cap = 437), so the parity branch always runs."""
+    img = _checkerboard()
+    p = vislam.default_params()
+    p.nlevels, p.nfeatures, p.w_size, p.h_size = 1, 360, 320, 240
+    ctx.set_params(p)
+    k, d = ctx.orb_detect_compute(img, slot=0, cap=20000)
+    ok, od = orc.orb_detect_compute(p, img, cap=20000)
+    assert len(ok) == 384 and len(np.unique(ok["response"])) == 1  # the oracle keeps every tie at the cut
+    assert len(k) == 384 and k.tobytes() == ok.tobytes() and (d == od).all()
+
+
+def test_ties_beyond_the_slack_are_reported(vislam, ctx):
+    """same image, quota 150: the 384 tied responses exceed keep_cap (200) -> VIS_E_CAPACITY, never a silent cut"""
     p = vislam.default_params()
     p.nlevels, p.nfeatures, p.w_size, p.h_size = 1, 150, 320, 240
     ctx.set_params(p)
-    try:
-        k, d = ctx.orb_detect_compute(img, slot=0, cap=20000)
-    except vislam.VisError as e:                                   # ties beyond the slack are reported, never silent
-        assert e.code == -4
-        return
-    ok, od = orc.orb_detect_compute(p, img, cap=20000)
-    assert k.tobytes() == ok.tobytes() and (d == od).all()
-    assert len(k) > 150                                            # ties kept beyond the quota
+    with pytest.raises(vislam.VisError) as ei:
+        ctx.orb_detect_compute(_checkerboard(), slot=0, cap=20000)
+    assert ei.value.code == -4
+    # the flag is cleared by the failed call: the context keeps working
+    q = vislam.default_params()
+    q.nlevels, q.nfeatures, q.w_size, q.h_size = 1, 360, 320, 240
+    ctx.set_params(q)
+    k, _ = ctx.orb_detect_compute(_checkerboard(), slot=0, cap=20000)
+    assert len(k) == 384
 
 
 def test_context_reuse_and_param_changes(vislam, orc, ctx, canvas):

@@ -41,6 +41,7 @@ extern "C" void vis_default_params(vis_params* p) {
     p->ransac_seed = 0xFFFFFFFFFFFFFFFFULL;
     p->fx = 458.654; p->fy = 457.296; p->cx = 367.215; p->cy = 248.375;     // calibrationEUROC.xml:20
     p->f2f_iters = 1000; p->f2f_threshold = 370.0;
+    p->pose_input = VIS_POSE_GOOD;
 }
 
 static int validate_params(const vis_params& p) {
@@ -53,6 +54,7 @@ static int validate_params(const vis_params& p) {
     if (p.ransac_max_iters < 1 || p.ransac_max_iters > 100000) return VIS_E_INVALID;
     if (!(p.ransac_prob > 0 && p.ransac_prob < 1) || !(p.fx > 0) || !(p.fy > 0)) return VIS_E_INVALID;
     if (p.f2f_iters < 0) return VIS_E_INVALID;
+    if (p.pose_input != VIS_POSE_GOOD && p.pose_input != VIS_POSE_SYM) return VIS_E_INVALID;
     return VIS_OK;
 }
 
@@ -210,6 +212,10 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
     pl->kcap = kcap;
     std::vector<float> hf, wf; vis_grid_limits(ctx->p, &pl->root, hf, wf);
     const int ncell = pl->root * pl->root;
+    // correspondences per pair the pose stage sees: the grid-filtered good matches (reference pipeline) or every symmetric match
+    const int mcap = ctx->p.pose_input == VIS_POSE_SYM ? kcap : ncell;
+    if (mcap > VIS_RANSAC_MAX_M) { delete pl; return VIS_E_INVALID; }
+    pl->pose_mcap = mcap;
     pl->max_iters = ctx->p.ransac_max_iters;
     DALLOC(pl->d_stage, (size_t)stride * h);
     for (int l = 1; l < L; l++) {
@@ -241,14 +247,14 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
     DALLOC(pl->d_knn12, (size_t)npairs * kcap * 2); DALLOC(pl->d_knn21, (size_t)npairs * kcap * 2);
     DALLOC(pl->d_sym, (size_t)npairs * kcap); DALLOC(pl->d_nsym, npairs);
     DALLOC(pl->d_good, (size_t)npairs * ncell); DALLOC(pl->d_ngood, npairs);
-    DALLOC(pl->d_p1, (size_t)npairs * ncell * 2); DALLOC(pl->d_p2, (size_t)npairs * ncell * 2);
+    DALLOC(pl->d_p1, (size_t)npairs * mcap * 2); DALLOC(pl->d_p2, (size_t)npairs * mcap * 2);
     DALLOC(pl->d_hf, pl->root); DALLOC(pl->d_wf, pl->root);
     HIPCHK(ctx, hipMemcpy(pl->d_hf, hf.data(), (size_t)pl->root * 4, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(pl->d_wf, wf.data(), (size_t)pl->root * 4, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemset(pl->d_nsym, 0, (size_t)npairs * 4));
     HIPCHK(ctx, hipMemset(pl->d_ngood, 0, (size_t)npairs * 4));
-    DALLOC(pl->d_n1, (size_t)npairs * ncell * 2); DALLOC(pl->d_n2, (size_t)npairs * ncell * 2);
-    DALLOC(pl->d_mask, (size_t)npairs * ncell);
+    DALLOC(pl->d_n1, (size_t)npairs * mcap * 2); DALLOC(pl->d_n2, (size_t)npairs * mcap * 2);
+    DALLOC(pl->d_mask, (size_t)npairs * mcap);
     DALLOC(pl->d_samples, (size_t)npairs * pl->max_iters * 5);
     DALLOC(pl->d_models, (size_t)npairs * pl->max_iters * 90);
     DALLOC(pl->d_counts, (size_t)npairs * pl->max_iters * 10);
@@ -264,10 +270,11 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
     HIPCHK(ctx, hipMemset(pl->d_worklist, 0, ((size_t)npairs + 1) * sizeof(int32_t)));
     HIPCHK(ctx, hipMemset(pl->d_knn12, 0xFF, (size_t)npairs * kcap * 2 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMemset(pl->d_knn21, 0xFF, (size_t)npairs * kcap * 2 * sizeof(uint32_t)));
-    HIPCHK(ctx, hipMemset(pl->d_p1, 0, (size_t)npairs * ncell * 2 * sizeof(float)));
-    HIPCHK(ctx, hipMemset(pl->d_p2, 0, (size_t)npairs * ncell * 2 * sizeof(float)));
+    HIPCHK(ctx, hipMemset(pl->d_p1, 0, (size_t)npairs * mcap * 2 * sizeof(float)));
+    HIPCHK(ctx, hipMemset(pl->d_p2, 0, (size_t)npairs * mcap * 2 * sizeof(float)));
     HIPCHK(ctx, hipMemset(pl->d_pose, 0, (size_t)npairs * sizeof(PoseOut)));
-    { int rc2 = vis_build_sample_table(ctx, ncell); if (rc2) { plan_destroy(pl); return rc2; } }
+    // cv::RNG sample tables only for small M (the reference pipeline: M <= root^2); larger M replays the stream on the device
+    { int rc2 = vis_build_sample_table(ctx, std::min(mcap, 1024)); if (rc2) { plan_destroy(pl); return rc2; } }
     *out = pl;
     return VIS_OK;
 }
@@ -277,7 +284,7 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
 int vis_build_sample_table(vis_ctx* ctx, int max_m) {
     const int iters = ctx->p.ransac_max_iters;
     if (ctx->d_sample_table && ctx->sample_max_m >= max_m && ctx->sample_iters == iters && ctx->sample_seed == ctx->p.ransac_seed) return VIS_OK;
-    if (ctx->d_sample_table) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->d_sample_table); ctx->d_sample_table = nullptr; ctx->sample_max_m = 0; }
+    if (ctx->d_sample_table) { sync_all(ctx); (void)hipFree(ctx->d_sample_table); ctx->d_sample_table = nullptr; ctx->sample_max_m = 0; }
     if (max_m < 6 || (size_t)(max_m - 5) * iters * 5 * 4 > ((size_t)256 << 20)) return VIS_OK;     // no table: device replay
     std::vector<int32_t> tab((size_t)(max_m - 5) * iters * 5);
     for (int M = 6; M <= max_m; M++) {
@@ -305,23 +312,23 @@ int vis_build_sample_table(vis_ctx* ctx, int max_m) {
 
 int launch_pose(vis_ctx* ctx, Plan* pl, int npairs) {
     if (npairs <= 0) return VIS_OK;
-    return pose_run(ctx, npairs, pl->root * pl->root, pl->max_iters, pl->d_p1, pl->d_p2, pl->d_ngood, pl->d_n1, pl->d_n2,
+    return pose_run(ctx, npairs, pl->pose_mcap, pl->max_iters, pl->d_p1, pl->d_p2,
+                    ctx->p.pose_input == VIS_POSE_SYM ? pl->d_nsym : pl->d_ngood, pl->d_n1, pl->d_n2,
                     pl->d_samples, pl->d_models, pl->d_counts, pl->d_rstate, nullptr, pl->d_mask, pl->d_pose, 1, 1, pl->d_worklist, pl->d_hyp);
 }
 
-static int ensure_scratch(vis_ctx* ctx, size_t bytes) {
+// grow-only scratch of the host-pointer entry points.  Every stream of the context is drained before the old block is
+// freed: batch work queued on the matcher / pose streams may still read buffers carved from it.
+int vis_ensure_scratch(vis_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->scratch_bytes) return VIS_OK;
-    (void)hipStreamSynchronize(ctx->stream);
+    sync_all(ctx);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     ctx->d_scratch = nullptr; ctx->scratch_bytes = 0;
     HIPCHK(ctx, hipMalloc(&ctx->d_scratch, bytes));
     ctx->scratch_bytes = bytes;
     return VIS_OK;
 }
-struct Carver {
-    char* base; size_t off;
-    template <class T> T* take(size_t count) { off = (off + 255) & ~(size_t)255; T* p = (T*)(base + off); off += count * sizeof(T); return p; }
-};
+static inline int ensure_scratch(vis_ctx* ctx, size_t bytes) { return vis_ensure_scratch(ctx, bytes); }
 
 static int ensure_single(vis_ctx* ctx, int w, int h) {
     (void)hipSetDevice(ctx->device);

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void k_filter(const vis_keypoint* __restrict__
                                                 const float* __restrict__ hf, const float* __restrict__ wf,
                                                 vis_dmatch* __restrict__ sym_out, int32_t* __restrict__ nsym_out,
                                                 vis_dmatch* __restrict__ good_out, int32_t* __restrict__ ngood_out,
-                                                float* __restrict__ p1, float* __restrict__ p2, int keys_cap) {
+                                                float* __restrict__ p1, float* __restrict__ p2, int keys_cap, int pose_mcap, int pose_sym) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
     uint32_t* cell = reinterpret_cast<uint32_t*>(smem + (size_t)keys_cap * 8);
@@ -287,6 +287,15 @@ __global__ __launch_bounds__(256) void k_filter(const vis_keypoint* __restrict__
     }
     int P2 = 2; while (P2 < nsym) P2 <<= 1;
     __syncthreads();
+    if (pose_sym) {                                                // VIS_POSE_SYM: the pose stage takes every symmetric match
+        float* q1 = p1 + (size_t)pair * pose_mcap * 2;
+        float* q2 = p2 + (size_t)pair * pose_mcap * 2;
+        for (int i = tid; i < min(nsym, pose_mcap); i += 256) {
+            const vis_dmatch m = sym[i];
+            q1[2 * i] = K1[m.queryIdx].x; q1[2 * i + 1] = K1[m.queryIdx].y;
+            q2[2 * i] = K2[m.trainIdx].x; q2[2 * i + 1] = K2[m.trainIdx].y;
+        }
+    }
     for (int i = nsym + tid; i < P2; i += 256) keys[i] = ~0ull;
     for (int i = tid; i < ncell; i += 256) cell[i] = 0xFFFFFFFFu;
     __syncthreads();
@@ -326,8 +335,10 @@ __global__ __launch_bounds__(256) void k_filter(const vis_keypoint* __restrict__
             if (v == 0xFFFFFFFFu) continue;
             const vis_dmatch m = sym[(uint32_t)keys[v & 0xFFFF]];
             good[n] = m;
-            q1[2 * n] = K1[m.queryIdx].x; q1[2 * n + 1] = K1[m.queryIdx].y;     // getGoodMatches
-            q2[2 * n] = K2[m.trainIdx].x; q2[2 * n + 1] = K2[m.trainIdx].y;
+            if (!pose_sym) {
+                q1[2 * n] = K1[m.queryIdx].x; q1[2 * n + 1] = K1[m.queryIdx].y;     // getGoodMatches
+                q2[2 * n] = K2[m.trainIdx].x; q2[2 * n + 1] = K2[m.trainIdx].y;
+            }
             n++;
         }
         ngood_out[pair] = n;
@@ -373,7 +384,8 @@ int launch_filter(vis_ctx* ctx, Plan* pl, int npairs) {
     hipLaunchKernelGGL(k_filter, dim3(npairs), dim3(256), lds, ctx->stream, pl->d_kps, pl->d_nkp, pl->kcap,
                        pl->d_pair_q, pl->d_pair_t, pl->d_knn12, pl->d_knn21, (double)ctx->p.ratio, ctx->p.sym_mode,
                        pl->root, pl->d_hf, pl->d_wf, pl->d_sym, pl->d_nsym, pl->d_good, pl->d_ngood,
-                       pl->d_p1, pl->d_p2, keys_cap);
+                       pl->d_p1, pl->d_p2, keys_cap, pl->pose_mcap ? pl->pose_mcap : pl->root * pl->root,
+                       (pl->pose_mcap && ctx->p.pose_input == VIS_POSE_SYM) ? 1 : 0);
     HIPCHK(ctx, hipGetLastError());
     return VIS_OK;
 }

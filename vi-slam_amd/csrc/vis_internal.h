@@ -37,6 +37,7 @@ struct Plan {
     int kcap = 0;                // keypoints per record (sum of keep_cap)
     int npairs = 0;              // pair result capacity
     int root = 0;                // grid root
+    int pose_mcap = 0;           // correspondences per pair the pose stage is sized for (root^2, or kcap with VIS_POSE_SYM)
     LevelInfo lv[VIS_MAX_LEVELS];
     // ---- device buffers
     uint8_t* d_stage = nullptr;              // single-frame upload staging (stride x h)
@@ -115,6 +116,13 @@ struct vis_ctx {
     do { hipError_t e_ = (call);                                                   \
          if (e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); \
                                  return VIS_E_HIP; } } while (0)
+
+// carve typed, 256-byte aligned pieces out of the context scratch block
+struct Carver {
+    char* base; size_t off;
+    template <class T> T* take(size_t count) { off = (off + 255) & ~(size_t)255; T* p = (T*)(base + off); off += count * sizeof(T); return p; }
+};
+int vis_ensure_scratch(vis_ctx* ctx, size_t bytes);
 
 // ---- host-side geometry / tables (geometry.cpp) ----
 int  vis_compute_levels(const vis_params& p, int w, int h, int stride0, LevelInfo* lv);

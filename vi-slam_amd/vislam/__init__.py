@@ -45,12 +45,33 @@ class Params(C.Structure):
         ("ransac_max_iters", C.c_int32), ("ransac_adaptive", C.c_int32), ("ransac_seed", C.c_uint64),
         ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
         ("f2f_iters", C.c_int32), ("f2f_threshold", C.c_double),
+        ("pose_input", C.c_int32), ("reserved_", C.c_int32),
     ]
 
     def copy(self):
         p = Params()
         C.memmove(C.byref(p), C.byref(self), C.sizeof(Params))
         return p
+
+
+class Se3f(C.Structure):
+    """Sophus::SE3f storage order: unit quaternion (x, y, z, w) + translation"""
+    _fields_ = [("qx", C.c_float), ("qy", C.c_float), ("qz", C.c_float), ("qw", C.c_float),
+                ("tx", C.c_float), ("ty", C.c_float), ("tz", C.c_float)]
+
+    def as_array(self):
+        return np.array([self.qx, self.qy, self.qz, self.qw, self.tx, self.ty, self.tz], np.float32)
+
+
+class AlignParams(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("first_level", C.c_int32), ("last_level", C.c_int32), ("max_iterations", C.c_int32),
+                ("epsilon", C.c_float), ("z_factor", C.c_float)]
+
+
+class AlignResult(C.Structure):
+    _fields_ = [("pose", Se3f), ("matrix", C.c_float * 16), ("error", C.c_float * 5), ("initial_error", C.c_float),
+                ("iterations", C.c_int32 * 5), ("n_residuals", C.c_int32 * 5)]
 
 
 class Timings(C.Structure):
@@ -80,6 +101,7 @@ ABI_SYMBOLS = [
     "vis_gradient_frame_elems", "vis_gradient_batch", "vis_compute_gradient", "vis_patch_points",
     "vis_image_list", "vis_image_time", "vis_pgm_info", "vis_image_read",
     "vis_feeder_create", "vis_feeder_destroy", "vis_feeder_host_buffer", "vis_feeder_submit", "vis_feeder_release",
+    "vis_default_align_params", "vis_estimate_pose_features", "vis_align_batch", "vis_batch_align",
 ]
 
 
@@ -142,6 +164,12 @@ def _load():
     lib.vis_feeder_host_buffer.restype = C.c_void_p
     lib.vis_feeder_submit.argtypes = [vp, ci, ci, C.POINTER(C.c_void_p)]
     lib.vis_feeder_release.argtypes = [vp, ci]
+    lib.vis_default_align_params.argtypes = [C.POINTER(AlignParams)]
+    lib.vis_default_align_params.restype = None
+    pv = C.POINTER(C.c_void_p)
+    lib.vis_estimate_pose_features.argtypes = [vp, C.POINTER(AlignParams), ci, ci, pv, pv, pv, pv, pv, ip, C.POINTER(Se3f), C.POINTER(AlignResult)]
+    lib.vis_align_batch.argtypes = [vp, C.POINTER(AlignParams), vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp]
+    lib.vis_batch_align.argtypes = [vp, C.POINTER(AlignParams), vp, ci, vp, vp, vp, vp, vp]
     return lib
 
 
@@ -168,6 +196,12 @@ def default_params():
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def default_align_params():
+    ap = AlignParams()
+    lib.vis_default_align_params(C.byref(ap))
+    return ap
 
 
 # ---- synthetic stream (host-side utility of the library; integer-only, bit-reproducible) ----------
@@ -335,6 +369,34 @@ class Context:
         npt = (C.c_int * 5)(); ndb = (C.c_int * 5)()
         self._chk(lib.vis_patch_points(self._h, _ptr(good), len(good), cap, ap, npt, ad, ndb), "vis_patch_points")
         return [patch[l][:npt[l]].copy() for l in range(5)], [debug[l][:ndb[l]].copy() for l in range(5)]
+
+    # -- VISystem::EstimatePoseFeatures (src/VISystem.cpp:1113-1448) ------------------------------------------
+    def estimate_pose_features(self, ap, w, h, gray1, gray2, gx1, gy1, cand1, init=None):
+        """one pair, host arrays: per-level lists (None for unused levels) -> AlignResult"""
+        def lv(arrs, dt):
+            keep = [None if a is None else np.ascontiguousarray(a, dt) for a in arrs]
+            keep += [None] * (5 - len(keep))
+            return keep, (C.c_void_p * 5)(*[None if a is None else a.ctypes.data for a in keep])
+        k1, a1 = lv(gray1, np.uint8); k2, a2 = lv(gray2, np.uint8); k3, a3 = lv(gx1, np.int16); k4, a4 = lv(gy1, np.int16)
+        k5, a5 = lv(cand1, np.float32)
+        n = (C.c_int * 5)(*[0 if c is None else len(c) for c in k5])
+        res = AlignResult()
+        self._chk(lib.vis_estimate_pose_features(self._h, C.byref(ap), w, h, a1, a2, a3, a4, a5, n,
+                                                 None if init is None else C.byref(init), C.byref(res)), "vis_estimate_pose_features")
+        return res
+
+    def align_batch(self, ap, d_frames_ptr, w, h, stride, n, d_gray_ptr, d_gx_ptr, d_gy_ptr, d_pts_ptr, d_npts_ptr, max_pts,
+                    d_init_ptr, d_out_ptr):
+        """device pointers; asynchronous on the context's stream"""
+        self._chk(lib.vis_align_batch(self._h, C.byref(ap), C.c_void_p(d_frames_ptr), w, h, stride, n, C.c_void_p(d_gray_ptr),
+                                      C.c_void_p(d_gx_ptr), C.c_void_p(d_gy_ptr), C.c_void_p(d_pts_ptr), C.c_void_p(d_npts_ptr), max_pts,
+                                      C.c_void_p(d_init_ptr) if d_init_ptr else None, C.c_void_p(d_out_ptr)), "vis_align_batch")
+
+    def batch_align(self, ap, d_frames_ptr, n, d_gray_ptr, d_gx_ptr, d_gy_ptr, d_init_ptr, d_out_ptr):
+        """alignment of the pairs of the last batch_run, matched points taken from the plan; asynchronous"""
+        self._chk(lib.vis_batch_align(self._h, C.byref(ap), C.c_void_p(d_frames_ptr), n, C.c_void_p(d_gray_ptr), C.c_void_p(d_gx_ptr),
+                                      C.c_void_p(d_gy_ptr), C.c_void_p(d_init_ptr) if d_init_ptr else None, C.c_void_p(d_out_ptr)),
+                  "vis_batch_align")
 
     # -- CameraGPU::detectAndComputeGPUFeatures ---------------------------------------------------------
     def orb_detect_compute(self, img, slot=0, cap=None):
