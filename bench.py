@@ -4,12 +4,22 @@
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it
 under torch.distributed.run, one rank per GPU.  One JSON line on rank 0.
 
-Workload (BASELINE.json configs[1]): synthetic 752x480 mono8 EuRoC-shaped stream ("S-752", integer-only
-generator, see vi-slam_amd/csrc/geometry.cpp), ORB 1000 keypoints x 8 levels, BF-Hamming k=2 both
-directions + ratio/symmetry/grid filter, essential RANSAC + recoverPose.  A "step" = one pass of the
-whole hot path over one batch of B consecutive frames that are already resident in HBM.
-Multi-GPU (configs[3]): rank r processes its own stream (seed + r); the only collective is one
-broadcast of the parameter/intrinsics struct from rank 0 (RCCL); scaling is weak.
+Headline workload (BASELINE.json configs[1]): synthetic 752x480 mono8 EuRoC-shaped stream ("S-752", integer-only
+generator, vi-slam_amd/csrc/synth_core.h), ORB 1000 keypoints x 8 levels, BF-Hamming k=2 both directions +
+ratio/symmetry/grid filter, essential RANSAC + recoverPose.  A "step" = one pass of the whole hot path over one batch of
+B consecutive frames that are already resident in HBM.
+Multi-GPU (configs[3]): rank r processes its own stream (seed + r); the only collective is one broadcast of the
+parameter/intrinsics struct from rank 0 (RCCL); scaling is weak.
+
+Beside `value` the line carries (rank 0, N = 1 only, all OUTSIDE the timed region of `value`):
+  legs.s752_fixed1000   the same stream with ransac_adaptive = 0: 1000 hypotheses per pair (the pose kernels loaded)
+  legs.s752_parallax    "S-752P": two depth layers + independently moving objects (adaptive RANSAC does real work)
+  legs.s752_results_d2h the headline step + a pinned, overlapped D2H copy of poses and good matches every step
+  legs.config3_s1080    BASELINE configs[2]: 1920x1080, 4 levels, 4000 kps, RANSAC 2000 fixed iterations on the symmetric matches
+  legs.config5_s2160    BASELINE configs[4]: 3840x2160, 8000 kps, 8000 x 8000 all-pairs
+  legs.align_n4         SURVEY 8(f) N4: half pyramid + gradients + batched Gauss-Newton photometric alignment
+  cpu_baseline*         the oracle ('port' of the reference CPU path) on the host cores: config 2 single thread,
+                        config 1 (ORB::create(200), first frames of S-752), and frame-parallel on all cores
 """
 import argparse
 import ctypes as C
@@ -29,11 +39,7 @@ from vislam import dist as vdist  # noqa: E402
 
 W, H, NFEAT, LEVELS = 752, 480, 1000, 8
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy)
-
-
-def level_pixels(ctx):
-    ws, hs, sc, q = ctx.level_geometry(W, H)
-    return [int(a) * int(b) for a, b in zip(ws, hs)]
+FAM = ("ms_pyramid", "ms_fast", "ms_select", "ms_describe", "ms_knn", "ms_filter", "ms_pose", "ms_total")
 
 
 def algorithmic_bytes(px, n):
@@ -47,21 +53,132 @@ def algorithmic_bytes(px, n):
     }
 
 
-def make_frames(seed, count):
-    canvas = vislam.synth_canvas(4096, seed)
-    fr = np.empty((count, H, W), np.uint8)
-    for t in range(count):
-        vislam.synth_frame(canvas, t, W, H, seed, out=fr[t])
-    return fr
+class Stream:
+    """B*R frames of a synthetic stream generated on the device (byte-identical to the host generator,
+    tests/test_synth_gpu.py), so no rank spends host time or PCIe on frame synthesis."""
+
+    def __init__(self, ctx, dev, w, h, count, seed, canvas_dim=4096, parallax=False):
+        self.w, self.h, self.count = w, h, count
+        self.canvas = vislam.synth_canvas(canvas_dim, seed)
+        d_canvas = torch.from_numpy(self.canvas).to(dev)
+        self.frames = torch.empty((count, h, w), dtype=torch.uint8, device=dev)
+        step = 256
+        for t0 in range(0, count, step):
+            n = min(step, count - t0)
+            ctx.synth_frames_device(d_canvas.data_ptr(), canvas_dim, seed, t0, n, w, h, w, self.frames.data_ptr() + t0 * w * h, parallax)
+        torch.cuda.synchronize()
+        del d_canvas
+
+    def ptr(self, first):
+        return self.frames.data_ptr() + first * self.w * self.h
+
+    def host(self, n):
+        return self.frames[:n].cpu().numpy()
 
 
-def cpu_baseline(p, frames, budget_s=12.0):
+def timed_steps(ctx, stream, B, R, stages, steps, warmup, dist=None, dev=None, after_step=None):
+    def step(i):
+        ctx.batch_run(stream.ptr((i % R) * B), B, stages)
+        if after_step is not None:
+            after_step(i)
+    for i in range(warmup):
+        step(i)
+    ctx.batch_sync()
+    if ctx.batch_status() != 0:
+        raise RuntimeError("device capacity flag set during warm-up")
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    ctx.batch_sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if ctx.batch_status() != 0:
+        raise RuntimeError("device capacity flag set during the timed region")
+    return dt, step
+
+
+def family_times(ctx, step, nprof=6):
+    """per-kernel-family durations from HIP events on the library's streams, one batch in flight"""
+    fam = {k: 0.0 for k in FAM}
+    launches_fast = 1
+    for i in range(nprof):
+        step(i)
+        ctx.batch_sync()
+        t = ctx.timings()
+        for k in fam:
+            fam[k] += getattr(t, k) / nprof
+        launches_fast = t.launches_fast
+    return fam, launches_fast
+
+
+def pose_load(ctx, n):
+    """RANSAC load of the LAST batch: iterations, correspondences, candidate models"""
+    pose, good, ng = ctx.batch_results(n)
+    it = pose["iters_run"][1:].astype(np.int64)
+    return {"iters_run_mean": float(it.mean()), "iters_run_max": int(it.max()), "correspondences_mean": float(pose["n_points"][1:].mean()),
+            "pose_good_mean": float(pose["n_pose_good"][1:].mean()), "inliers_mean": float(pose["n_inliers"][1:].mean()),
+            "hypotheses": int(it.sum()), "point_evals": int((pose["n_models"].astype(np.int64) * pose["n_points"]).sum())}
+
+
+def kernel_rooflines(fam, launches_fast, px, nfeat, B, nlevels):
+    alg = algorithmic_bytes(px, nfeat)
+    out = {}
+    for key, (name, nl) in {"ms_fast": ("k_fast", launches_fast), "ms_pyramid": ("k_resize", max(nlevels - 1, 1)), "ms_describe": ("k_describe", 1)}.items():
+        if fam[key] <= 0:
+            continue
+        gbs = alg[name] * B / (fam[key] * 1e-3) / 1e9
+        out[name] = {"ms": round(fam[key], 4), "launches": nl, "algorithmic_bytes_per_frame": alg[name], "GBps": gbs, "frac": gbs / HBM_PEAK_GBS}
+    tot = fam["ms_pyramid"] + fam["ms_fast"] + fam["ms_select"] + fam["ms_describe"]
+    out["detect_describe_GBps"] = alg["total_detect_describe"] * B / (tot * 1e-3) / 1e9
+    return out, alg
+
+
+def run_leg(dev, w, h, B, R, params, seed, canvas_dim, steps, warmup, stages=vislam.STAGE_ALL, parallax=False, want_pose=True, d2h=False):
+    ctx = vislam.Context(dev.index or 0, params)
+    try:
+        st = Stream(ctx, dev, w, h, B * R, seed, canvas_dim, parallax)
+        ctx.batch_plan(w, h, w, B)
+        after = None
+        if d2h:
+            root2 = int(np.floor(np.sqrt(params.n_cells))) ** 2
+            hp = torch.empty(B * C.sizeof(vislam.PoseResult), dtype=torch.uint8).pin_memory()
+            hg = torch.empty(B * root2 * 16, dtype=torch.uint8).pin_memory()
+            hn = torch.empty(B, dtype=torch.int32).pin_memory()
+            after = lambda i: ctx.batch_results_async(hp.data_ptr(), hg.data_ptr(), hn.data_ptr())   # noqa: E731
+        dt, step = timed_steps(ctx, st, B, R, stages, steps, warmup, after_step=after)
+        fam, lf = family_times(ctx, step, 4)
+        ws, hs, sc, q = ctx.level_geometry(w, h)
+        px = [int(a) * int(b) for a, b in zip(ws, hs)]
+        roof, alg = kernel_rooflines(fam, lf, px, params.nfeatures, B, params.nlevels)
+        out = {"frames_per_step": B, "steps": steps, "ms_per_step": dt / steps * 1e3, "frames_per_s": B * steps / dt,
+               "kernels_ms_per_step": {k: round(v, 4) for k, v in fam.items()}, "kernels": roof}
+        if want_pose and (stages & vislam.STAGE_POSE):
+            step(0); ctx.batch_sync()
+            pl = pose_load(ctx, B)
+            ms_pose = ctx.timings().ms_pose
+            pl["ms_pose_per_step"] = ms_pose
+            pl["hypotheses_per_s"] = pl["hypotheses"] / (ms_pose * 1e-3) if ms_pose > 0 else None
+            pl["point_evals_per_s"] = pl["point_evals"] / (ms_pose * 1e-3) if ms_pose > 0 else None
+            out["ransac"] = pl
+        return out
+    finally:
+        ctx.close()
+        torch.cuda.empty_cache()
+
+
+def cpu_baseline(p, frames, budget_s, what):
     """oracle ('port' of the reference CPU path) timed on this host, 1 thread, bounded sample"""
     import oracle_bind as orc
     prev = None
     n = 0
-    # 3 warm-up frames, then as many as fit the budget (at most len(frames))
-    for t in range(3):
+    for t in range(3):                                   # warm-up
         k, d, r = orc.pipeline_frame(p, frames[t], prev)
         prev = (k, d)
     t0 = time.perf_counter()
@@ -73,8 +190,8 @@ def cpu_baseline(p, frames, budget_s=12.0):
             break
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n} consecutive S-752 frames (752x480, N=1000, 8 levels), oracle pipeline_frame: Camera::Update + ORB + knn x2 + "
-                      f"filters + essential RANSAC + recoverPose, g++ -O2, 1 thread; host has {os.cpu_count()} logical CPUs"}
+            "sample": f"{n} consecutive S-752 frames ({what}), oracle pipeline_frame: Camera::Update + ORB + knn x2 + filters + essential RANSAC + "
+                      f"recoverPose, g++ -O2, 1 thread; host has {os.cpu_count()} logical CPUs"}
 
 
 def main():
@@ -85,6 +202,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="frames per step (per GPU)")
     ap.add_argument("--ring", type=int, default=2, help="distinct batches resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the side legs (profiling runs)")
     ap.add_argument("--stages", type=int, default=vislam.STAGE_ALL, help="debug: bitmask of stages (1 detect, 2 match, 4 pose); the reported metric needs all 7")
     a = ap.parse_args()
 
@@ -111,59 +229,31 @@ def main():
 
     ctx = vislam.Context(local_rank if world > 1 else 0, p)
     B, R = a.batch, a.ring
-    frames = make_frames(vdist.stream_seed(rank, world), B * R)
-    dframes = torch.from_numpy(frames).to(dev)
+    seed = vdist.stream_seed(rank, world)
+    stream = Stream(ctx, dev, W, H, B * R, seed)          # generated on the device: no host synthesis, no H2D
     ctx.batch_plan(W, H, W, B)
-    fbytes = W * H
-
-    def step(i):
-        ctx.batch_run(dframes.data_ptr() + (i % R) * B * fbytes, B, a.stages)
-
-    for i in range(a.warmup):
-        step(i)
-    ctx.batch_sync()
-    if ctx.batch_status() != 0:
-        raise RuntimeError("device capacity flag set during warm-up")
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(a.warmup + i)
-    ctx.batch_sync()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt, step = timed_steps(ctx, stream, B, R, a.stages, a.steps, a.warmup, dist, dev)
     dt = vdist.max_over_ranks(dt, dist, dev)
-    if ctx.batch_status() != 0:
-        raise RuntimeError("device capacity flag set during the timed region")
 
-    # ---- per-kernel-family durations from HIP events on the library's stream (outside the timed region)
-    fam = {k: 0.0 for k in ("ms_pyramid", "ms_fast", "ms_select", "ms_describe", "ms_knn", "ms_filter", "ms_pose", "ms_total")}
-    nprof = 8
-    launches_fast = LEVELS
-    for i in range(nprof):
-        step(i)
-        ctx.batch_sync()
-        t = ctx.timings()
-        for k in fam:
-            fam[k] += getattr(t, k) / nprof
-        launches_fast = t.launches_fast
+    fam, launches_fast = family_times(ctx, step, 8)
+    headline_pose = None
+    if rank == 0 and (a.stages & vislam.STAGE_POSE):
+        step(0); ctx.batch_sync()
+        headline_pose = pose_load(ctx, B)
+        headline_pose["ms_pose_per_step"] = ctx.timings().ms_pose
 
-    # ---- SURVEY 8(f) N2 (outside the timed region, not part of `value`): Camera::Update half pyramid +
-    # Camera::computeGradient over the same resident batch; pure streaming, reported against the HBM roofline
-    aux = None
-    if rank == 0:
+    # ---- SURVEY 8(f) N2 + N4 (outside the timed region, not part of `value`)
+    aux, legs = None, None
+    if rank == 0 and not a.no_legs:
+        aux, legs = {}, {}
         try:
             fe = vislam.gradient_frame_elems(W, H)
             gray = torch.empty(B * fe, dtype=torch.uint8, device=dev)
             gxb = torch.empty(B * fe, dtype=torch.int16, device=dev); gyb = torch.empty_like(gxb)
             gb = torch.empty(B * fe, dtype=torch.uint8, device=dev)
+            d0 = stream.ptr(0)
             def grad():
-                ctx.gradient_batch(dframes.data_ptr(), W, H, W, B, gray.data_ptr(), gxb.data_ptr(), gyb.data_ptr(), gb.data_ptr())
+                ctx.gradient_batch(d0, W, H, W, B, gray.data_ptr(), gxb.data_ptr(), gyb.data_ptr(), gb.data_ptr())
             for _ in range(3):
                 grad()
             torch.cuda.synchronize()
@@ -176,21 +266,44 @@ def main():
             pg = sum((W >> l) * (H >> l) for l in range(5))
             p_half = sum((W >> l) * (H >> l) for l in range(4)) + sum((W >> l) * (H >> l) for l in range(1, 5))
             gbytes = 6 * pg + p_half                     # gradient: 1 B read + 5 B written per pixel; pyramid: read 4 levels, write 4
-            aux = {"gradient_batch": {"what": "Camera::Update half pyramid + Camera::computeGradient (Scharr x/y int16 + blended u8), 5 levels",
-                                      "ms_per_batch": tg * 1e3, "frames": B, "algorithmic_bytes_per_frame": gbytes,
-                                      "achieved_GBps": gbytes * B / tg / 1e9, "peak_GBps": HBM_PEAK_GBS,
-                                      "frac": gbytes * B / tg / 1e9 / HBM_PEAK_GBS, "frames_per_s": B / tg}}
-            del gray, gxb, gyb, gb
-        except Exception as e:                            # never let the side measurement break the contract line
-            aux = {"gradient_batch": {"error": str(e)}}
-
-    # ---- SURVEY 8(f) N3 (outside the timed region, never `value`): the same pipeline fed from pinned HOST memory through
-    # the double-buffered feeder -- the PCIe-inclusive rate
-    if rank == 0 and aux is not None:
+            aux["gradient_batch"] = {"what": "Camera::Update half pyramid + Camera::computeGradient (Scharr x/y int16 + blended u8), 5 levels",
+                                     "ms_per_batch": tg * 1e3, "frames": B, "algorithmic_bytes_per_frame": gbytes,
+                                     "achieved_GBps": gbytes * B / tg / 1e9, "peak_GBps": HBM_PEAK_GBS,
+                                     "frac": gbytes * B / tg / 1e9 / HBM_PEAK_GBS, "frames_per_s": B / tg}
+            # N4: VISystem::EstimatePoseFeatures on every consecutive pair of the batch (good matches from the plan)
+            ctx.batch_reset()
+            ctx.batch_run(d0, B, vislam.STAGE_DETECT | vislam.STAGE_MATCH)
+            ctx.batch_sync()
+            outb = torch.empty(B * C.sizeof(vislam.AlignResult), dtype=torch.uint8, device=dev)
+            apar = vislam.default_align_params()
+            def align():
+                ctx.batch_align(apar, d0, B, gray.data_ptr(), gxb.data_ptr(), gyb.data_ptr(), 0, outb.data_ptr())
+            for _ in range(2):
+                align()
+            ctx.batch_sync(); torch.cuda.synchronize()
+            ta = time.perf_counter()
+            KA = 10
+            for _ in range(KA):
+                align()
+            ctx.batch_sync(); torch.cuda.synchronize()
+            ta = (time.perf_counter() - ta) / KA
+            raw = np.frombuffer(outb.cpu().numpy().tobytes(), dtype=np.uint8).reshape(B, -1)
+            its = np.frombuffer(raw[:, 28 + 64 + 20 + 4:28 + 64 + 20 + 4 + 20].tobytes(), np.int32).reshape(B, 5)
+            nres = np.frombuffer(raw[:, 28 + 64 + 20 + 4 + 20:].tobytes(), np.int32).reshape(B, 5)
+            evals = int(((its[:, :4] + 1) * nres[:, :4]).sum())        # iterations evaluated x residuals of the level
+            legs["align_n4"] = {"what": "VISystem::EstimatePoseFeatures (Gauss-Newton photometric alignment, levels 3..0, <= 10 iterations) on the "
+                                        f"{B - 1} consecutive pairs of one batch, one persistent workgroup per pair; inputs = the N2 stage outputs",
+                                "ms_per_batch": ta * 1e3, "pairs_per_s": (B - 1) / ta, "iterations_mean_per_level": [float(x) for x in its[1:, :4].mean(0)],
+                                "residual_evals_per_s": evals / ta}
+            del gray, gxb, gyb, gb, outb
+        except Exception as e:                            # never let a side measurement break the contract line
+            aux["gradient_batch_or_align"] = {"error": repr(e)}
+        # N3: the same pipeline fed from pinned HOST memory through the double-buffered feeder -- the PCIe-inclusive rate
         try:
+            hostf = stream.host(min(B * R, 2 * B))
             feed = vislam.Feeder(ctx, W, H, B)
             for k in range(2):
-                feed.host_buffer(k)[:] = frames[(k % R) * B:(k % R + 1) * B]
+                feed.host_buffer(k)[:] = hostf[(k % R) * B:(k % R + 1) * B]
             def fed_step(i):
                 k = i & 1
                 feed.host_buffer(k)                       # waits until the previous copy out of this buffer is done
@@ -210,11 +323,59 @@ def main():
             aux["host_fed_pipeline"] = {"what": "same step, frames copied from pinned host memory by the double-buffered feeder (H2D overlapped with compute)",
                                         "frames_per_s": B / tf, "ms_per_step": tf * 1e3, "h2d_GBps": B * W * H / tf / 1e9}
             feed.close()
+            del hostf
         except Exception as e:
-            aux["host_fed_pipeline"] = {"error": str(e)}
+            aux["host_fed_pipeline"] = {"error": repr(e)}
+
+    px = None
+    if rank == 0:
+        ws, hs, sc, q = ctx.level_geometry(W, H)
+        px = [int(x) * int(y) for x, y in zip(ws, hs)]
+    host_frames = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        host_frames = stream.host(min(B * R, max(400, 4 * (os.cpu_count() or 1) + 8)))
+    ctx.close()
+    del stream
+    torch.cuda.empty_cache()
+
+    # ---- the other configurations BASELINE.json names + the loaded-RANSAC / results-download variants of the headline
+    if rank == 0 and legs is not None and world == 1:
+        def guarded(name, fn):
+            try:
+                legs[name] = fn()
+            except Exception as e:
+                legs[name] = {"error": repr(e)}
+        q1 = p.copy(); q1.ransac_adaptive = 0
+        guarded("s752_fixed1000", lambda: dict(run_leg(dev, W, H, B, R, q1, vdist.SINGLE_SEED, 4096, 6, 2),
+                what="headline step with ransac_adaptive = 0: 1000 five-point hypotheses per frame pair, every candidate E scored on every match"))
+        guarded("s752_parallax", lambda: dict(run_leg(dev, W, H, B, R, p, vdist.SINGLE_SEED, 4096, 20, 3, parallax=True),
+                what="S-752P: two depth layers (1.5x parallax) + independently moving objects; adaptive RANSAC, same parameters as the headline"))
+        guarded("s752_results_d2h", lambda: dict(run_leg(dev, W, H, B, R, p, vdist.SINGLE_SEED, 4096, 20, 3, d2h=True, want_pose=False),
+                what="headline step + D2H of 1024 pose records (192 B), good matches (49 x 16 B) and counts into pinned memory every step, overlapped with the next step"))
+        q3 = vislam.default_params()
+        q3.nfeatures, q3.nlevels, q3.w_size, q3.h_size = 4000, 4, 1920, 1080
+        q3.fy = q3.fx
+        q3.ransac_adaptive, q3.ransac_max_iters, q3.pose_input = 0, 2000, 1
+        guarded("config3_s1080", lambda: dict(run_leg(dev, 1920, 1080, 32, 2, q3, 0xE0C00003, 8192, 5, 2),
+                what="BASELINE configs[2]: 1920x1080, 4-level pyramid, 4000 kps/frame, 4000x4000 knn both directions, essential RANSAC with a FIXED "
+                     "2000 iterations on the un-gridded symmetric matches (pose_input = SYM) + recoverPose; 32 frames per step"))
+        q5 = vislam.default_params()
+        q5.nfeatures, q5.nlevels, q5.w_size, q5.h_size = 8000, 8, 3840, 2160
+        q5.fy = q5.fx
+        def leg5():
+            r = run_leg(dev, 3840, 2160, 8, 2, q5, 0xE0C00005, 8192, 5, 2)
+            n5 = 8000
+            kn = r["kernels_ms_per_step"]["ms_knn"]
+            r["matcher"] = {"pairs_per_distance_matrix": n5 * n5, "valu_lane_ops_per_matrix": 16 * n5 * n5,
+                            "distance_matrices_per_s": 8 / (kn * 1e-3) if kn > 0 else None,
+                            "equivalent_popcount_lane_ops_per_s": 16.0 * n5 * n5 * 8 / (kn * 1e-3) if kn > 0 else None,
+                            "note": "one matrix serves both knn directions (the reference computes it twice); computed on the int8 matrix cores, "
+                                    "the lane-op figure is the xor+popcount work it replaces (SURVEY 8(d))"}
+            r["what"] = "BASELINE configs[4]: 3840x2160, 8 levels, 8000 kps/frame, 8000x8000 BF-Hamming all-pairs, filters, pose; 8 frames per step"
+            return r
+        guarded("config5_s2160", leg5)
 
     if rank == 0:
-        px = level_pixels(ctx)
         alg = algorithmic_bytes(px, NFEAT)
         fam_bytes = {"ms_fast": ("k_fast", alg["k_fast"], launches_fast), "ms_pyramid": ("k_resize", alg["k_resize"], LEVELS - 1),
                      "ms_describe": ("k_describe", alg["k_describe"], 1)}
@@ -226,56 +387,65 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/profile_workload.py, separate
         # FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE correction calibrated on a 256 MiB copy); measured at
         # profiles/pmc_traffic.json["batch_frames"] frames per launch and scaled linearly to this run's batch
-        traffic = None
+        traffic, valu, pmc_commit = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 pj = json.load(open(pmc))
+                pmc_commit = pj.get("measured_at_commit")
                 traffic = pj[kname]["hbm_bytes_per_launch"] * (B / pj["batch_frames"])
+                # the detect kernels are bound by integer VALU issue, not by bytes: instruction counts from the committed
+                # SQ_INSTS_VALU pass against (a) the issue rate of this kernel's own instruction mix measured by
+                # tools/valu_rates.hip and (b) the SIMD-32 issue peak of the guide (one wave64 VALU instruction per 2 cycles)
+                vi = pj["raw"][kname]["SQ_INSTS_VALU"]["mean"] * (B / pj["batch_frames"])
+                peak_mix = pj["valu_peak_measured"]["wave_insts_per_s"]
+                peak_issue = 256 * 4 * 2.4e9 / 2
+                valu = {"kernel": kname, "wave_insts_per_launch": vi, "achieved": vi / per_launch_s, "unit": "wave-instr/s",
+                        "peak_issue": peak_issue, "frac_of_issue_peak": vi / per_launch_s / peak_issue,
+                        "peak_measured_for_this_instruction_mix": peak_mix, "frac_of_mix_peak": vi / per_launch_s / peak_mix,
+                        "pmc_measured_at_commit": pmc_commit}
             except Exception:
-                traffic = None
+                pass
         fps = vdist.aggregate_fps(world, a.steps, B, dt)
-        # the detect/match kernels are bound by integer VALU issue, not by bytes: report that roofline too
-        # (instruction counts from the committed SQ_INSTS_VALU pass, peak measured by tools/valu_peak.hip)
-        valu = None
-        try:
-            pj = json.load(open(pmc))
-            vi = pj["raw"][kname]["SQ_INSTS_VALU"]["mean"] * (B / pj["batch_frames"])
-            peak = pj["valu_peak_measured"]["wave_insts_per_s"]
-            valu = {"kernel": kname, "wave_insts_per_launch": vi, "achieved": vi / per_launch_s, "peak": peak,
-                    "unit": "wave-instr/s", "frac": vi / per_launch_s / peak}
-        except Exception:
-            valu = None
         out = {
             "metric": "frames/sec detect+match+pose, 752x480 mono8", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "S-752: synthetic 752x480 mono8 EuRoC-shaped stream, 1000 ORB kps x 8 levels, BF-Hamming k=2 both "
-                                   "directions + ratio/sym/grid filter, essential RANSAC (adaptive, max 1000) + recoverPose",
+            "config": {"workload": "S-752: synthetic 752x480 mono8 EuRoC-shaped stream (frames resident in HBM), 1000 ORB kps x 8 levels, BF-Hamming k=2 "
+                                   "both directions + ratio/sym/grid filter, essential RANSAC (adaptive, max 1000) + recoverPose.  S-752 is a planar "
+                                   "crop under pure image translation: every grid match is an exact inlier, the adaptive stop ends RANSAC after "
+                                   "<= 4 hypotheses (see pose_load) and the recovered pose is degenerate; legs.s752_fixed1000 / legs.s752_parallax load "
+                                   "the pose kernels.  Results stay on the device inside the timed region (legs.s752_results_d2h adds the download); "
+                                   "Camera::Update's half pyramid is not part of the step (aux_kernels.gradient_batch), the CPU baseline includes it",
                        "frames_per_step_per_gpu": B, "parallelism": f"stream-per-gpu x{world}" if world > 1 else "single-gpu"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": per_launch_s * 1e3},
             "valu_roofline": valu,
+            "pose_load": headline_pose,
             "aux_kernels": aux,
+            "legs": legs,
             "kernels_ms_per_step": {k: round(v, 4) for k, v in fam.items()},
             "detect_describe_GBps": alg["total_detect_describe"] * B / ((fam["ms_pyramid"] + fam["ms_fast"] + fam["ms_select"] + fam["ms_describe"]) * 1e-3) / 1e9,
         }
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(p, frames)
-            # the same port frame-parallel on the host cores this GPU's share allows (OpenCV itself would
-            # run TBB inside its calls); informational, `cpu_baseline` stays the single-thread figure of the reference's own code
+        if host_frames is not None:
+            out["cpu_baseline"] = cpu_baseline(p, host_frames, 10.0, "752x480, N=1000, 8 levels: BASELINE configs[1]")
+            p200 = p.copy(); p200.nfeatures = 200
+            out["cpu_baseline_config1"] = cpu_baseline(p200, host_frames[:203], 8.0, "752x480, ORB::create(200) as the reference CPU main, src/Camera.cpp:127: "
+                                                       "BASELINE configs[0], synthetic stand-in for EuRoC MH_01 which is not in the image")
+            # the same port frame-parallel on ALL host cores (OpenCV itself would run TBB inside its calls);
+            # informational, `cpu_baseline` stays the single-thread figure of the reference's own single-threaded code
             try:
                 import oracle_bind as orc
-                th = max(1, min(16, os.cpu_count() or 1))
-                ns = min(len(frames), 24 * th)
-                sec, _ = orc.pipeline_stream_mt(p, frames[:ns], th)
+                th = max(1, os.cpu_count() or 1)
+                ns = min(len(host_frames), 4 * th)
+                sec, _ = orc.pipeline_stream_mt(p, host_frames[:ns], th)
                 out["cpu_baseline_multicore"] = {"value": ns / sec, "unit": "frames/s", "cores": th, "kind": "port",
-                                                 "sample": f"{ns} consecutive S-752 frames, frame-parallel std::thread pool over the same oracle pipeline"}
+                                                 "sample": f"{ns} consecutive S-752 frames, frame-parallel std::thread pool over the same oracle pipeline, "
+                                                           f"all {th} logical CPUs of the host (nproc = {os.cpu_count()})"}
             except Exception as e:
-                out["cpu_baseline_multicore"] = {"error": str(e)}
+                out["cpu_baseline_multicore"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -301,6 +301,19 @@ int  vis_batch_get_matches(vis_ctx* ctx, int frame, vis_dmatch* good, int cap, i
                            int* n_sym);
 int  vis_batch_get_pose(vis_ctx* ctx, int frame, double E[9], double R[9], double t[3],
                         int* n_inliers, int* n_pose_good, int* iters_run);
+/* what the pose stage leaves per pair on the device (vis_batch_results_async copies these records) */
+typedef struct vis_pose_result {
+    double E[9], R[9], t[3];
+    int32_t n_inliers, n_pose_good, iters_run, n_points;
+    int32_t n_models;          /* candidate essential matrices scored against the n_points correspondences (SURVEY 8(d):
+                                  point evaluations = n_models x n_points) */
+    int32_t reserved_;
+} vis_pose_result;
+/* Queue the device-to-host copy of the last batch's results -- n pose records, the good matches (n x root^2, dense
+ * rows) and their counts -- behind the batch's own work; any pointer may be NULL; pinned host memory makes the copy
+ * overlap the next vis_batch_run.  The reference downloads its results every frame (src/CameraGPU.cpp:103, the
+ * DMatch vectors of src/MatcherGPU.cpp:54-56); vis_batch_sync() (or the next vis_batch_results_async) completes it. */
+int  vis_batch_results_async(vis_ctx* ctx, vis_pose_result* h_pose, vis_dmatch* h_good, int32_t* h_ngood);
 /* device-side error/overflow flags of the last batch (0 = clean) */
 int  vis_batch_status(vis_ctx* ctx, int* flags);
 
@@ -309,6 +322,16 @@ int  vis_batch_status(vis_ctx* ctx, int* flags);
 int  vis_synth_canvas(uint8_t* canvas, int canvas_dim, uint64_t seed);
 int  vis_synth_frame(const uint8_t* canvas, int canvas_dim, uint64_t seed, int t,
                      int w, int h, uint8_t* out, int out_stride);
+/* "S-752P": the same stream with a second depth layer (1.5x parallax, same direction) and independently moving objects
+ * (outliers) on top of the static background: image motion that is NOT one planar shift, so the adaptive RANSAC stop
+ * does not trigger after a handful of hypotheses.  Same integer-only rule on host and device. */
+int  vis_synth_frame_parallax(const uint8_t* canvas, int canvas_dim, uint64_t seed, int t,
+                              int w, int h, uint8_t* out, int out_stride);
+/* n consecutive frames t0 .. t0+n-1 generated on the device into d_out (frame stride = stride*h); d_canvas = the canvas
+ * of vis_synth_canvas in device memory.  mode 0 = S-752, 1 = S-752P.  Byte-identical to the host generators.
+ * Asynchronous on the context's stream. */
+int  vis_synth_frames_device(vis_ctx* ctx, const uint8_t* d_canvas, int canvas_dim, uint64_t seed, int t0, int n,
+                             int w, int h, int stride, int mode, uint8_t* d_out);
 
 #ifdef __cplusplus
 }

@@ -84,6 +84,16 @@ def test_pattern_tables_identical():
     assert max(x * x + y * y for x, y in zip(v[0::2], v[1::2])) <= 18.4 ** 2     # rotated samples stay within +-18
 
 
+def test_parallax_stream_is_pinned(vislam):
+    """S-752P (second depth layer + independently moving objects): integer rule, pinned by hash; differs from S-752"""
+    import hashlib
+    cv = vislam.synth_canvas(512, 123)
+    f = vislam.synth_frame(cv, 5, 160, 120, 123, parallax=True)
+    assert hashlib.sha256(f.tobytes()).hexdigest() == "8477b2ab267587a01fbb2be9201c6ecb5fe7db8c3565fdad38c67c9befa3b25c"
+    g = vislam.synth_frame(cv, 5, 160, 120, 123)
+    assert 0.03 < float((f != g).mean()) < 0.5
+
+
 def test_synth_stream_is_bit_reproducible(vislam):
     import hashlib
     cv = vislam.synth_canvas(512, 123)

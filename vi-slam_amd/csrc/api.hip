@@ -81,6 +81,7 @@ extern "C" int vis_create(int device, vis_ctx** out) {
         hipEventCreateWithFlags(&ctx->ev_filter_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_pose_done, hipEventDefault) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_pose_start, hipEventDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_results_done, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->match_stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_detect_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_match_start, hipEventDefault) != hipSuccess ||
@@ -106,6 +107,7 @@ extern "C" void vis_destroy(vis_ctx* ctx) {
     if (ctx->ev_filter_done) (void)hipEventDestroy(ctx->ev_filter_done);
     if (ctx->ev_pose_done) (void)hipEventDestroy(ctx->ev_pose_done);
     if (ctx->ev_pose_start) (void)hipEventDestroy(ctx->ev_pose_start);
+    if (ctx->ev_results_done) (void)hipEventDestroy(ctx->ev_results_done);
     if (ctx->match_stream) { (void)hipStreamSynchronize(ctx->match_stream); (void)hipStreamDestroy(ctx->match_stream); }
     if (ctx->ev_detect_done) (void)hipEventDestroy(ctx->ev_detect_done);
     if (ctx->ev_match_start) (void)hipEventDestroy(ctx->ev_match_start);
@@ -118,7 +120,7 @@ static void sync_all(vis_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->match_stream) (void)hipStreamSynchronize(ctx->match_stream);
     if (ctx->pose_stream) (void)hipStreamSynchronize(ctx->pose_stream);
-    ctx->pose_pending = false;
+    ctx->pose_pending = false; ctx->results_pending = false;
     if (ctx->batch) ctx->batch->match_pending[0] = ctx->batch->match_pending[1] = false;
 }
 
@@ -803,6 +805,8 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
             if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[5], sM);
             // the filter rewrites the pose inputs of the previous batch: wait until its pose work is done
             if (ctx->pose_pending) { hipError_t e = hipStreamWaitEvent(sM, ctx->ev_pose_done, 0); if (e != hipSuccess) rc = VIS_E_HIP; }
+            // ... and until the previous batch's results have left the device
+            if (!rc && ctx->results_pending) { hipError_t e = hipStreamWaitEvent(sM, ctx->ev_results_done, 0); if (e != hipSuccess) rc = VIS_E_HIP; }
             if (!rc) rc = launch_filter(ctx, pl, n);
         }
         if (!rc && ctx->ev_ok) (void)hipEventRecord(ctx->ev[6], sM);
@@ -831,7 +835,7 @@ extern "C" int vis_batch_sync(vis_ctx* ctx) {
     if (ctx->match_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->match_stream));
     const bool had_pose = ctx->pose_pending;
     if (ctx->pose_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->pose_stream));
-    ctx->pose_pending = false;
+    ctx->pose_pending = false; ctx->results_pending = false;
     if (ctx->batch) ctx->batch->match_pending[0] = ctx->batch->match_pending[1] = false;
     if (ctx->ev_ok) {
         collect_detect_timings(ctx);
@@ -844,6 +848,23 @@ extern "C" int vis_batch_sync(vis_ctx* ctx) {
         if (hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[6]) == hipSuccess && a > ctx->tm.ms_total) ctx->tm.ms_total = a;
         if (had_pose && hipEventElapsedTime(&a, ctx->ev[0], ctx->ev_pose_done) == hipSuccess && a > ctx->tm.ms_total) ctx->tm.ms_total = a;
     }
+    return VIS_OK;
+}
+
+extern "C" int vis_batch_results_async(vis_ctx* ctx, vis_pose_result* h_pose, vis_dmatch* h_good, int32_t* h_ngood) {
+    if (!ctx || !ctx->batch) return VIS_E_STATE;
+    Plan* pl = ctx->batch;
+    const int n = pl->last_n;
+    if (n < 1) return VIS_E_STATE;
+    (void)hipSetDevice(ctx->device);
+    // the pose stream is ordered behind the matcher of the same batch (ev_filter_done); without a pose stage the matcher's own stream
+    hipStream_t s = ctx->pose_pending ? ctx->pose_stream : ctx->match_stream;
+    const int ncell = pl->root * pl->root;
+    if (h_pose) HIPCHK(ctx, hipMemcpyAsync(h_pose, pl->d_pose, (size_t)n * sizeof(vis_pose_result), hipMemcpyDeviceToHost, s));
+    if (h_good) HIPCHK(ctx, hipMemcpyAsync(h_good, pl->d_good, (size_t)n * ncell * sizeof(vis_dmatch), hipMemcpyDeviceToHost, s));
+    if (h_ngood) HIPCHK(ctx, hipMemcpyAsync(h_ngood, pl->d_ngood, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_results_done, s));
+    ctx->results_pending = true;
     return VIS_OK;
 }
 

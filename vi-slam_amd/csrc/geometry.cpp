@@ -6,6 +6,7 @@
 // /root/reference/src/Camera.cpp:87 (cv::ORB::detectAndCompute) -- see SURVEY.md Appendix A.1
 // items 2-3 -- and Matcher::bestMatchesFilter's window arithmetic (/root/reference/src/Matcher.cpp:171-216).
 #include "vis_internal.h"
+#include "synth_core.h"
 #include <cmath>
 #include <cstring>
 
@@ -112,25 +113,38 @@ extern "C" int vis_synth_canvas(uint8_t* canvas, int dim, uint64_t seed) {
     return VIS_OK;
 }
 
-extern "C" int vis_synth_frame(const uint8_t* canvas, int dim, uint64_t seed, int t,
-                               int w, int h, uint8_t* out, int out_stride) {
-    if (!canvas || !out || w < 1 || h < 1 || w >= dim || h >= dim || out_stride < w || t < 0) return VIS_E_INVALID;
+// origins of the layers at frame t (host side: the PRNG draws happen once per stream)
+int vis_synth_origin(int dim, uint64_t seed, int t, int w, int h, SynthOrigin* o) {
+    if (w < 1 || h < 1 || w >= dim || h >= dim || t < 0 || dim < 64) return VIS_E_INVALID;
     XorShift64s rng(seed ^ 0xD1B54A32D192ED03ULL);
     const int rx = dim - w, ry = dim - h;
     const int ox = (int)rng.below((uint32_t)rx), oy = (int)rng.below((uint32_t)ry);
-    const int x0 = (int)(((int64_t)ox + 12LL * t) % rx), y0 = (int)(((int64_t)oy + 8LL * t) % ry);
+    o->x0 = (int)(((int64_t)ox + 12LL * t) % rx); o->y0 = (int)(((int64_t)oy + 8LL * t) % ry);
+    // the layer offsets stay non-negative for every t < 2^20 so that >> 6 and / 48 are plain floor divisions
+    const int mx0 = (int)rng.below(4096), my0 = (int)rng.below(4096), ux0 = (int)rng.below(4096), uy0 = (int)rng.below(4096);
+    o->mx = mx0 + 18 * t; o->my = my0 + 12 * t;
+    o->ux = ux0 + 48 * 200000 - 7 * t; o->uy = uy0 + 15 * t;
+    return VIS_OK;
+}
+
+static int synth_frame_mode(const uint8_t* canvas, int dim, uint64_t seed, int t, int w, int h, uint8_t* out, int out_stride, int mode) {
+    if (!canvas || !out || out_stride < w) return VIS_E_INVALID;
+    SynthOrigin o;
+    const int rc = vis_synth_origin(dim, seed, t, w, h, &o);
+    if (rc) return rc;
     for (int y = 0; y < h; y++) {
-        const uint8_t* s = canvas + (size_t)(y0 + y) * dim + x0;
         uint8_t* d = out + (size_t)y * out_stride;
-        for (int x = 0; x < w; x++) {
-            // counter-based per-pixel noise in {-2..2} (splitmix64 finaliser)
-            uint64_t z = seed + 0x9E3779B97F4A7C15ULL * (((uint64_t)(uint32_t)t << 32) + (uint64_t)((uint32_t)y * (uint32_t)w + (uint32_t)x) + 1ULL);
-            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-            z ^= z >> 31;
-            int v = (int)s[x] + (int)(z % 5) - 2;
-            d[x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
-        }
+        for (int x = 0; x < w; x++) d[x] = synth_pixel(canvas, dim, seed, t, w, x, y, mode, o);
     }
     return VIS_OK;
+}
+
+extern "C" int vis_synth_frame(const uint8_t* canvas, int dim, uint64_t seed, int t,
+                               int w, int h, uint8_t* out, int out_stride) {
+    return synth_frame_mode(canvas, dim, seed, t, w, h, out, out_stride, 0);
+}
+
+extern "C" int vis_synth_frame_parallax(const uint8_t* canvas, int dim, uint64_t seed, int t,
+                                        int w, int h, uint8_t* out, int out_stride) {
+    return synth_frame_mode(canvas, dim, seed, t, w, h, out, out_stride, 1);
 }

@@ -169,8 +169,8 @@ struct PoseParams {
 };
 
 // rstate: [0] niters, [1] maxGood, [2] best hypothesis index (-1 none), [3] best model, [4] next iteration to scan,
-//         [5] special (1 = M==5 shortcut, 2 = M<5), [6] M, [7] iterations run
-#define RS 8
+//         [5] special (1 = M==5 shortcut, 2 = M<5), [6] M, [7] iterations run, [8] candidate models scored (all chunks)
+#define RS VIS_RSTATE_WORDS
 
 // getSubset (ptsetreg.cpp): 5 distinct indices in [0,M), redraw on duplicates, from the running cv::RNG
 DEV void draw_subset(CvRng& rng, int M, int* idx) {
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_pose_prep(PoseParams P, const float* __
     int32_t* rs = rstate + (size_t)pair * RS;
     int32_t* sm = samples + (size_t)pair * P.max_iters * 5;
     if (tid == 0) {
-        rs[1] = 0; rs[2] = -1; rs[3] = 0; rs[4] = 0; rs[6] = M; rs[7] = 0;
+        rs[1] = 0; rs[2] = -1; rs[3] = 0; rs[4] = 0; rs[6] = M; rs[7] = 0; rs[8] = 0;
         if (M < 5) { rs[0] = 0; rs[5] = 2; }
         else if (M == 5) { rs[0] = 1; rs[5] = 1; for (int k = 0; k < 5; k++) sm[k] = k; }
         else { rs[0] = max(P.max_iters, 1); rs[5] = 0; }
@@ -739,7 +739,10 @@ __global__ __launch_bounds__(256) void k_hyp_score(PoseParams P, int h0, int h_e
             sCnt[tid] = c;
         }
         __syncthreads();
-        if (tid == 0) { int t = 0; for (int k = 0; k < 16; k++) { sBase[k] = t; t += sCnt[k]; } sTotal = t; }
+        if (tid == 0) {
+            int t = 0; for (int k = 0; k < 16; k++) { sBase[k] = t; t += sCnt[k]; } sTotal = t;
+            if (t) atomicAdd(const_cast<int32_t*>(rstate) + (size_t)pair * RS + 8, t);   // point evaluations = models x M
+        }
         __syncthreads();
         if (valid) {
             int m = 0;
@@ -953,7 +956,7 @@ __global__ __launch_bounds__(256) void k_pose_final(PoseParams P, const double* 
         for (int i = 0; i < 9; i++) { o.E[i] = sE[i]; o.R[i] = 0; }
         o.t[0] = o.t[1] = o.t[2] = 0;
         o.n_inliers = E_in ? 0 : (have ? (rs[5] == 1 ? 5 : rs[1]) : 0);
-        o.iters_run = rs[7]; o.n_points = M; o.n_pose_good = 0;
+        o.iters_run = rs[7]; o.n_points = M; o.n_pose_good = 0; o.n_models = rs[8]; o.reserved_ = 0;
         if (do_pose && have) {
             const int* g = sgood;
             int sel;

@@ -26,10 +26,7 @@ struct LevelInfo {
 };
 
 // device-resident compact kNN entry: key = (dist << 16) | trainIdx, 0xFFFFFFFF = none
-struct PoseOut {
-    double E[9], R[9], t[3];
-    int n_inliers, n_pose_good, iters_run, n_points;
-};
+typedef vis_pose_result PoseOut;       // E, R, t (double) + n_inliers, n_pose_good, iters_run, n_points, n_models
 
 struct Plan {
     int w = 0, h = 0, stride = 0, B = 0, L = 0;
@@ -98,6 +95,7 @@ struct vis_ctx {
     hipStream_t match_stream = nullptr;      // knn + filters of batch i overlap the detect chain of batch i+1
     hipEvent_t ev_detect_done = nullptr, ev_match_start = nullptr, ev_match_done[2] = {nullptr, nullptr};
     bool pose_pending = false;
+    hipEvent_t ev_results_done = nullptr; bool results_pending = false;   // D2H of the last batch's results (vis_batch_results_async)
     vis_params p;
     std::string err;
     Plan* single = nullptr;
@@ -128,6 +126,9 @@ int vis_ensure_scratch(vis_ctx* ctx, size_t bytes);
 int  vis_compute_levels(const vis_params& p, int w, int h, int stride0, LevelInfo* lv);
 void vis_grid_limits(const vis_params& p, int* root, std::vector<float>& hf, std::vector<float>& wf);
 
+struct SynthOrigin;
+int  vis_synth_origin(int dim, uint64_t seed, int t, int w, int h, SynthOrigin* o);
+
 // ---- plan management (plan.hip) ----
 int  plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npairs, Plan** out, int nsets = 1);
 void plan_destroy(Plan* pl);
@@ -153,6 +154,6 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
 int  vis_build_sample_table(vis_ctx* ctx, int max_m);
 int f2f_run(vis_ctx* ctx, const vis_keypoint* d_pts1, const vis_keypoint* d_pts2, int m, const float* d_rot,
             const int32_t* d_idx, int iters, double* d_nv, float* d_counts);
-#define VIS_RSTATE_WORDS 8
+#define VIS_RSTATE_WORDS 12
 
 #endif

@@ -74,6 +74,16 @@ class AlignResult(C.Structure):
                 ("iterations", C.c_int32 * 5), ("n_residuals", C.c_int32 * 5)]
 
 
+class PoseResult(C.Structure):
+    _fields_ = [("E", C.c_double * 9), ("R", C.c_double * 9), ("t", C.c_double * 3), ("n_inliers", C.c_int32), ("n_pose_good", C.c_int32),
+                ("iters_run", C.c_int32), ("n_points", C.c_int32), ("n_models", C.c_int32), ("reserved_", C.c_int32)]
+
+
+POSE_RESULT_DTYPE = np.dtype([("E", "<f8", (9,)), ("R", "<f8", (9,)), ("t", "<f8", (3,)), ("n_inliers", "<i4"), ("n_pose_good", "<i4"),
+                              ("iters_run", "<i4"), ("n_points", "<i4"), ("n_models", "<i4"), ("reserved_", "<i4")])
+assert POSE_RESULT_DTYPE.itemsize == C.sizeof(PoseResult) == 192
+
+
 class Timings(C.Structure):
     _fields_ = [("ms_total", C.c_float), ("ms_pyramid", C.c_float), ("ms_fast", C.c_float),
                 ("ms_select", C.c_float), ("ms_describe", C.c_float), ("ms_knn", C.c_float),
@@ -102,6 +112,7 @@ ABI_SYMBOLS = [
     "vis_image_list", "vis_image_time", "vis_pgm_info", "vis_image_read",
     "vis_feeder_create", "vis_feeder_destroy", "vis_feeder_host_buffer", "vis_feeder_submit", "vis_feeder_release",
     "vis_default_align_params", "vis_estimate_pose_features", "vis_align_batch", "vis_batch_align",
+    "vis_synth_frame_parallax", "vis_synth_frames_device", "vis_batch_results_async",
 ]
 
 
@@ -164,6 +175,9 @@ def _load():
     lib.vis_feeder_host_buffer.restype = C.c_void_p
     lib.vis_feeder_submit.argtypes = [vp, ci, ci, C.POINTER(C.c_void_p)]
     lib.vis_feeder_release.argtypes = [vp, ci]
+    lib.vis_synth_frame_parallax.argtypes = [vp, ci, C.c_uint64, ci, ci, ci, vp, ci]
+    lib.vis_synth_frames_device.argtypes = [vp, vp, ci, C.c_uint64, ci, ci, ci, ci, ci, ci, vp]
+    lib.vis_batch_results_async.argtypes = [vp, vp, vp, vp]
     lib.vis_default_align_params.argtypes = [C.POINTER(AlignParams)]
     lib.vis_default_align_params.restype = None
     pv = C.POINTER(C.c_void_p)
@@ -275,10 +289,11 @@ def synth_canvas(dim=4096, seed=0xE0C00001):
     return cv
 
 
-def synth_frame(canvas, t, w=752, h=480, seed=0xE0C00001, out=None):
+def synth_frame(canvas, t, w=752, h=480, seed=0xE0C00001, out=None, parallax=False):
     if out is None:
         out = np.empty((h, w), np.uint8)
-    rc = lib.vis_synth_frame(_ptr(canvas), canvas.shape[0], C.c_uint64(seed), int(t), w, h, _ptr(out), out.strides[0])
+    fn = lib.vis_synth_frame_parallax if parallax else lib.vis_synth_frame
+    rc = fn(_ptr(canvas), canvas.shape[0], C.c_uint64(seed), int(t), w, h, _ptr(out), out.strides[0])
     if rc:
         raise VisError(rc, "vis_synth_frame")
     return out
@@ -315,6 +330,11 @@ class Context:
     def set_params(self, p):
         self._chk(lib.vis_set_params(self._h, C.byref(p)), "vis_set_params")
         self.params = p.copy()
+
+    def synth_frames_device(self, d_canvas_ptr, dim, seed, t0, n, w, h, stride, d_out_ptr, parallax=False):
+        """frames t0 .. t0+n-1 of the synthetic stream straight into device memory (asynchronous)"""
+        self._chk(lib.vis_synth_frames_device(self._h, C.c_void_p(d_canvas_ptr), dim, C.c_uint64(seed), t0, n, w, h, stride,
+                                              1 if parallax else 0, C.c_void_p(d_out_ptr)), "vis_synth_frames_device")
 
     def set_stream(self, raw_stream):
         self._chk(lib.vis_set_stream(self._h, C.c_void_p(raw_stream)), "vis_set_stream")
@@ -495,6 +515,20 @@ class Context:
 
     def batch_sync(self):
         self._chk(lib.vis_batch_sync(self._h), "vis_batch_sync")
+
+    def batch_results_async(self, h_pose_ptr=None, h_good_ptr=None, h_ngood_ptr=None):
+        """queue the D2H copy of the last batch's results (raw host pointers, ideally pinned); completed by batch_sync()"""
+        self._chk(lib.vis_batch_results_async(self._h, C.c_void_p(h_pose_ptr) if h_pose_ptr else None,
+                                              C.c_void_p(h_good_ptr) if h_good_ptr else None,
+                                              C.c_void_p(h_ngood_ptr) if h_ngood_ptr else None), "vis_batch_results_async")
+
+    def batch_results(self, n):
+        """synchronous convenience: (pose records, good matches n x root^2, counts) of the last batch"""
+        root2 = int(np.floor(np.sqrt(self.params.n_cells))) ** 2
+        pose = np.zeros(n, POSE_RESULT_DTYPE); good = np.zeros((n, root2), DMATCH_DTYPE); ng = np.zeros(n, np.int32)
+        self.batch_results_async(pose.ctypes.data, good.ctypes.data, ng.ctypes.data)
+        self.batch_sync()
+        return pose, good, ng
 
     def batch_status(self):
         f = C.c_int(0)
