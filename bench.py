@@ -161,8 +161,8 @@ def run_leg(dev, w, h, B, R, params, seed, canvas_dim, steps, warmup, stages=vis
                "kernels_ms_per_step": {k: round(v, 4) for k, v in fam.items()}, "kernels": roof}
         if want_pose and (stages & vislam.STAGE_POSE):
             step(0); ctx.batch_sync()
+            ms_pose = ctx.timings().ms_pose               # before the results download re-syncs the streams
             pl = pose_load(ctx, B)
-            ms_pose = ctx.timings().ms_pose
             pl["ms_pose_per_step"] = ms_pose
             pl["hypotheses_per_s"] = pl["hypotheses"] / (ms_pose * 1e-3) if ms_pose > 0 else None
             pl["point_evals_per_s"] = pl["point_evals"] / (ms_pose * 1e-3) if ms_pose > 0 else None
@@ -171,6 +171,29 @@ def run_leg(dev, w, h, B, R, params, seed, canvas_dim, steps, warmup, stages=vis
     finally:
         ctx.close()
         torch.cuda.empty_cache()
+
+
+def usable_cpus():
+    """host threads this process may really use: the scheduler affinity mask, capped by the cgroup CPU quota (a GPU box
+    hands one GPU's share of a 256-thread host to the job)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except Exception:
+            continue
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
 
 
 def cpu_baseline(p, frames, budget_s, what):
@@ -239,8 +262,9 @@ def main():
     headline_pose = None
     if rank == 0 and (a.stages & vislam.STAGE_POSE):
         step(0); ctx.batch_sync()
+        ms_pose = ctx.timings().ms_pose                   # before the results download re-syncs the streams
         headline_pose = pose_load(ctx, B)
-        headline_pose["ms_pose_per_step"] = ctx.timings().ms_pose
+        headline_pose["ms_pose_per_step"] = ms_pose
 
     # ---- SURVEY 8(f) N2 + N4 (outside the timed region, not part of `value`)
     aux, legs = None, None
@@ -333,7 +357,7 @@ def main():
         px = [int(x) * int(y) for x, y in zip(ws, hs)]
     host_frames = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        host_frames = stream.host(min(B * R, max(400, 4 * (os.cpu_count() or 1) + 8)))
+        host_frames = stream.host(min(B * R, max(400, 6 * usable_cpus()[0] + 8)))
     ctx.close()
     del stream
     torch.cuda.empty_cache()
@@ -437,12 +461,17 @@ def main():
             # informational, `cpu_baseline` stays the single-thread figure of the reference's own single-threaded code
             try:
                 import oracle_bind as orc
-                th = max(1, os.cpu_count() or 1)
-                ns = min(len(host_frames), 4 * th)
-                sec, _ = orc.pipeline_stream_mt(p, host_frames[:ns], th)
-                out["cpu_baseline_multicore"] = {"value": ns / sec, "unit": "frames/s", "cores": th, "kind": "port",
-                                                 "sample": f"{ns} consecutive S-752 frames, frame-parallel std::thread pool over the same oracle pipeline, "
-                                                           f"all {th} logical CPUs of the host (nproc = {os.cpu_count()})"}
+                th, quota = usable_cpus()
+                best = None
+                for tt in sorted({th, min(th, 16)}):         # all usable threads, and the documented 16-core share of one GPU
+                    ns = min(len(host_frames), max(48, 6 * tt))
+                    sec, _ = orc.pipeline_stream_mt(p, host_frames[:ns], tt)
+                    cand = {"value": ns / sec, "unit": "frames/s", "cores": tt, "kind": "port",
+                            "sample": f"{ns} consecutive S-752 frames, frame-parallel std::thread pool over the same oracle pipeline on {tt} threads "
+                                      f"(nproc = {os.cpu_count()}, affinity = {len(os.sched_getaffinity(0))}, cgroup cpu quota = {quota})"}
+                    if best is None or cand["value"] > best["value"]:
+                        best = cand
+                out["cpu_baseline_multicore"] = best
             except Exception as e:
                 out["cpu_baseline_multicore"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)

@@ -230,6 +230,13 @@ typedef struct vis_align_result {
     int32_t n_residuals[5];      /* valid residuals in the last iteration of the level */
 } vis_align_result;
 void vis_default_align_params(vis_align_params* ap);
+/* Sophus::SE3f value operations on the host (thirdparty/sophus/se3.hpp:723-744 exp, :317-321 product, :253-259 matrix,
+ * SE3(Matrix3, Point)): what VISystem::Track / EstimatePoseFeatures compose poses with (src/VISystem.cpp:1413,1607);
+ * the same code the alignment kernel runs.  a = (upsilon, omega); matrices row-major. */
+void vis_se3_exp(const float a[6], vis_se3f* out);
+void vis_se3_mul(const vis_se3f* a, const vis_se3f* b, vis_se3f* out);
+void vis_se3_from_rt(const float R[9], const float t[3], vis_se3f* out);
+void vis_se3_matrix(const vis_se3f* a, float M[16]);
 /* One pair, HOST pointers.  Level l images are dense (w>>l) x (h>>l): gray1/gx1/gy1 of the previous keyframe
  * (Frame::grayImage / gradientX / gradientY), gray2 of the current frame, cand1[l] = n_cand[l] rows (x, y, z, 1) as
  * Frame::candidatePoints[l] holds them.  Levels outside [last_level, first_level] may be NULL.  init may be NULL

@@ -144,3 +144,19 @@ def test_multi_iteration_case_and_golden(vislam, orc, canvas):
     assert list(r.n_residuals) == list(g["n_residuals"])
     assert np.array_equal(np.array(r.error, np.float32), g["error"])
     assert np.array_equal(r.pose.as_array(), g["pose"])
+
+
+def test_library_se3_host_helpers_equal_the_oracle(vislam, orc):
+    """vis_se3_* (host-side value operations the adapters' Track() composes poses with) == the oracle, bit for bit.
+    No GPU involved: these are host functions of the library."""
+    rng = np.random.default_rng(7)
+    for _ in range(50):
+        a6 = np.concatenate([rng.normal(0, 0.5, 3), rng.normal(0, 0.8, 3) * rng.choice([1.0, 1e-6])]).astype(np.float32)
+        b6 = rng.normal(0, 0.3, 6).astype(np.float32)
+        ea, oa = vislam.se3_exp(a6), orc.se3_exp(a6)
+        assert np.array_equal(ea.as_array(), oa.as_array())
+        eb = vislam.se3_exp(b6)
+        assert np.array_equal(vislam.se3_mul(ea, eb).as_array(), orc.se3_mul(oa, orc.se3_exp(b6)).as_array())
+        M = vislam.se3_matrix(ea)
+        assert np.array_equal(M, orc.se3_matrix(oa))
+        assert np.array_equal(vislam.se3_from_rt(M[:3, :3], M[:3, 3]).as_array(), orc.se3_from_rt(M[:3, :3], M[:3, 3]).as_array())

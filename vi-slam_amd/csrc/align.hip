@@ -24,6 +24,7 @@
 #include <cstring>
 
 #define DEV __device__ __forceinline__
+#define HD __host__ __device__ inline              // the SE3 pieces also back the host-side vis_se3_* helpers of the adapters
 #define AL_THREADS 256
 #define AL_MAXKP 200                     // min(num_max_keypoints, 200), src/Camera.cpp:377
 
@@ -48,7 +49,7 @@ struct Quat { float w, x, y, z; };
 struct Se3 { Quat q; float t[3]; };
 
 // deterministic double sin/cos, identical to detect.hip's / the oracle's sincos_det
-DEV void al_sincos(double x, double* s, double* c) {
+HD void al_sincos(double x, double* s, double* c) {
     const double TWO_OVER_PI = 6.36619772367581382433e-01;
     const double PIO2_HI = 1.57079632673412561417e+00;
     const double PIO2_LO = 6.07710050650619224932e-11;
@@ -73,10 +74,10 @@ DEV void al_sincos(double x, double* s, double* c) {
         default: *s = -cr; *c = sr; break;
     }
 }
-DEV float sin_det(float a) { double s, c; al_sincos((double)a, &s, &c); return (float)s; }
-DEV float cos_det(float a) { double s, c; al_sincos((double)a, &s, &c); return (float)c; }
+HD float sin_det(float a) { double s, c; al_sincos((double)a, &s, &c); return (float)s; }
+HD float cos_det(float a) { double s, c; al_sincos((double)a, &s, &c); return (float)c; }
 
-DEV Quat qmul(const Quat& a, const Quat& b) {
+HD Quat qmul(const Quat& a, const Quat& b) {
     Quat r;
     r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
     r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
@@ -84,7 +85,7 @@ DEV Quat qmul(const Quat& a, const Quat& b) {
     r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
     return r;
 }
-DEV void qrot(const Quat& q, const float (&v)[3], float (&out)[3]) {
+HD void qrot(const Quat& q, const float (&v)[3], float (&out)[3]) {
     float uv0 = q.y * v[2] - q.z * v[1], uv1 = q.z * v[0] - q.x * v[2], uv2 = q.x * v[1] - q.y * v[0];
     uv0 += uv0; uv1 += uv1; uv2 += uv2;
     const float c0 = q.y * uv2 - q.z * uv1, c1 = q.z * uv0 - q.x * uv2, c2 = q.x * uv1 - q.y * uv0;
@@ -92,7 +93,7 @@ DEV void qrot(const Quat& q, const float (&v)[3], float (&out)[3]) {
     out[1] = v[1] + q.w * uv1 + c1;
     out[2] = v[2] + q.w * uv2 + c2;
 }
-DEV void qmat(const Quat& q, float (&R)[9]) {
+HD void qmat(const Quat& q, float (&R)[9]) {
     const float tx = 2.f * q.x, ty = 2.f * q.y, tz = 2.f * q.z;
     const float twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
     const float txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
@@ -101,7 +102,7 @@ DEV void qmat(const Quat& q, float (&R)[9]) {
     R[3] = txy + twz;         R[4] = 1.f - (txx + tzz); R[5] = tyz - twx;
     R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.f - (txx + tyy);
 }
-DEV Se3 se3_exp(const float (&a)[6]) {
+HD Se3 se3_exp(const float (&a)[6]) {
     const float o0 = a[3], o1 = a[4], o2 = a[5];
     const float theta_sq = o0 * o0 + o1 * o1 + o2 * o2;
     const float theta = sqrtf(theta_sq);
@@ -136,7 +137,7 @@ DEV Se3 se3_exp(const float (&a)[6]) {
     for (int i = 0; i < 3; i++) r.t[i] = V[3 * i] * a[0] + V[3 * i + 1] * a[1] + V[3 * i + 2] * a[2];
     return r;
 }
-DEV Se3 se3_mul(const Se3& a, const Se3& b) {
+HD Se3 se3_mul(const Se3& a, const Se3& b) {
     Se3 r = a;
     float rt[3];
     qrot(a.q, b.t, rt);
@@ -364,6 +365,41 @@ __global__ __launch_bounds__(AL_THREADS) void k_align(AlignArgs G) {
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+// Sophus::SE3f value operations for the host adapters (VISystem::Track composes poses, src/VISystem.cpp:1567-1635): the same
+// functions the kernel runs, evaluated on the host.
+static Se3 to_se3(const vis_se3f& a) { Se3 r; r.q.w = a.qw; r.q.x = a.qx; r.q.y = a.qy; r.q.z = a.qz; r.t[0] = a.tx; r.t[1] = a.ty; r.t[2] = a.tz; return r; }
+static void from_se3(const Se3& e, vis_se3f* o) { o->qx = e.q.x; o->qy = e.q.y; o->qz = e.q.z; o->qw = e.q.w; o->tx = e.t[0]; o->ty = e.t[1]; o->tz = e.t[2]; }
+extern "C" void vis_se3_exp(const float a[6], vis_se3f* out) { const float v[6] = {a[0], a[1], a[2], a[3], a[4], a[5]}; from_se3(se3_exp(v), out); }
+extern "C" void vis_se3_mul(const vis_se3f* a, const vis_se3f* b, vis_se3f* out) { from_se3(se3_mul(to_se3(*a), to_se3(*b)), out); }
+extern "C" void vis_se3_matrix(const vis_se3f* a, float M[16]) {
+    float R[9]; qmat(to_se3(*a).q, R);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[4 * i + j] = R[3 * i + j];
+    M[3] = a->tx; M[7] = a->ty; M[11] = a->tz; M[12] = M[13] = M[14] = 0.f; M[15] = 1.f;
+}
+// SE3(Matrix3 R, Point t): Eigen's rotation-matrix -> quaternion conversion
+extern "C" void vis_se3_from_rt(const float R[9], const float t[3], vis_se3f* out) {
+    float qw, v[3];
+    float tr = R[0] + R[4] + R[8];
+    if (tr > 0.f) {
+        tr = sqrtf(tr + 1.f);
+        qw = 0.5f * tr;
+        tr = 0.5f / tr;
+        v[0] = (R[7] - R[5]) * tr; v[1] = (R[2] - R[6]) * tr; v[2] = (R[3] - R[1]) * tr;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        tr = sqrtf(R[4 * i] - R[4 * j] - R[4 * k] + 1.f);
+        v[i] = 0.5f * tr;
+        tr = 0.5f / tr;
+        qw = (R[3 * k + j] - R[3 * j + k]) * tr;
+        v[j] = (R[3 * j + i] + R[3 * i + j]) * tr;
+        v[k] = (R[3 * k + i] + R[3 * i + k]) * tr;
+    }
+    out->qx = v[0]; out->qy = v[1]; out->qz = v[2]; out->qw = qw; out->tx = t[0]; out->ty = t[1]; out->tz = t[2];
+}
+
 extern "C" void vis_default_align_params(vis_align_params* ap) {
     if (!ap) return;
     std::memset(ap, 0, sizeof(*ap));

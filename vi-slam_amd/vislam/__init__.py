@@ -113,6 +113,7 @@ ABI_SYMBOLS = [
     "vis_feeder_create", "vis_feeder_destroy", "vis_feeder_host_buffer", "vis_feeder_submit", "vis_feeder_release",
     "vis_default_align_params", "vis_estimate_pose_features", "vis_align_batch", "vis_batch_align",
     "vis_synth_frame_parallax", "vis_synth_frames_device", "vis_batch_results_async",
+    "vis_se3_exp", "vis_se3_mul", "vis_se3_from_rt", "vis_se3_matrix",
 ]
 
 
@@ -178,6 +179,10 @@ def _load():
     lib.vis_synth_frame_parallax.argtypes = [vp, ci, C.c_uint64, ci, ci, ci, vp, ci]
     lib.vis_synth_frames_device.argtypes = [vp, vp, ci, C.c_uint64, ci, ci, ci, ci, ci, ci, vp]
     lib.vis_batch_results_async.argtypes = [vp, vp, vp, vp]
+    lib.vis_se3_exp.argtypes = [vp, C.POINTER(Se3f)]; lib.vis_se3_exp.restype = None
+    lib.vis_se3_mul.argtypes = [C.POINTER(Se3f), C.POINTER(Se3f), C.POINTER(Se3f)]; lib.vis_se3_mul.restype = None
+    lib.vis_se3_from_rt.argtypes = [vp, vp, C.POINTER(Se3f)]; lib.vis_se3_from_rt.restype = None
+    lib.vis_se3_matrix.argtypes = [C.POINTER(Se3f), vp]; lib.vis_se3_matrix.restype = None
     lib.vis_default_align_params.argtypes = [C.POINTER(AlignParams)]
     lib.vis_default_align_params.restype = None
     pv = C.POINTER(C.c_void_p)
@@ -216,6 +221,32 @@ def default_align_params():
     ap = AlignParams()
     lib.vis_default_align_params(C.byref(ap))
     return ap
+
+
+def se3_exp(a):
+    a = np.ascontiguousarray(a, np.float32)
+    o = Se3f()
+    lib.vis_se3_exp(_ptr(a), C.byref(o))
+    return o
+
+
+def se3_mul(a, b):
+    o = Se3f()
+    lib.vis_se3_mul(C.byref(a), C.byref(b), C.byref(o))
+    return o
+
+
+def se3_from_rt(R, t):
+    R = np.ascontiguousarray(R, np.float32).reshape(9); t = np.ascontiguousarray(t, np.float32)
+    o = Se3f()
+    lib.vis_se3_from_rt(_ptr(R), _ptr(t), C.byref(o))
+    return o
+
+
+def se3_matrix(a):
+    M = np.zeros(16, np.float32)
+    lib.vis_se3_matrix(C.byref(a), _ptr(M))
+    return M.reshape(4, 4)
 
 
 # ---- synthetic stream (host-side utility of the library; integer-only, bit-reproducible) ----------
