@@ -28,8 +28,8 @@ int vis_compute_levels(const vis_params& p, int w, int h, int stride0, LevelInfo
         // the x origin is rounded down to 16 so that k_fast's 16-byte tile loads stay aligned
         const int e = p.edge_threshold, tx0 = e & ~15;
         lv[l].tiles_x = std::max(1, (lv[l].w - e - tx0 + 127) / 128);
-        lv[l].tiles_y = std::max(1, (lv[l].h - 2 * e + 31) / 32);
-        lv[l].cand_cap = lv[l].tiles_x * lv[l].tiles_y * 1024;
+        lv[l].tiles_y = std::max(1, (lv[l].h - 2 * e + VIS_FT_H - 1) / VIS_FT_H);
+        lv[l].cand_cap = lv[l].tiles_x * lv[l].tiles_y * (VIS_FT_W * VIS_FT_H / 4);
         lv[l].tile_base = l == 0 ? 0 : lv[l - 1].tile_base + lv[l - 1].tiles_x * lv[l - 1].tiles_y;
     }
     float factor = (float)(1.0 / sf);

@@ -12,6 +12,10 @@
 #define VIS_NSLOTS 32            // device keyframe slots of the single-frame API (Camera::frameList)
 #define VIS_RANSAC_MAX_M 8192    // max correspondences per RANSAC problem
 #define VIS_MAX_MODELS 10
+#define VIS_FT_W 128              // FAST tile (k_fast workgroup) in pixels; the candidate slot of a tile holds VIS_FT_W*VIS_FT_H/4 entries
+#ifndef VIS_FT_H
+#define VIS_FT_H 32
+#endif
 
 struct LevelInfo {
     int w, h, stride;            // stride: bytes per row of the level buffer (level 0: caller's)
