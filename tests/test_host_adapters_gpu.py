@@ -1,5 +1,9 @@
-"""GPU: the C++ adapter classes (reference CameraGPU / MatcherGPU / VISystemGPU surface over the C ABI)
-driven by a main_vi_slamGPU-style frame loop produce what the oracle's per-frame pipeline produces."""
+"""The C++ adapter classes (reference CameraGPU / MatcherGPU / VISystemGPU surface over the C ABI).
+CPU: the translation unit with the reference main's calls holds them VERBATIM (checked against the reference tree when it
+is present) and the calibration XML reader returns the file's fields.
+GPU: that program, driven for 45 frames (more than the 32 device slots and the 20 keyframes the reference keeps:
+FreeLastFrameGPU and the slot ring wrap both execute), produces per frame what the oracle's restatement of the same
+sequence produces: detect -> match -> patch points -> Gauss-Newton alignment -> Track(), plus the essential-matrix path."""
 import os
 import re
 import subprocess
@@ -7,41 +11,159 @@ import subprocess
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "vi-slam_amd", "lib", "vislam_main_gpu")
+
+CAL_XML = """<?xml version="1.0"?>
+<!-- synthetic EuRoC-shaped calibration for the tests: ORB + GPU Hamming matcher, no distortion -->
+<opencv_storage>
+<in_width type_id="integer"> 752 </in_width>
+<in_height type_id="integer"> 480 </in_height>
+<out_width type_id="integer"> 752 </out_width>
+<out_height type_id="integer"> 480 </out_height>
+<calibration_values type_id="opencv-matrix">
+  <rows>1</rows> <cols>4</cols> <dt>f</dt>
+  <data> 458.654 457.296 367.215 248.375 </data></calibration_values>
+<rectification type_id="opencv-matrix">
+  <rows>1</rows> <cols>4</cols> <dt>f</dt>
+  <data> 0 0 0 0 </data></rectification>
+<imu2cam0Transformation type_id="opencv-matrix">
+  <rows>4</rows> <cols>4</cols> <dt>f</dt>
+  <data> 0.0148655429818 -0.999880929698 0.00414029679422 -0.0216401454975
+         0.999557249008 0.0149672133247 0.025715529948 -0.064676986768
+        -0.0257744366974 0.00375618835797 0.999660727178 0.00981073058949
+         0.0 0.0 0.0 1.0 </data></imu2cam0Transformation>
+<camera_frecuency type_id="float"> 20 </camera_frecuency>
+<imu_frecuency type_id="float"> 200 </imu_frecuency>
+<min_features type_id="integer"> 20</min_features>
+<num_max_keyframes type_id="integer"> 10</num_max_keyframes>
+<start_index type_id="integer"> 0 </start_index>
+<use_gt type_id="integer">1</use_gt>
+<use_ros type_id="integer">0</use_ros>
+<num_cells type_id="integer"> 49</num_cells>
+<length_patch type_id="integer"> 3</length_patch>
+<detector type_id="integer">2</detector>
+<matcher type_id="integer">4</matcher>
+</opencv_storage>
+"""
 
 
-def test_demo_loop_matches_oracle(vislam, orc, canvas):
-    exe = os.path.join(ROOT, "vi-slam_amd", "lib", "vislam_demo")
-    assert os.path.exists(exe), "host demo not built"
-    n = 4
-    out = subprocess.run([exe, str(n)], capture_output=True, text=True, timeout=300)
+def test_main_calls_are_verbatim():
+    ref = "/root/reference/src/main_vi_slamGPU.cpp"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not present on this machine")
+    rl = open(ref).read().split("\n")
+    src = open(os.path.join(ROOT, "vi-slam_amd", "host", "main_calls_gpu.cpp")).read().split("\n")
+    blocks, i = [], 0
+    while i < len(src):
+        m = re.search(r"// BEGIN verbatim src/main_vi_slamGPU.cpp:(\d+)-(\d+)", src[i])
+        if m:
+            a, b = int(m.group(1)), int(m.group(2))
+            j, blk = i + 1, []
+            while "// END verbatim" not in src[j]:
+                blk.append(src[j].rstrip()); j += 1
+            assert blk == [x.rstrip() for x in rl[a - 1:b]], (a, b)
+            blocks.append((a, b))
+            i = j
+        i += 1
+    covered = set()
+    for a, b in blocks:
+        covered |= set(range(a, b + 1))
+    for need in (41, 43, 64, 65, 123, 125, 126, 127, 133, 138, 144):       # the call sites VERDICT r1 / SURVEY 8(b) name
+        assert need in covered, need
+
+
+def test_calibration_xml_reader(tmp_path, built):
+    f = tmp_path / "cal.xml"
+    f.write_text(CAL_XML)
+    out = subprocess.run([EXE, "--calibration-only", str(f)], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stdout + out.stderr
-    rows = re.findall(r"FRAME (\d+) kps (\d+) sym (\d+) good (\d+) inliers (\d+) posegood (\d+)", out.stdout)
-    assert len(rows) == n
-    grows = re.findall(r"GRAD (\d+) g (\d+) gx (-?\d+) patch (\d+) debug (\d+)", out.stdout)
-    assert len(grows) == n
+    line = [l for l in out.stdout.splitlines() if l.startswith("CAL ")][0]
+    assert "in 752 480 out 752 480" in line and "num_cells 49 length_patch 3 detector 2 matcher 4" in line
+    assert "min_features 20 num_max_keyframes 10 start_index 0 use_gt 1 use_ros 0" in line
+    k = [float(x) for x in re.search(r"K (\S+) (\S+) (\S+) (\S+)", line).groups()]
+    assert np.allclose(k, [458.654, 457.296, 367.215, 248.375], rtol=1e-7)
+    imu = [float(x) for x in [l for l in out.stdout.splitlines() if l.startswith("IMU2CAM")][0].split()[1:]]
+    assert abs(imu[1] + 0.999880929698) < 1e-7 and imu[15] == 1.0 and abs(imu[11] - 0.00981073058949) < 1e-9
+    # the shipped EuRoC calibration of the reference (distortion present, SURF + L2): parsed, rectification reported as out of scope
+    ref = "/root/reference/calibration/calibrationEUROC.xml"
+    if os.path.exists(ref):
+        out = subprocess.run([EXE, "--calibration-only", ref], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0 and "in 752 480 out 736 480" in out.stdout and "detector 4 matcher 0" in out.stdout
+
+
+def _f32(line):
+    return np.array([int(x, 16) for x in line.split()[1:]], np.uint32).view(np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,nframes", [("plain", 45), ("parallax", 12)])
+def test_main_loop_matches_oracle(vislam, orc, canvas, tmp_path, mode, nframes):
+    f = tmp_path / "cal.xml"
+    f.write_text(CAL_XML)
+    csv = tmp_path / "out.csv"
+    args = [EXE, str(f), str(nframes), str(csv)] + (["parallax"] if mode == "parallax" else [])
+    out = subprocess.run(args, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = out.stdout.splitlines()
+    frames = [re.match(r"FRAME (\d+) kps (\d+) sym (\d+) good (\d+) keyframes (\d+)", l) for l in lines]
+    frames = [[int(x) for x in m.groups()] for m in frames if m]
+    aligns = [[int(x) for x in re.findall(r"-?\d+", l)] for l in lines if l.startswith("ALIGN ")]
+    aposes = [_f32(l) for l in lines if l.startswith("ALIGNPOSE")]
+    fposes = [_f32(l) for l in lines if l.startswith("FINALPOSE")]
+    ransac = {int(m.group(1)): (int(m.group(2)), int(m.group(3))) for m in (re.match(r"RANSAC (\d+) inliers (\d+) posegood (\d+)", l) for l in lines) if m}
+    init = _f32([l for l in lines if l.startswith("INITPOSE")][0])
+    assert len(frames) == len(aligns) == len(aposes) == len(fposes) == nframes
+    assert len(open(csv).read().strip().splitlines()) == nframes and all(len(r.split(",")) == 14 for r in open(csv).read().strip().splitlines())
+    # the initial camera pose: quaternion of RPY(imu2camRotation * world2imuRotation), translation (-x, -z, -y) of imu2cam * position
+    assert abs(float((init[:4].astype(np.float64) ** 2).sum()) - 1) < 1e-6
+
     p = vislam.default_params()
-    p.fy = p.fx = float(np.float32(458.654))             # the adapters keep fx as a float member (include/VISystem.hpp)
+    p.fx = p.fy = float(np.float32(458.654))
     p.cx, p.cy = float(np.float32(367.215)), float(np.float32(248.375))
-    prev = None
-    for t in range(n):
-        img = vislam.synth_frame(canvas, t, 752, 480)
-        k, d, r = orc.pipeline_frame(p, img, prev)
-        prev = (k, d)
-        got = [int(x) for x in rows[t]]
-        assert got[1] == len(k)
-        if t > 0:
-            assert got[2:] == [r.n_sym, r.n_good, r.n_inliers, r.n_pose_good], (t, got, r.n_sym, r.n_good, r.n_inliers, r.n_pose_good)
-        # Camera::computeGradient of this frame: checksums over the 5 levels (weights catch transposed / shifted errors)
-        gsum = gxsum = 0
-        for lv in orc.half_pyramid(img):
-            ox, oy, og = orc.scharr_gradient(lv)
-            yy, xx = np.mgrid[0:lv.shape[0], 0:lv.shape[1]]
-            gsum += int(og.astype(np.int64).sum())
-            gxsum += int((ox.astype(np.int64) * (1 + ((xx + yy) & 3))).sum())
-        gg = [int(x) for x in grows[t]]
-        assert gg[1] == gsum and gg[2] == gxsum, (t, gg, gsum, gxsum)
-        if t > 0:
-            # the patch builders ran on the previous keyframe with its good matches: one debug point per match and level
-            assert gg[4] == 5 * min(r.n_good, 200) and gg[3] > 0, (t, gg, r.n_good)
+    ap = orc.default_align_params()
+    ap.fx, ap.fy, ap.cx, ap.cy = np.float32(458.654), np.float32(457.296), np.float32(367.215), np.float32(248.375)
+    seed_pose = orc.se3_from_rt(np.eye(3, dtype=np.float32), np.array([-0.0, -0.0, -0.0], np.float32))   # SE3(I, -TranslationResidual)
+    final = vislam.Se3f(*[float(x) for x in init])
+    keyframes = []            # dicts: kp, desc, pyr, gx, gy
+    checked_free = False
+    for i in range(nframes):
+        img = vislam.synth_frame(canvas, i + 2, 752, 480, parallax=(mode == "parallax"))    # main feeds stream frames 2, 3, ...
+        k, d = orc.orb_detect_compute(p, img)
+        pyr = orc.half_pyramid(img)
+        gx, gy = [], []
+        for lv in pyr:
+            a, b, _ = orc.scharr_gradient(lv, 3)
+            gx.append(a); gy.append(b)
+        cur = dict(kp=k, desc=d, pyr=pyr, gx=gx, gy=gy)
+        fr = frames[i]
+        assert fr[0] == i and fr[1] == len(k)
+        if keyframes:
+            last = keyframes[-1]
+            o12, o21 = orc.knn2_hamming(last["desc"], d)
+            good, sym = orc.good_matches(p, last["kp"], k, o12, o21)
+            assert fr[2] == len(sym) and fr[3] == len(good), (i, fr, len(sym), len(good))
+            prev_good = last["kp"][good["queryIdx"]]
+            cand = [orc.patch_points(prev_good, 752, 480, l) for l in range(5)]
+            keyframes.append(cur)
+            if len(keyframes) > 20:                                  # num_max_keyframes = camera_model->min_features (src/VISystemGPU.cpp:121)
+                keyframes.pop(0); checked_free = True
+            assert fr[4] == len(keyframes), (i, fr[4], len(keyframes))
+            r = orc.estimate_pose_features(ap, 752, 480, last["pyr"], pyr, last["gx"], last["gy"], cand, seed_pose)
+            assert aligns[i][1:5] == [r.iterations[3], r.iterations[2], r.iterations[1], r.iterations[0]], (i, aligns[i])
+            assert aligns[i][5:9] == [r.n_residuals[3], r.n_residuals[2], r.n_residuals[1], r.n_residuals[0]]
+            assert np.array_equal(aposes[i], r.pose.as_array()), (i, aposes[i], r.pose.as_array())
+            # Track(): final_poseCam = final_poseCam * SE3(rotation matrix of the estimate, its translation)
+            M = orc.se3_matrix(r.pose)
+            final = orc.se3_mul(final, orc.se3_from_rt(M[:3, :3], M[:3, 3]))
+            assert np.array_equal(fposes[i], final.as_array()), (i, fposes[i], final.as_array())
+            # the essential-matrix path on the same good matches
+            p1 = np.stack([last["kp"]["x"][good["queryIdx"]], last["kp"]["y"][good["queryIdx"]]], 1)
+            p2 = np.stack([k["x"][good["trainIdx"]], k["y"][good["trainIdx"]]], 1)
+            oE, omask, oninl, oiters = orc.essential_ransac(p, p1, p2)
+            ong = orc.recover_pose(p, oE, p1, p2)[2] if oninl else 0
+            assert ransac[i] == (oninl, ong), (i, ransac[i], oninl, ong)
+        else:
+            keyframes.append(cur)
+            assert fr[4] == 1 and np.array_equal(fposes[i], init)
+    assert checked_free == (nframes > 21)

@@ -126,15 +126,39 @@ static void sync_all(vis_ctx* ctx) {
 
 extern "C" const char* vis_last_error(vis_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+// the fields that fix the per-record layout (keypoint capacity per level, descriptor pattern)
+static bool same_record_geometry(const vis_params& a, const vis_params& b) {
+    return a.nfeatures == b.nfeatures && a.nlevels == b.nlevels && a.scale_factor == b.scale_factor &&
+           a.edge_threshold == b.edge_threshold && a.patch_size == b.patch_size;
+}
+
 extern "C" int vis_set_params(vis_ctx* ctx, const vis_params* p) {
     if (!ctx || !p) return VIS_E_INVALID;
     int rc = validate_params(*p);
     if (rc) return rc;
     sync_all(ctx);
+    // The reference changes matcher / pose settings while its keyframes keep their keypoints and descriptors
+    // (Matcher::setImageDimensions, computeBestMatches(n_cells)): when only such fields change, the device slots of the
+    // single-frame API survive -- the records move into the re-created plan.  A change of the detector geometry drops them
+    // (vis_bf_knn2_hamming / vis_good_matches on a dropped slot return VIS_E_STATE, never stale data).
+    Plan* old = ctx->single;
+    const bool keep = old && same_record_geometry(ctx->p, *p);
     ctx->p = *p;
-    // geometry depends on the params: drop plans (re-created lazily / by vis_batch_plan)
-    plan_destroy(ctx->single); ctx->single = nullptr;
     plan_destroy(ctx->batch); ctx->batch = nullptr;
+    ctx->single = nullptr;
+    if (keep) {
+        Plan* np = nullptr;
+        rc = plan_create(ctx, old->w, old->h, old->stride, 1, VIS_NSLOTS, 1, &np);
+        if (rc == VIS_OK && np->kcap == old->kcap && np->nrec == old->nrec) {
+            std::swap(np->d_kps, old->d_kps); std::swap(np->d_desc, old->d_desc);
+            std::swap(np->d_nkp, old->d_nkp); std::swap(np->d_descx, old->d_descx);
+            ctx->single = np;
+            plan_destroy(old);
+            return VIS_OK;
+        }
+        plan_destroy(np);
+    }
+    plan_destroy(old);
     for (int i = 0; i < VIS_NSLOTS; i++) ctx->slot_valid[i] = 0;
     return VIS_OK;
 }
@@ -773,9 +797,10 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
     hipStream_t sA = ctx->stream, sM = ctx->match_stream, sP = ctx->pose_stream;
     ctx->tm.launches_total = 0;
     const bool detect = (stages & VIS_STAGE_DETECT) != 0;
-    const int cur = detect ? (pl->run_count++ & 1) : (pl->last_base / pl->rec_per_set);
+    const int cur = detect ? (pl->run_count & 1) : (pl->last_base / pl->rec_per_set);   // run_count is committed only when every launch succeeded
     const int base = cur * pl->rec_per_set;
     int rc = VIS_OK;
+    bool have_prev = pl->have_prev;
     if (detect) {
         // this record set was last read by the matcher two batches ago
         if (pl->match_pending[cur]) HIPCHK(ctx, hipStreamWaitEvent(sA, ctx->ev_match_done[cur], 0));
@@ -784,10 +809,9 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
             HIPCHK(ctx, hipMemcpyAsync(pl->d_kps + (size_t)base * pl->kcap, pl->d_kps + (size_t)c * pl->kcap, (size_t)pl->kcap * sizeof(vis_keypoint), hipMemcpyDeviceToDevice, sA));
             HIPCHK(ctx, hipMemcpyAsync(pl->d_desc + (size_t)base * pl->kcap * 32, pl->d_desc + (size_t)c * pl->kcap * 32, (size_t)pl->kcap * 32, hipMemcpyDeviceToDevice, sA));
             HIPCHK(ctx, hipMemcpyAsync(pl->d_nkp + base, pl->d_nkp + c, 4, hipMemcpyDeviceToDevice, sA));
-            pl->have_prev = true; pl->carry_from = 0;
+            have_prev = true;
         }
     }
-    pl->pair0_valid = pl->have_prev;
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[0], sA);
     if (detect) { rc = launch_detect(ctx, pl, d_frames, n, base + 1); if (rc) return rc; }
     else if (ctx->ev_ok) for (int i = 1; i <= 4; i++) (void)hipEventRecord(ctx->ev[i], sA);
@@ -795,7 +819,7 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
     if (stages & (VIS_STAGE_MATCH | VIS_STAGE_POSE)) HIPCHK(ctx, hipStreamWaitEvent(sM, ctx->ev_detect_done, 0));
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev_match_start, sM);
     // pair i: query = record base+i (frame i-1, or the carried frame for i = 0), train = record base+i+1 (frame i)
-    pl->d_pair_q = pl->have_prev ? pl->d_pq[cur] : pl->d_pqn[cur];
+    pl->d_pair_q = have_prev ? pl->d_pq[cur] : pl->d_pqn[cur];
     pl->d_pair_t = pl->d_pt[cur];
     ctx->stream = sM;
     if (stages & VIS_STAGE_MATCH) {
@@ -822,8 +846,9 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
         ctx->pose_pending = true;
     }
     ctx->stream = sA;
-    if (rc) return rc;
-    if (detect) pl->carry_from = base + n;
+    if (rc) return rc;            // nothing of the stream state (carried frame, record set) has been committed
+    pl->have_prev = have_prev; pl->pair0_valid = have_prev;
+    if (detect) { pl->run_count++; pl->carry_from = base + n; }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[8], sA);
     pl->last_n = n; pl->last_base = base;
     return VIS_OK;

@@ -113,7 +113,7 @@ extern "C" int vis_image_read(const char* path, uint8_t* out, int out_stride, in
 struct vis_feeder {
     vis_ctx* ctx; int w, h, batch; size_t frame_bytes;
     uint8_t* h_buf[2]; uint8_t* d_buf[2];
-    hipStream_t copy_stream; hipEvent_t copied[2]; hipEvent_t consumed[2]; bool busy[2];
+    hipStream_t copy_stream; hipEvent_t copied[2]; hipEvent_t consumed[2]; bool busy[2]; bool released[2];
 };
 
 extern "C" int vis_feeder_create(vis_ctx* ctx, int w, int h, int batch, vis_feeder** out) {
@@ -121,7 +121,7 @@ extern "C" int vis_feeder_create(vis_ctx* ctx, int w, int h, int batch, vis_feed
     (void)hipSetDevice(ctx->device);
     vis_feeder* f = new vis_feeder();
     f->ctx = ctx; f->w = w; f->h = h; f->batch = batch; f->frame_bytes = (size_t)w * h;
-    for (int k = 0; k < 2; k++) { f->h_buf[k] = nullptr; f->d_buf[k] = nullptr; f->copied[k] = nullptr; f->consumed[k] = nullptr; f->busy[k] = false; }
+    for (int k = 0; k < 2; k++) { f->h_buf[k] = nullptr; f->d_buf[k] = nullptr; f->copied[k] = nullptr; f->consumed[k] = nullptr; f->busy[k] = false; f->released[k] = true; }
     f->copy_stream = nullptr;
     bool ok = hipStreamCreateWithFlags(&f->copy_stream, hipStreamNonBlocking) == hipSuccess;
     for (int k = 0; k < 2 && ok; k++) {
@@ -173,11 +173,17 @@ extern "C" int vis_feeder_submit(vis_feeder* f, int which, int n, const uint8_t*
     if (!f || which < 0 || which > 1 || n < 1 || n > f->batch || !d_frames) return VIS_E_INVALID;
     vis_ctx* ctx = f->ctx;
     (void)hipSetDevice(ctx->device);
+    // the previous use of this device buffer must have been released (vis_feeder_release records the event the copy waits
+    // for): without it the next copy could overwrite frames the detect chain is still reading
+    if (f->busy[which] && !f->released[which]) { ctx->err = "vis_feeder_submit: previous batch of this buffer was not released"; return VIS_E_STATE; }
+    if (ctx->batch && (ctx->batch->w != f->w || ctx->batch->h != f->h || ctx->batch->stride != f->w)) {
+        ctx->err = "vis_feeder_submit: the batch plan's geometry (w, h, stride == w) does not match the feeder"; return VIS_E_INVALID;
+    }
     if (f->busy[which]) HIPCHK(ctx, hipStreamWaitEvent(f->copy_stream, f->consumed[which], 0));    // detect of the batch that used d_buf[which]
     HIPCHK(ctx, hipMemcpyAsync(f->d_buf[which], f->h_buf[which], f->frame_bytes * n, hipMemcpyHostToDevice, f->copy_stream));
     HIPCHK(ctx, hipEventRecord(f->copied[which], f->copy_stream));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, f->copied[which], 0));
-    f->busy[which] = true;
+    f->busy[which] = true; f->released[which] = false;
     *d_frames = f->d_buf[which];
     return VIS_OK;
 }
@@ -187,5 +193,6 @@ extern "C" int vis_feeder_submit(vis_feeder* f, int which, int n, const uint8_t*
 extern "C" int vis_feeder_release(vis_feeder* f, int which) {
     if (!f || which < 0 || which > 1) return VIS_E_INVALID;
     HIPCHK(f->ctx, hipEventRecord(f->consumed[which], f->ctx->stream));
+    f->released[which] = true;
     return VIS_OK;
 }

@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void k_hyp_roots(PoseParams P, int h0, int h_e
         if (!sub_item(worklist, chunks, h0, npairs, sub, pair, hbase)) return;
         const int h = hbase + g;
         const bool active = h < rstate[(size_t)pair * RS] && h < h_end && h < max(P.max_iters, 1);
-        const size_t slot = (size_t)pair * P.max_iters + (active ? h : hbase);
+        const size_t slot = (size_t)pair * P.max_iters + (active ? h : min(hbase, max(P.max_iters, 1) - 1));   // inactive lanes never dereference it; kept in range anyway
         int32_t* flags = reinterpret_cast<int32_t*>(hyp + (size_t)HR_DOUBLES * S);
         int32_t* nrs = flags + S;
         const int flag = active ? flags[slot] : 0;
@@ -1029,11 +1029,10 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
              const double* d_E_in, uint8_t* d_mask, PoseOut* d_pose, int do_ransac, int do_pose, int32_t* d_worklist, double* d_hyp) {
     hipStream_t st = ctx->stream;
     PoseParams P = make_pose_params(ctx, max_iters, mcap);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!ctx->pose_attr_set) {       // the > 64 KiB dynamic-LDS opt-in is stored per device function: once per context (= per device)
         HIPCHK(ctx, hipFuncSetAttribute((const void*)k_ransac_hyp, hipFuncAttributeMaxDynamicSharedMemorySize, HYP_LDS_BYTES));
         HIPCHK(ctx, hipFuncSetAttribute((const void*)k_ransac_hyp_list, hipFuncAttributeMaxDynamicSharedMemorySize, HYP_LDS_BYTES));
-        attr_set = true;
+        ctx->pose_attr_set = true;
     }
     hipLaunchKernelGGL(k_pose_prep, dim3(npairs), dim3(256), 0, st, P, d_p1, d_p2, d_npts, d_n1, d_n2, d_samples, d_rstate);
     if (do_ransac) {

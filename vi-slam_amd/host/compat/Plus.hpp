@@ -1,0 +1,2 @@
+// forwards the reference header name include/Plus.hpp to the adapter surface (vi-slam_amd/host/vislam_host.hpp)
+#include "../vislam_host.hpp"

@@ -16,7 +16,16 @@ namespace cv {
 typedef std::string String;
 template <class T> struct Point_ { T x, y; Point_() : x(0), y(0) {} Point_(T a, T b) : x(a), y(b) {} };
 typedef Point_<float> Point2f; typedef Point_<double> Point2d;
-template <class T> struct Point3_ { T x, y, z; Point3_() : x(0), y(0), z(0) {} Point3_(T a, T b, T c) : x(a), y(b), z(c) {} };
+template <class T> struct Point3_ {
+    T x, y, z;
+    Point3_() : x(0), y(0), z(0) {}
+    Point3_(T a, T b, T c) : x(a), y(b), z(c) {}
+    template <class U> Point3_(const Point3_<U>& o) : x((T)o.x), y((T)o.y), z((T)o.z) {}
+};
+template <class T> inline Point3_<T> operator+(const Point3_<T>& a, const Point3_<T>& b) { return Point3_<T>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <class T> inline Point3_<T> operator-(const Point3_<T>& a, const Point3_<T>& b) { return Point3_<T>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <class T> inline Point3_<T> operator-(const Point3_<T>& a) { return Point3_<T>(-a.x, -a.y, -a.z); }
+template <class T> inline Point3_<T> operator*(const Point3_<T>& a, double s) { return Point3_<T>((T)(a.x * s), (T)(a.y * s), (T)(a.z * s)); }
 typedef Point3_<float> Point3f; typedef Point3_<double> Point3d;
 struct KeyPoint { Point2f pt; float size, angle, response; int octave, class_id;
                   KeyPoint() : size(0), angle(-1), response(0), octave(0), class_id(-1) {} };
@@ -25,8 +34,8 @@ struct DMatch { int queryIdx, trainIdx, imgIdx; float distance;
                 DMatch(int q, int t, float d) : queryIdx(q), trainIdx(t), imgIdx(-1), distance(d) {}
                 bool operator<(const DMatch& m) const { return distance < m.distance; } };
 static_assert(sizeof(KeyPoint) == 28 && sizeof(DMatch) == 16, "layout must match the C ABI");
-enum { CV_8U = 0, CV_16S = 3, CV_32F = 5 };               // OpenCV depth codes
-// minimal single-channel matrix with shared storage (enough for grayImage / descriptors / gradients / point lists)
+enum { CV_8U = 0, CV_16S = 3, CV_32F = 5, CV_8UC1 = 0, CV_16SC1 = 3, CV_32FC1 = 5 };               // OpenCV depth codes
+// minimal single-channel matrix with shared storage (enough for grayImage / descriptors / gradients / point lists / K)
 struct Mat {
     int rows = 0, cols = 0, depth = CV_8U; size_t step = 0; uint8_t* data = nullptr;
     std::shared_ptr<std::vector<uint8_t>> store;
@@ -35,6 +44,8 @@ struct Mat {
     static size_t esz(int type) { return type == CV_16S ? 2 : (type == CV_32F ? 4 : 1); }
     size_t elemSize() const { return esz(depth); }
     void create(int r, int c, int type) { rows = r; cols = c; depth = type; step = (size_t)c * esz(type); store = std::make_shared<std::vector<uint8_t>>((size_t)r * step); data = store->data(); }
+    static Mat zeros(int r, int c, int type) { return Mat(r, c, type); }
+    static Mat eye(int r, int c, int type) { Mat m(r, c, type); if (type == CV_32F) for (int i = 0; i < r && i < c; i++) m.at<float>(i, i) = 1.f; return m; }
     bool empty() const { return rows == 0 || cols == 0; }
     void release() { rows = cols = 0; step = 0; data = nullptr; store.reset(); }
     Mat clone() const { Mat m; if (!empty()) { m.create(rows, cols, depth); for (int y = 0; y < rows; y++) std::memcpy(m.data + (size_t)y * m.step, data + (size_t)y * step, (size_t)cols * esz(depth)); } return m; }
@@ -43,6 +54,20 @@ struct Mat {
     template <class T> T& at(int y, int x) { return *reinterpret_cast<T*>(data + (size_t)y * step + (size_t)x * sizeof(T)); }
     template <class T> const T& at(int y, int x) const { return *reinterpret_cast<const T*>(data + (size_t)y * step + (size_t)x * sizeof(T)); }
 };
+// cv::Matx33f: 3x3 float value matrix, row-major `val`
+struct Matx33f {
+    float val[9];
+    Matx33f() { for (int i = 0; i < 9; i++) val[i] = 0.f; }
+    float& operator()(int r, int c) { return val[3 * r + c]; }
+    const float& operator()(int r, int c) const { return val[3 * r + c]; }
+    Matx33f t() const { Matx33f m; for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) m(r, c) = (*this)(c, r); return m; }
+    static Matx33f eye() { Matx33f m; m(0, 0) = m(1, 1) = m(2, 2) = 1.f; return m; }
+};
+inline Matx33f operator*(const Matx33f& a, const Matx33f& b) {
+    Matx33f m;
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) m(r, c) = a(r, 0) * b(0, c) + a(r, 1) * b(1, c) + a(r, 2) * b(2, c);
+    return m;
+}
 template <class T> using Ptr = std::shared_ptr<T>;
 }  // namespace cv
 #endif

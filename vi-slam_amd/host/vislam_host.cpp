@@ -1,7 +1,10 @@
 // vislam_host.cpp -- adapter bodies; every method cites the reference body it mirrors.
 #include "vislam_host.hpp"
+#include <cmath>
 #include <cstdlib>
 #include <ctime>
+#include <fstream>
+#include <sstream>
 
 namespace { int g_device = 0; vis_ctx* g_ctx = nullptr; }
 namespace cv { namespace cuda {
@@ -20,6 +23,54 @@ void VisDevice::fail(int rc, const char* where) {
     cout << where << ": " << vis_strerror(rc) << " " << (g_ctx ? vis_last_error(g_ctx) : "") << endl;
     exit(1);
 }
+
+// ---------------------------------------------------------------- Plus (src/Plus.cpp): Euler / quaternion / matrix helpers
+Quaterniond toQuaternion(double roll, double pitch, double yaw) {                // src/Plus.cpp:3-21
+    const double cy = cos(yaw * 0.5), sy = sin(yaw * 0.5), cr = cos(roll * 0.5), sr = sin(roll * 0.5), cp = cos(pitch * 0.5), sp = sin(pitch * 0.5);
+    Quaterniond q;
+    q.w = cy * cr * cp + sy * sr * sp; q.x = cy * sr * cp - sy * cr * sp;
+    q.y = cy * cr * sp + sy * sr * cp; q.z = sy * cr * cp - cy * sr * sp;
+    return q;
+}
+Point3d toRPY(const Quaterniond& q) {                                             // src/Plus.cpp:23-54
+    const double sinr_cosp = 2.0 * (q.w * q.x + q.y * q.z), cosr_cosp = 1.0 - 2.0 * (q.x * q.x + q.y * q.y);
+    const double sinp = 2.0 * (q.w * q.y - q.z * q.x);
+    const double siny_cosp = 2.0 * (q.w * q.z + q.x * q.y), cosy_cosp = 1.0 - 2.0 * (q.y * q.y + q.z * q.z);
+    Point3d a;
+    a.x = atan2(sinr_cosp, cosr_cosp);
+    a.y = fabs(sinp) >= 1 ? copysign(M_PI / 2, sinp) : asin(sinp);                // 90 degrees when out of range
+    a.z = atan2(siny_cosp, cosy_cosp);
+    return a;
+}
+Point3d rotationMatrix2RPY(Matx33f R) {                                           // src/Plus.cpp:56-83
+    const double r11 = R(0, 0), r21 = R(1, 0), r31 = R(2, 0), r32 = R(2, 1), r33 = R(2, 2);
+    Point3d a;
+    a.z = atan2(r21, r11); a.y = atan2(-r31, sqrt(r32 * r32 + r33 * r33)); a.x = atan2(r32, r33);
+    return a;
+}
+static void rpy_rotation(const Point3d& rpy, double m[9]) {                       // the ZYX product both Plus.cpp builders write out
+    const double c1 = cos(rpy.x), s1 = sin(rpy.x), c2 = cos(rpy.y), s2 = sin(rpy.y), c3 = cos(rpy.z), s3 = sin(rpy.z);
+    m[0] = c3 * c2; m[1] = c3 * s2 * s1 - s3 * c1; m[2] = c3 * s2 * c1 + s3 * s1;
+    m[3] = s3 * c2; m[4] = s3 * s2 * s1 + c3 * c1; m[5] = s3 * s2 * c1 - c3 * s1;
+    m[6] = -s2;     m[7] = c2 * s1;                m[8] = c2 * c1;
+}
+Matx33f RPY2rotationMatrix(Point3d rpy) {                                         // src/Plus.cpp:182-220
+    double m[9]; rpy_rotation(rpy, m);
+    Matx33f R; for (int i = 0; i < 9; i++) R.val[i] = (float)m[i];
+    return R;
+}
+Mat RPYAndPosition2transformationMatrix(Point3d rpy, Point3d position) {          // src/Plus.cpp:284-323
+    double m[9]; rpy_rotation(rpy, m);
+    Mat T = Mat::zeros(4, 4, CV_32FC1);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) T.at<float>(r, c) = (float)m[3 * r + c];
+    T.at<float>(0, 3) = (float)position.x; T.at<float>(1, 3) = (float)position.y; T.at<float>(2, 3) = (float)position.z; T.at<float>(3, 3) = 1.0f;
+    return T;
+}
+Matx33f transformationMatrix2rotationMatrix(Mat T) {                              // src/Plus.cpp:222-241
+    Matx33f R; for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R(r, c) = T.at<float>(r, c);
+    return R;
+}
+Point3d transformationMatrix2position(Mat T) { return Point3d(T.at<float>(0, 3), T.at<float>(1, 3), T.at<float>(2, 3)); }   // src/Plus.cpp:116-127
 
 Frame::Frame() { obtainedGradients = false; obtainedGoodMatches = false; isKeyFrame = false; }   // src/Camera.cpp:6-11
 Frame::~Frame() { grayImage.clear(); }
@@ -65,7 +116,7 @@ void Matcher::computeBestMatches(int n_cells) {                                 
     vis_params p; vis_get_params(ctx, &p);
     if (p.n_cells != n_cells || p.w_size != w_size || p.h_size != h_size) {
         p.n_cells = n_cells; p.w_size = w_size; p.h_size = h_size;
-        int rc = vis_set_params(ctx, &p);                 // note: drops device slots; callers re-detect (only at init)
+        int rc = vis_set_params(ctx, &p);                 // matcher-side fields only: the device slots of the keyframes survive
         if (rc) VisDevice::fail(rc, "computeBestMatches/set_params");
     }
     const int n1 = (int)keypoints_1.size(), n2 = (int)keypoints_2.size();
@@ -109,8 +160,10 @@ void Matcher::printStatistics() {                                               
 // ---------------------------------------------------------------- MatcherGPU (src/MatcherGPU.cpp)
 MatcherGPU::MatcherGPU() { setGPUMatcher(0); }
 MatcherGPU::MatcherGPU(int _matcher) { setGPUMatcher(_matcher); }
+void MatcherGPU::setGPUFrames(Mat _frame1, Mat _frame2) { frameGPU1 = _frame1; frameGPU2 = _frame2; }   // include/MatcherGPU.hpp:20 (no body in the reference)
 void MatcherGPU::setGPUMatcher(int _matcher) {                                    // :16-42
     matcherType = _matcher;
+    matcherGPU = cuda::DescriptorMatcher::createBFMatcher(_matcher == USE_BRUTE_FORCE_GPU ? cuda::NORM_L2 : cuda::NORM_HAMMING);   // :23,:30
     if (_matcher == USE_BRUTE_FORCE_GPU_HAMMING) { cout << "Using Brute Force -Hamming GPU  Matcher" << endl; useGPU = true; }
     else if (_matcher == USE_BRUTE_FORCE_GPU) { cout << "L2 brute force is outside the hot path; using Hamming" << endl; useGPU = true; }
     else { useGPU = false; setMatcher(_matcher); }
@@ -179,7 +232,10 @@ static void patch_lists(Frame* last, bool patches, bool debug) {
 }
 void Camera::ObtainPatchesPointsPreviousFrame() { patch_lists(frameList[frameList.size() - 1], true, false); }   // :358-410
 void Camera::ObtainDebugPointsPreviousFrame() { patch_lists(frameList[frameList.size() - 1], false, true); }     // :413-445
-void Camera::saveFrame() { currentFrame->isKeyFrame = true; frameList.push_back(currentFrame); }   // :188-193
+void Camera::saveFrame() {                                                        // :188-193
+    currentFrame->isKeyFrame = true; frameList.push_back(currentFrame);
+    if (currentFrame->gpuSlot == nextSlot) nextSlot = (nextSlot + 1) % 32;          // the keyframe keeps its device slot
+}
 void Camera::printStatistics() {                                                  // :325-356
     cout << "\nESTADISTICAS\tTdetect: " << elapsed_detect * 1000 << " ms\tTmatch: " << elapsed_computeGoodMatches * 1000
          << " ms\tNdetect: " << nPointsDetect << "\tNmatch: " << nBestMatches << endl;
@@ -205,6 +261,7 @@ void CameraGPU::setGPUDetector(int _detector) {                                 
     if (_detector == USE_ORB) { useGPU = true; detectorType = _detector; cout << "Using ORB detector in GPU" << endl; }
     else { useGPU = true; detectorType = USE_ORB; cout << "Only ORB is on the hot path: using ORB detector in GPU" << endl; }
 }
+void CameraGPU::detectGPUFeatures() { nPointsDetect = detectAndComputeGPUFeatures(); }   // include/CameraGPU.hpp:22 (no body in the reference)
 void CameraGPU::setGPUMatcher(int _matcher) { matcherGPU.setGPUMatcher(_matcher); matcherGPU.setImageDimensions(w_size[0], h_size[0]); }   // :119-123
 int CameraGPU::detectAndComputeGPUFeatures() {                                    // :71-117
     keypointsGPU.release(); descriptorsGPU.release(); frameGPU.release();
@@ -214,10 +271,11 @@ int CameraGPU::detectAndComputeGPUFeatures() {                                  
     vector<vis_keypoint> kps(cap);
     currentFrame->descriptors.create(cap, 32, CV_8U);
     int n = 0;
-    const int slot = nextSlot; nextSlot = (nextSlot + 1) % 32;
+    const int slot = nextSlot;                            // kept only if saveFrame() makes this frame a keyframe
     int rc = vis_orb_detect_compute(ctx, img.data, img.cols, img.rows, (int)img.step, slot, kps.data(), currentFrame->descriptors.data, cap, &n);
     if (rc) VisDevice::fail(rc, "detectAndComputeGPUFeatures");
-    currentFrame->gpuSlot = slot; frameGPU.slot = keypointsGPU.slot = descriptorsGPU.slot = slot;
+    currentFrame->gpuSlot = slot; currentFrame->gpuGen = ++slotGen[slot];
+    frameGPU.slot = keypointsGPU.slot = descriptorsGPU.slot = slot;
     currentFrame->keypoints.resize((size_t)n);
     if (n) std::memcpy(static_cast<void*>(currentFrame->keypoints.data()), kps.data(), (size_t)n * sizeof(vis_keypoint));
     currentFrame->descriptors = currentFrame->descriptors.rowRange(0, n);
@@ -229,7 +287,10 @@ void CameraGPU::computeGPUGoodMatches() {                                       
     matcherGPU.clear();
     matcherGPU.setKeypoints(last->keypoints, currentFrame->keypoints);
     matcherGPU.setDescriptors(last->descriptors, currentFrame->descriptors);
-    matcherGPU.slot1 = last->gpuSlot; matcherGPU.slot2 = currentFrame->gpuSlot;
+    // device-resident descriptors of the last keyframe, unless its slot has been recycled since (more than 32 live keyframes):
+    // then the host copies the reference keeps in frameList.back() are matched instead (src/CameraGPU.cpp:129-130)
+    const bool resident = last->gpuSlot >= 0 && slotGen[last->gpuSlot] == last->gpuGen && last->gpuSlot != currentFrame->gpuSlot;
+    matcherGPU.slot1 = resident ? last->gpuSlot : -1; matcherGPU.slot2 = resident ? currentFrame->gpuSlot : -1;
     matcherGPU.computeGPUMatches();
     matcherGPU.computeBestMatches(n_cells);
     matcherGPU.getGoodMatches(last->nextGoodMatches, currentFrame->prevGoodMatches);
@@ -305,61 +366,252 @@ Mat ImageReader::getImage(int index) {                                          
 size_t ImageReader::getSize() { return file_names.size(); }
 void ImageReader::computeTimeStep() { TimeStep = (double)getImageTime(1) - (double)getImageTime(0); }   // :107-112
 
-// ---------------------------------------------------------------- vi::VISystemGPU (src/VISystemGPU.cpp, src/VISystem.cpp)
+// ---------------------------------------------------------------- vi::CameraModel (src/CameraModel.cpp)
 namespace vi {
-VISystemGPU::VISystemGPU() {}
-VISystemGPU::VISystemGPU(int, char*[]) {}                                         // ros::init dropped (out of scope)
-VISystemGPU::~VISystemGPU() { cout << "SLAM System shutdown ..." << endl; }
-void VISystemGPU::InitializeSystemGPU(double _fx, double _fy, double _cx, double _cy, int w, int h, int num_cells, int detector, int matcher, Mat image) {
-    currentImage = image;
-    fx = (float)_fx; fy = (float)_fy; cx = (float)_cx; cy = (float)_cy;           // src/VISystemGPU.cpp:57-60
-    InitializeCameraGPU(detector, matcher, w, h, num_cells, 3);
-    vis_ctx* ctx = VisDevice::get();
-    vis_params p; vis_get_params(ctx, &p);
-    p.fx = fx; p.fy = fx; p.cx = cx; p.cy = cy;                                   // findEssentialMat(focal = fx): src/VISystem.cpp:1679
-    int rc = vis_set_params(ctx, &p);
-    if (rc) VisDevice::fail(rc, "InitializeSystemGPU");
-    initialized = true;
-    cout << "Initializing system ... done" << endl << endl;
+// the calibration files are cv::FileStorage XML (calibration/calibrationEUROC.xml): <tag type_id=...> value </tag>, matrices
+// carry their numbers in a <data> element.  This reader handles exactly that shape; no OpenCV.
+static bool xml_element(const string& doc, const string& tag, string& out) {
+    size_t a = doc.find("<" + tag);
+    while (a != string::npos) {                              // "<tag" followed by '>' or whitespace (not a longer tag name)
+        const char c = doc[a + tag.size() + 1];
+        if (c == '>' || c == ' ' || c == '\t' || c == '\n' || c == '\r') break;
+        a = doc.find("<" + tag, a + 1);
+    }
+    if (a == string::npos) return false;
+    const size_t b = doc.find('>', a), e = doc.find("</" + tag + ">", a);
+    if (b == string::npos || e == string::npos || e < b) return false;
+    out = doc.substr(b + 1, e - b - 1);
+    return true;
 }
-void VISystemGPU::InitializeCameraGPU(int d, int m, int w, int h, int c, int l) { cameraGPU.initializateCameraGPU(d, m, w, h, c, l); }   // :132-135
-void VISystemGPU::AddFrameGPU(Mat _currentImage) {                                // :137-175
-    prevImage = currentImage;
-    currentImage = _currentImage.clone();
-    cameraGPU.Update(_currentImage);
-    cameraGPU.addGPUKeyframe();
-    num_keyframes = (int)cameraGPU.frameList.size();
-    if (cameraGPU.frameList.size() > 1) {
-        if (num_keyframes > num_max_keyframes) FreeLastFrameGPU();
-        float R[9], t[3];
-        EstimatePoseFeaturesRansac(cameraGPU.frameList[cameraGPU.frameList.size() - 2], cameraGPU.frameList[cameraGPU.frameList.size() - 1], R, t);
+static vector<double> xml_numbers(const string& doc, const string& tag) {
+    vector<double> v; string el;
+    if (!xml_element(doc, tag, el)) return v;
+    string data;
+    if (xml_element(el, "data", data)) el = data;
+    std::istringstream is(el); double x;
+    while (is >> x) v.push_back(x);
+    return v;
+}
+void CameraModel::GetCameraModel(string _calibration_path) {                          // src/CameraModel.cpp:16-101
+    valid_ = true;
+    std::ifstream f(_calibration_path.c_str());
+    if (!f.is_open()) {
+        cout << " ... not found" << endl << "Cannot operate without calibration" << endl << "Exiting..." << endl;
+        valid_ = false; exit(0);                                                      // :46-52
+    }
+    cout << " ... found" << endl;
+    std::stringstream ss; ss << f.rdbuf();
+    const string doc = ss.str();
+    auto num = [&](const char* tag, double dflt) { vector<double> v = xml_numbers(doc, tag); return v.empty() ? dflt : v[0]; };
+    in_width_ = (int)num("in_width", 0); in_height_ = (int)num("in_height", 0);
+    out_width_ = (int)num("out_width", 0); out_height_ = (int)num("out_height", 0);
+    vector<double> cal = xml_numbers(doc, "calibration_values"), dist = xml_numbers(doc, "rectification"), imu = xml_numbers(doc, "imu2cam0Transformation");
+    imu2cam0Transformation = Mat::eye(4, 4, CV_32FC1);
+    for (size_t i = 0; i < imu.size() && i < 16; i++) imu2cam0Transformation.at<float>((int)i / 4, (int)i % 4) = (float)imu[i];
+    camera_frecuency = (float)num("camera_frecuency", 0); imu_frecuency = (float)num("imu_frecuency", 0);
+    min_features = (int)num("min_features", 0); num_max_keyframes = (int)num("num_max_keyframes", 0); start_index = (int)num("start_index", 0);
+    use_gt = (int)num("use_gt", 0); use_ros = (int)num("use_ros", 0); num_cells = (int)num("num_cells", 0); length_patch = (int)num("length_patch", 0);
+    detector = (int)num("detector", 0); matcher = (int)num("matcher", 0);
+    for (int i = 0; i < 4; i++) { input_calibration_[i] = i < (int)cal.size() ? (float)cal[i] : 0.f; dist_coeffs_[i] = i < (int)dist.size() ? (float)dist[i] : 0.f; }
+    if (input_calibration_[2] < 1 && input_calibration_[3] < 1) {                     // relative intrinsics, :60-68
+        cout << "WARNING: cx = " << input_calibration_[2] << " < 1, which should not be the case for normal cameras" << endl;
+        input_calibration_[0] *= in_width_; input_calibration_[1] *= in_height_; input_calibration_[2] *= in_width_; input_calibration_[3] *= in_height_;
+    }
+    original_intrinsic_camera_ = Mat::zeros(3, 3, CV_32FC1);
+    original_intrinsic_camera_.at<float>(0, 0) = input_calibration_[0]; original_intrinsic_camera_.at<float>(1, 1) = input_calibration_[1];
+    original_intrinsic_camera_.at<float>(0, 2) = input_calibration_[2]; original_intrinsic_camera_.at<float>(1, 2) = input_calibration_[3];
+    original_intrinsic_camera_.at<float>(2, 2) = 1;
+    if (dist_coeffs_[0] == 0) {                                                       // :78-83
+        cout << "Distortion coefficients not found ... not rectifying" << endl;
+        valid_ = false;
+    } else {
+        // The reference rectifies here (getOptimalNewCameraMatrix + initUndistortRectifyMap, :84-99) and VISystem crops to a ROI:
+        // calib3d work outside the hot path.  The frames this build processes are taken as they come (the benches use a
+        // zero-distortion calibration), with the original intrinsics.
+        cout << "Distortion coefficients found ... rectification is outside this build: using the original intrinsics" << endl;
+        valid_ = false;
+    }
+    output_intrinsic_camera_ = original_intrinsic_camera_;
+}
+
+// ---------------------------------------------------------------- vi::VISystem / vi::VISystemGPU (src/VISystem.cpp, src/VISystemGPU.cpp)
+VISystem::VISystem() {
+    for (int i = 0; i < 9; i++) ransacR[i] = (i % 4 == 0) ? 1.f : 0.f;
+    ransacT[0] = ransacT[1] = ransacT[2] = 0.f;
+    std::memset(&lastAlignment, 0, sizeof(lastAlignment));
+}
+void VISystem::Calibration(string _calibration_path) {                                // src/VISystem.cpp:208-221
+    cout << "Reading calibration xml file";
+    camera_model = new CameraModel();
+    camera_model->GetCameraModel(_calibration_path);
+    w = camera_model->GetOutputWidth();
+    h = camera_model->GetOutputHeight();
+    if (w % 2 != 0 || h % 2 != 0) {
+        cout << "Output image dimensions must be multiples of 32. Choose another output dimentions" << endl << "Exiting..." << endl;
+        exit(0);
     }
 }
-void VISystemGPU::FreeLastFrameGPU() {                                            // :178-182 (without the reference's leak)
-    delete cameraGPU.frameList[0];
-    cameraGPU.frameList.erase(cameraGPU.frameList.begin());
+void VISystem::InitializePyramid(int _width, int _height, Mat _K) {                    // :1451-1493
+    w_[0] = _width; h_[0] = _height; K_[0] = _K;
+    fx_[0] = _K.at<float>(0, 0); fy_[0] = _K.at<float>(1, 1); cx_[0] = _K.at<float>(0, 2); cy_[0] = _K.at<float>(1, 2);
+    invfx_[0] = 1 / fx_[0]; invfy_[0] = 1 / fy_[0]; invcx_[0] = 1 / cx_[0]; invcy_[0] = 1 / cy_[0];
+    for (int lvl = 1; lvl < 5; lvl++) {
+        w_[lvl] = _width >> lvl; h_[lvl] = _height >> lvl;
+        fx_[lvl] = fx_[lvl - 1] * 0.5; fy_[lvl] = fy_[lvl - 1] * 0.5;
+        cx_[lvl] = (cx_[0] + 0.5) / ((int)1 << lvl) - 0.5; cy_[lvl] = (cy_[0] + 0.5) / ((int)1 << lvl) - 0.5;
+        K_[lvl] = Mat::eye(3, 3, CV_32FC1);
+        K_[lvl].at<float>(0, 0) = fx_[lvl]; K_[lvl].at<float>(1, 1) = fy_[lvl]; K_[lvl].at<float>(0, 2) = cx_[lvl]; K_[lvl].at<float>(1, 2) = cy_[lvl];
+        invfx_[lvl] = 1 / fx_[lvl]; invfy_[lvl] = 1 / fy_[lvl]; invcx_[lvl] = 1 / cx_[lvl]; invcy_[lvl] = 1 / cy_[lvl];
+    }
 }
-int VISystemGPU::EstimatePoseFeaturesRansac(Frame* prev, Frame* cur, float R_out[9], float t_out[3]) {   // src/VISystem.cpp:1655-1708
+void VISystem::setGtRes(Mat TranslationResGT, Mat RotationResGT) {                     // :415-419
+    TranslationResidual = TranslationResGT;
+    Matx33f R; for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R(r, c) = RotationResGT.at<float>(r, c);
+    RotationResidual = RPY2rotationMatrix(rotationMatrix2RPY(R));
+}
+// Gauss-Newton photometric alignment of the previous keyframe's candidate points to the current frame, :1113-1448.
+// Options (:1115-1121) are the defaults of vis_align_params.  The reference seeds the pose with the IMU's residual rotation and
+// the ground-truth translation residual (:1133-1166); the IMU core is outside this build (identity), the translation seed is
+// whatever setGtRes stored (zero without ground truth).  GUI calls (imshow / waitKey, :1250-1263) are dropped.
+void VISystem::EstimatePoseFeatures(Frame* _previous_frame, Frame* _current_frame) {
+    vis_align_params ap; vis_default_align_params(&ap);
+    ap.fx = fx_[0]; ap.fy = fy_[0]; ap.cx = cx_[0]; ap.cy = cy_[0];
+    const uint8_t* g1[5]; const uint8_t* g2[5]; const int16_t* gx[5]; const int16_t* gy[5]; const float* cd[5]; int32_t n[5];
+    for (int l = 0; l < 5; l++) {
+        g1[l] = _previous_frame->grayImage[l].data; g2[l] = _current_frame->grayImage[l].data;
+        gx[l] = reinterpret_cast<const int16_t*>(_previous_frame->gradientX[l].data);
+        gy[l] = reinterpret_cast<const int16_t*>(_previous_frame->gradientY[l].data);
+        cd[l] = reinterpret_cast<const float*>(_previous_frame->candidatePoints[l].data);
+        n[l] = _previous_frame->candidatePoints[l].rows;
+        if (!g1[l] || !g2[l] || !gx[l] || !gy[l]) n[l] = 0;                            // Update() could not build the half pyramid (size not a multiple of 16)
+    }
+    const float sx = TranslationResidual.at<float>(0, 0), sy = TranslationResidual.at<float>(1, 0), sz = TranslationResidual.at<float>(2, 0);
+    const SE3 current_pose(Matx33f::eye(), SE3::Point(-sx, -sy, -sz));                 // :1159
+    int rc = vis_estimate_pose_features(VisDevice::get(), &ap, w_[0], h_[0], g1, g2, gx, gy, cd, n, &current_pose.v, &lastAlignment);
+    if (rc) VisDevice::fail(rc, "EstimatePoseFeatures");
+    _previous_frame->rigid_transformation_.v = lastAlignment.pose;                     // :1445
+}
+int VISystem::EstimatePoseFeaturesRansac(Frame* prev, Frame* cur) {                    // :1655-1708
     vis_ctx* ctx = VisDevice::get();
     const int m = (int)prev->nextGoodMatches.size();
     vector<float> p1(2 * (size_t)std::max(m, 1)), p2(2 * (size_t)std::max(m, 1));
-    for (int i = 0; i < m; i++) {                                                 // KeyPoint::convert, :1673-1674
+    for (int i = 0; i < m; i++) {                                                     // KeyPoint::convert, :1673-1674
         p1[2 * i] = prev->nextGoodMatches[i].pt.x; p1[2 * i + 1] = prev->nextGoodMatches[i].pt.y;
         p2[2 * i] = cur->prevGoodMatches[i].pt.x; p2[2 * i + 1] = cur->prevGoodMatches[i].pt.y;
     }
     double E[9], R[9], t[3]; int ninl = 0, iters = 0, ngood = 0;
     int rc = vis_essential_ransac(ctx, p1.data(), p2.data(), m, E, nullptr, &ninl, &iters);   // :1679-1680
     if (rc) VisDevice::fail(rc, "findEssentialMat");
-    for (int i = 0; i < 9; i++) R_out[i] = (i % 4 == 0) ? 1.f : 0.f;
-    t_out[0] = t_out[1] = t_out[2] = 0.f;
+    for (int i = 0; i < 9; i++) ransacR[i] = (i % 4 == 0) ? 1.f : 0.f;
+    ransacT[0] = ransacT[1] = ransacT[2] = 0.f;
     lastInliers = ninl; lastPoseGood = 0;
     if (ninl > 0) {
-        rc = vis_recover_pose(ctx, E, p1.data(), p2.data(), m, R, t, &ngood);      // :1701
+        rc = vis_recover_pose(ctx, E, p1.data(), p2.data(), m, R, t, &ngood);          // :1701
         if (rc) VisDevice::fail(rc, "recoverPose");
-        for (int i = 0; i < 9; i++) R_out[i] = (float)R[i];                       // convertTo(CV_32FC1), :1702-1703
-        for (int i = 0; i < 3; i++) t_out[i] = (float)t[i];
+        for (int i = 0; i < 9; i++) ransacR[i] = (float)R[i];                         // convertTo(CV_32FC1), :1702-1703
+        for (int i = 0; i < 3; i++) ransacT[i] = (float)t[i];
         lastPoseGood = ngood;
     }
     return ninl;
+}
+// :1567-1635.  RotationResCam / translationResEst are the residual camera motion of the step (AddFrameGPU sets them from
+// the alignment result; in the reference they come from the IMU / F2FRansac path of the CPU main).  The IMU pose chain
+// composes the identity: imuCore is outside this build.
+void VISystem::Track() {
+    SE3::Point tRes(translationResEst.x, translationResEst.y, translationResEst.z);
+    current_poseCam = SE3(RotationResCam, tRes);
+    final_poseCam = final_poseCam * current_poseCam;
+    const SE3::Point t = final_poseCam.translation();
+    positionCam.x = t(0); positionCam.y = t(1); positionCam.z = t(2);
+    qOrientationCam.x = final_poseCam.unit_quaternion().x(); qOrientationCam.y = final_poseCam.unit_quaternion().y();
+    qOrientationCam.z = final_poseCam.unit_quaternion().z(); qOrientationCam.w = final_poseCam.unit_quaternion().w();
+    RPYOrientationCam = toRPY(qOrientationCam);
+    prev_world2camTransformation = RPYAndPosition2transformationMatrix(RPYOrientationCam, positionCam);
+    current_poseImu = SE3(Matx33f::eye(), SE3::Point(0.0, 0.0, 0.0));
+    final_poseImu = final_poseImu * current_poseImu;
+    const SE3::Point t2 = final_poseImu.translation();
+    positionImu.x = -t2(0); positionImu.y = -t2(2); positionImu.z = -t2(1);
+    qOrientationImu.x = final_poseImu.unit_quaternion().x(); qOrientationImu.y = final_poseImu.unit_quaternion().y();
+    qOrientationImu.z = final_poseImu.unit_quaternion().z(); qOrientationImu.w = final_poseImu.unit_quaternion().w();
+    RPYOrientationImu = toRPY(qOrientationImu);
+}
+
+VISystemGPU::VISystemGPU() { initialized = false; distortion_valid = false; depth_available = false; num_keyframes = 0; }
+VISystemGPU::VISystemGPU(int, char*[]) { initialized = false; distortion_valid = false; depth_available = false; num_keyframes = 0; }   // ros::init dropped (out of scope)
+VISystemGPU::~VISystemGPU() { cout << "SLAM System shutdown ..." << endl; }
+void VISystemGPU::InitializeSystemGPU(string _calPath, Point3d _iniPosition, Point3d _iniVelocity, Point3d _iniRPY, Mat image) {   // src/VISystemGPU.cpp:39-129
+    currentImage = image;
+    Calibration(_calPath);
+    imu2camTransformation = camera_model->imu2cam0Transformation;
+    imu2camRotation = transformationMatrix2rotationMatrix(imu2camTransformation);
+    imu2camTranslation = transformationMatrix2position(imu2camTransformation);
+    K = camera_model->GetK();
+    w_input = camera_model->GetInputWidth(); h_input = camera_model->GetInputHeight();
+    map1 = camera_model->GetMap1(); map2 = camera_model->GetMap2();
+    fx = K.at<float>(0, 0); fy = K.at<float>(1, 1); cx = K.at<float>(0, 2); cy = K.at<float>(1, 2);
+    distortion_valid = camera_model->IsValid();
+    w = w_input; h = h_input;                                                        // :72-85 without the ROI of rectified images
+    InitializePyramid(w, h, K);
+    initialized = true;
+    cout << "Initializing system ... done" << endl << endl;
+    // initial IMU pose, :97-104
+    positionImu = _iniPosition; velocityImu = _iniVelocity; RPYOrientationImu = _iniRPY;
+    qOrientationImu = toQuaternion(_iniRPY.x, _iniRPY.y, _iniRPY.z);
+    world2imuTransformation = RPYAndPosition2transformationMatrix(RPYOrientationImu, positionImu);
+    world2imuRotation = transformationMatrix2rotationMatrix(world2imuTransformation);
+    final_poseImu = SE3(SE3::Quaternion((float)qOrientationImu.w, (float)qOrientationImu.x, (float)qOrientationImu.y, (float)qOrientationImu.z), SE3::Point(0.0, 0.0, 0.0));
+    // initial camera pose, :107-113: positionCam = imu2camTransformation * (positionImu, 1), float like the Mat product
+    const float pi[4] = {(float)positionImu.x, (float)positionImu.y, (float)positionImu.z, 1.0f};
+    float pc[3], vc[3];
+    for (int r = 0; r < 3; r++) {
+        double acc = 0; for (int c = 0; c < 4; c++) acc += (double)imu2camTransformation.at<float>(r, c) * (double)pi[c];
+        pc[r] = (float)acc;
+        const float vi3[3] = {(float)velocityImu.x, (float)velocityImu.y, (float)velocityImu.z};
+        double av = 0; for (int c = 0; c < 3; c++) av += (double)imu2camRotation(r, c) * (double)vi3[c];
+        vc[r] = (float)av;
+    }
+    positionCam = Point3d(pc[0], pc[1], pc[2]);
+    velocityCam = Point3d(vc[0], vc[1], vc[2]);
+    RPYOrientationCam = rotationMatrix2RPY(imu2camRotation * world2imuRotation);
+    qOrientationCam = toQuaternion(RPYOrientationCam.x, RPYOrientationCam.y, RPYOrientationCam.z);
+    final_poseCam = SE3(SE3::Quaternion((float)qOrientationCam.w, (float)qOrientationCam.x, (float)qOrientationCam.y, (float)qOrientationCam.z),
+                        SE3::Point((float)-positionCam.x, (float)-positionCam.z, (float)-positionCam.y));
+    // imuCore.createPublisher / initializate / setImuInitialVelocity (:116-118): the ROS IMU core is outside this build
+    num_max_keyframes = camera_model->min_features;                                  // :121 (sic: the reference stores min_features)
+    min_features = camera_model->min_features;
+    start_index = camera_model->start_index;
+    InitializeCameraGPU(camera_model->detector, camera_model->matcher, w, h, camera_model->num_cells, camera_model->length_patch);
+    // intrinsics of the essential-matrix path: findEssentialMat(focal = fx, pp = (cx, cy)), src/VISystem.cpp:1679
+    vis_ctx* ctx = VisDevice::get();
+    vis_params p; vis_get_params(ctx, &p);
+    p.fx = fx; p.fy = fx; p.cx = cx; p.cy = cy;
+    int rc = vis_set_params(ctx, &p);
+    if (rc) VisDevice::fail(rc, "InitializeSystemGPU");
+}
+void VISystemGPU::InitializeCameraGPU(int d, int m, int w_, int h_, int c, int l) { cameraGPU.initializateCameraGPU(d, m, w_, h_, c, l); }   // :132-135
+void VISystemGPU::AddFrameGPU(Mat _currentImage, vector<Point3d> _imuAngularVelocity, vector<Point3d> _imuAcceleration) {   // :137-175
+    prevImage = currentImage;
+    currentImage = _currentImage.clone();
+    (void)_imuAngularVelocity; (void)_imuAcceleration;    // imuCore.setImuData / estimate (:142-143): the ROS IMU core is outside this build
+    cameraGPU.Update(_currentImage);
+    bool key_added = cameraGPU.addGPUKeyframe();
+    (void)key_added;
+    num_keyframes = (int)cameraGPU.frameList.size();
+    if (cameraGPU.frameList.size() > 1) {
+        cameraGPU.printStatistics();
+        if (num_keyframes > num_max_keyframes) FreeLastFrameGPU();
+        Frame* prev = cameraGPU.frameList[cameraGPU.frameList.size() - 2];
+        EstimatePoseFeatures(prev, cameraGPU.frameList[cameraGPU.frameList.size() - 1]);
+        // SPEC: the residual camera motion Track() composes is the alignment estimate (the commented line at
+        // src/VISystem.cpp:1580 shows that intent; the members are otherwise only set by the CPU main's IMU / F2F path)
+        RotationResCam = prev->rigid_transformation_.rotationMatrix();
+        const SE3::Point tt = prev->rigid_transformation_.translation();
+        translationResEst = Point3f(tt(0), tt(1), tt(2));
+        Track();
+    }
+}
+void VISystemGPU::FreeLastFrameGPU() {                                                // :178-182 (without the reference's leak)
+    delete cameraGPU.frameList[0];
+    cameraGPU.frameList.erase(cameraGPU.frameList.begin());
 }
 }  // namespace vi
