@@ -1,0 +1,27 @@
+"""The C++ multi-GPU launcher (vi-slam_amd/host/mgpu_main.cpp: one process per GPU, RCCL broadcast of the parameter POD).
+CPU: argument handling.  GPU: world size 1 end to end on the one card a test box has (communicator init, broadcast,
+barrier all-reduces, MAX-reduced time, JSON line); larger worlds are the driver's 8-GPU run."""
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "vi-slam_amd", "lib", "vislam_mgpu")
+
+
+def test_usage(built):
+    out = subprocess.run([EXE, "--gpus", "0"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 2 and "usage" in out.stderr
+
+
+@pytest.mark.gpu
+def test_world_size_one(built):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([EXE, "--gpus", "1", "--steps", "4", "--warmup", "2", "--batch", "128"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and j["steps"] == 4 and j["value"] > 10000 and j["scaling"] == "weak"
+    assert j["config"]["frames_per_step_per_gpu"] == 128
