@@ -20,6 +20,7 @@
 #include "vis_internal.h"
 #include <cfloat>
 #include <cmath>
+#include <vector>
 
 // ------------------------------------------------------------------------------------------------
 // k_resize: one thread = 4 horizontally adjacent destination pixels (one 32-bit store).  The two source
@@ -255,7 +256,10 @@ struct FastArgs { FastLevel lv[VIS_MAX_LEVELS]; int L, total_tiles; };
 // blockIdx.y the frame.  Phases: (A) pixel tile + halo -> LDS with dword loads, (B) pretest on every
 // score position, survivors are compacted into an LDS queue, (C) dense full cornerScore on the queue,
 // (D) 3x3 NMS + border cull on the scored survivors -> packed candidates in the tile's own slot.
-__global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edge, int32_t* __restrict__ tile_cnt, int nframes) {
+#define FAST_STAMP_SLOTS (1 << 20)          // workgroups of the largest stamped launch
+#define FAST_STAMP(i) do { if (stamps && tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tdelta[i] = (unsigned)(t_ - tprev); tprev = t_; } } while (0)
+__global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edge, int32_t* __restrict__ tile_cnt, int nframes,
+                                              unsigned long long* __restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) uint32_t px[PX_H * PX_W / 4];
     __shared__ __attribute__((aligned(16))) uint8_t sc[(SC_H * SC_S + 15) / 16 * 16];
     __shared__ uint16_t queue[SC_H * SC_W];
@@ -277,6 +281,8 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edg
     // every tile owns a fixed slot of TILE_CAND_CAP candidates: no returning atomics, no cross-tile ordering
     uint32_t* slot = V.cand + ((size_t)f * V.ntiles + tile) * TILE_CAND_CAP;
     if (tid == 0) { lcount = 0; qn = 0; }
+    unsigned long long tprev = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned tdelta[6] = {0, 0, 0, 0, 0, 0};
     // tile + halo -> LDS: 10 x 16-byte vectors per row (rows start 16 px left of the tile so every vector
     // is aligned in memory when stride % 16 == 0; otherwise dword loads)
     if ((stride & 15) == 0) {
@@ -300,6 +306,7 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edg
     }
     for (int i = tid; i < (SC_H * SC_S + 15) / 16; i += 256) reinterpret_cast<uint4*>(sc)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
+    FAST_STAMP(0);
     const uint8_t* pxb = reinterpret_cast<const uint8_t*>(px);
     // real scores are needed one pixel beyond the emit region (NMS neighbours), nowhere else
     const int lox = max(3, edge - 1), hix = min(w - 3, w - edge + 1);
@@ -356,6 +363,7 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edg
         }
     }
     __syncthreads();
+    FAST_STAMP(1);
     const int nq = qn;
     for (int i = tid; i < nq; i += 256) {
         const int pos = queue[i];
@@ -364,6 +372,7 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edg
         sc[sy * SC_S + sx] = (uint8_t)s;
     }
     __syncthreads();
+    FAST_STAMP(2);
     for (int i = tid; i < nq; i += 256) {
         const int pos = queue[i];
         const int sy = pos / SC_W, sx = pos - sy * SC_W;
@@ -378,6 +387,12 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edg
         }
     }
     __syncthreads();
+    FAST_STAMP(3);
+    if (stamps && tid == 0 && blockIdx.x < FAST_STAMP_SLOTS) {          // one private record per workgroup: no contention
+        unsigned long long* rec = stamps + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < 6; i++) rec[i] = tdelta[i];
+        rec[6] = (unsigned long long)nq; rec[7] = 0;
+    }
     if (tid == 0) tile_cnt[(size_t)f * F.total_tiles + gtile] = lcount;
 }
 
@@ -853,6 +868,36 @@ static void fill_desc_args(const vis_params& p, DescArgs& G, std::vector<uint32_
     }
 }
 
+// diagnostic: with VIS_FAST_STAMPS set in the environment thread 0 of every k_fast workgroup stores its s_memtime deltas
+// between the phase barriers into a private record; vis_debug_fast_stamps sums and clears them (tools/fast_phases.py).
+// Unset (the default): nullptr, no stamp executes.
+static unsigned long long* g_fast_stamps = nullptr;
+static unsigned long long* vis_fast_stamps() {
+    static const bool on = getenv("VIS_FAST_STAMPS") != nullptr;
+    if (on && !g_fast_stamps) {
+        if (hipMalloc((void**)&g_fast_stamps, (size_t)FAST_STAMP_SLOTS * 8 * sizeof(unsigned long long)) != hipSuccess) { g_fast_stamps = nullptr; return nullptr; }
+        (void)hipMemset(g_fast_stamps, 0, (size_t)FAST_STAMP_SLOTS * 8 * sizeof(unsigned long long));
+    }
+    return on ? g_fast_stamps : nullptr;
+}
+// out[0..5]: cycles of the phases load / pretest / score / nms / (unused) summed over the workgroups of the launches since the
+// last call, out[6] queue entries, out[8] workgroups
+extern "C" int vis_debug_fast_stamps(unsigned long long out[16]) {
+    if (!g_fast_stamps) return VIS_E_STATE;
+    if (hipDeviceSynchronize() != hipSuccess) return VIS_E_HIP;
+    std::vector<unsigned long long> h((size_t)FAST_STAMP_SLOTS * 8);
+    if (hipMemcpy(h.data(), g_fast_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return VIS_E_HIP;
+    for (int i = 0; i < 16; i++) out[i] = 0;
+    for (size_t b = 0; b < (size_t)FAST_STAMP_SLOTS; b++) {
+        const unsigned long long* r = &h[b * 8];
+        if (r[0] == 0 && r[1] == 0) continue;
+        for (int i = 0; i < 8; i++) out[i] += r[i];
+        out[8]++;
+    }
+    (void)hipMemset(g_fast_stamps, 0, h.size() * sizeof(unsigned long long));
+    return VIS_OK;
+}
+
 int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int rec0) {
     hipStream_t st = ctx->stream;
     const int L = pl->L;
@@ -892,7 +937,7 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
         const int tb = pl->total_tiles;
         FA.total_tiles = tb;
         hipLaunchKernelGGL(k_fast, dim3(xcd_grid(n, tb)), dim3(256), 0, st, FA, ctx->p.fast_threshold, ctx->p.edge_threshold,
-                           pl->d_tile_cnt, n);
+                           pl->d_tile_cnt, n, vis_fast_stamps());
         nfast = 1;
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[2], st);
