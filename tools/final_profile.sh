@@ -1,22 +1,27 @@
 #!/bin/bash
-# End-of-round profiling on the GPU box: tools/final_profile.sh OUTDIR   (OUTDIR under gpurun_out/)
-# 1. rocprofv3 --kernel-trace --stats of the default bench command
-# 2. PMC passes (separate runs, no trace domains besides --kernel-trace) of the pipeline workload and of the gradient stage
+# End-of-round profiling on the GPU box: tools/final_profile.sh OUTDIR COMMIT   (OUTDIR under gpurun_out/)
+# 1. rocprofv3 --kernel-trace --stats of the default bench command (side legs off: they would mix other configurations into the per-kernel averages)
+# 2. the same with the side legs on (configs 3 / 5, fixed-1000 RANSAC, parallax, alignment): one stats file for the legs
+# 3. PMC passes (separate runs, no trace domain besides --kernel-trace) of the pipeline workload and of the gradient stage
 set -e
 OUT=${1:-gpurun_out/final}
+COMMIT=${2:-unknown}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/$OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/$OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-legs > $R/$OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_legs -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/$OUT/bench_legs_under_rocprof.log 2>&1
 export VIS_PROFILE_BATCH=512 VIS_PROFILE_STEPS=3
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_VALU_MFMA_BUSY_CYCLES"; do
   n=$(echo $c | cut -d' ' -f1)
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/pipe/pass_$n -- python3 $R/tools/profile_workload.py > $R/$OUT/pipe_$n.log 2>&1
 done
+python3 $R/tools/pmc_summarize.py $R/$OUT/pipe 512 $COMMIT > $R/$OUT/pmc_summary.log 2>&1
 export VIS_PROFILE_BATCH=1024 VIS_PROFILE_STEPS=3
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
   n=$(echo $c | cut -d' ' -f1)
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/grad/pass_$n -- python3 $R/tools/profile_gradient.py > $R/$OUT/grad_$n.log 2>&1
 done
+python3 $R/tools/pmc_summarize.py $R/$OUT/grad 1024 $COMMIT > $R/$OUT/pmc_grad_summary.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/grad_stats -- python3 $R/tools/profile_gradient.py > $R/$OUT/grad_stats.log 2>&1
 echo final_profile done

@@ -9,6 +9,7 @@ import sys
 from collections import defaultdict
 
 out_dir, B = sys.argv[1], int(sys.argv[2])
+commit = sys.argv[3] if len(sys.argv) > 3 else None      # the build the counters were taken on (stamp it)
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -24,7 +25,7 @@ for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recur
     for r in csv.DictReader(open(f)):
         if "copyBuffer" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             cal[r["Counter_Name"]] = max(cal.get(r["Counter_Name"], 0.0), float(r["Counter_Value"]))
-res = {"batch_frames": B, "raw": summary,
+res = {"batch_frames": B, "measured_at_commit": commit, "raw": summary,
        "calibration": {"known_bytes_each_way": known, "FETCH_SIZE_units": cal.get("FETCH_SIZE"), "WRITE_SIZE_units": cal.get("WRITE_SIZE"),
                        "fetch_bytes_per_unit": known / cal["FETCH_SIZE"] if cal.get("FETCH_SIZE") else None,
                        "write_bytes_per_unit": known / cal["WRITE_SIZE"] if cal.get("WRITE_SIZE") else None,

@@ -21,10 +21,11 @@ p = vislam.default_params()
 p.fy = p.fx
 ctx = vislam.Context(0, p)
 cv = vislam.synth_canvas(4096, 0xE0C00001)
-fr = np.empty((B, H, W), np.uint8)
-for t in range(B):
-    vislam.synth_frame(cv, t, W, H, 0xE0C00001, out=fr[t])
-d = torch.from_numpy(fr).cuda()
+dcv = torch.from_numpy(cv).cuda()
+d = torch.empty((B, H, W), dtype=torch.uint8, device="cuda")
+for t0 in range(0, B, 256):            # device-side generator: byte-identical to the host one (tests/test_synth_gpu.py)
+    ctx.synth_frames_device(dcv.data_ptr(), 4096, 0xE0C00001, t0, min(256, B - t0), W, H, W, d.data_ptr() + t0 * W * H)
+torch.cuda.synchronize()
 ctx.batch_plan(W, H, W, B)
 # flush the 256 MiB Infinity Cache between steps with a 1 GiB fill so every step reads its frames from HBM
 junk = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")

@@ -21,6 +21,7 @@
 // (tests/test_pose_gpu.py), not bit-exactly.
 #include "vis_internal.h"
 #include <cfloat>
+#include <cstdlib>
 
 #define DEV __device__ __forceinline__
 
@@ -1039,10 +1040,12 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
         // per chunk of hypotheses: (A) minimal solver up to the degree-10 polynomial, lane = hypothesis, 118 KB LDS per wave;
         // (B) its real roots, 16 lanes per hypothesis; (C) models + inlier counts, 256 threads per 16 hypotheses;
         // then the sequential accept/adaptive-bound rule is replayed by k_ransac_scan.
-        const int first = std::min(16, std::max(max_iters, 1));
+        static const int first_chunk = getenv("VIS_RANSAC_FIRST") ? std::max(4, std::min(16, atoi(getenv("VIS_RANSAC_FIRST")) & ~3)) : 16;   // A/B knob
+        const int first = std::min(ctx->p.ransac_adaptive ? first_chunk : 16, std::max(max_iters, 1));
+        const int hc = first <= 4 ? 4 : (first <= 8 ? 8 : 16), ppb = 64 / hc;
         const size_t S = (size_t)npairs * max_iters;
         HIPCHK(ctx, hipMemsetAsync(d_worklist, 0, sizeof(int32_t), st));
-        hipLaunchKernelGGL(k_ransac_hyp, dim3(1, (npairs + 3) / 4), dim3(64), HYP_LDS_BYTES, st, P, 0, 16, first, npairs, d_n1, d_n2,
+        hipLaunchKernelGGL(k_ransac_hyp, dim3(1, (npairs + ppb - 1) / ppb), dim3(64), HYP_LDS_BYTES, st, P, 0, hc, first, npairs, d_n1, d_n2,
                            d_samples, d_rstate, d_hyp, S);
         hipLaunchKernelGGL(k_hyp_roots, dim3(npairs), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_hyp, S, (const int32_t*)nullptr, 0);
         hipLaunchKernelGGL(k_hyp_score, dim3(npairs), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_n1, d_n2, d_hyp, S, d_models,
