@@ -602,6 +602,7 @@ struct DescArgs {
     int kq[7];                // 7-tap Gaussian, Q8
     uint32_t k0, k1;          // the same taps packed as bytes for v_dot4_u32_u8: (k0..k3), (k4..k6, 0)
     uint32_t kp[4];           // and as u16 pairs for v_dot2_u32_u16: (k0,k1) (k2,k3) (k4,k5) (k6,0)
+    uint32_t kw[4][3];        // the 7 byte taps placed at byte offset j = 0..3 of a 12-byte window (three dot4 operands)
     const uint32_t* angle_tab; // [31 rows][9 dwords][2]: byte weights (u+16 inside the disc, else 0) and byte mask (1/0)
     float rad_per_deg;        // (float)(CV_PI/180.f)
     int patch_size;
@@ -749,10 +750,12 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
                 const uint32_t b0 = r1[0], b1 = r1[1], b2 = r1[2];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const uint32_t al = j ? __builtin_amdgcn_alignbyte(a1, a0, j) : a0, ah = j ? __builtin_amdgcn_alignbyte(a2, a1, j) : a1;
-                    const uint32_t bl = j ? __builtin_amdgcn_alignbyte(b1, b0, j) : b0, bh = j ? __builtin_amdgcn_alignbyte(b2, b1, j) : b1;
-                    const uint32_t oa = __builtin_amdgcn_udot4(al, G.k0, __builtin_amdgcn_udot4(ah, G.k1, 0u, false), false);
-                    const uint32_t ob = __builtin_amdgcn_udot4(bl, G.k0, __builtin_amdgcn_udot4(bh, G.k1, 0u, false), false);
+                    // the 7 taps start at byte j of the 12-byte window: instead of shifting the pixels (two v_alignbyte per
+                    // row and output) the byte weights are shifted -- G.kw[j] = the kernel placed at byte offset j of three
+                    // dwords -- so an output is a chain of 2 (j < 2) or 3 v_dot4_u32_u8
+                    uint32_t oa = __builtin_amdgcn_udot4(a1, G.kw[j][1], __builtin_amdgcn_udot4(a0, G.kw[j][0], 0u, false), false);
+                    uint32_t ob = __builtin_amdgcn_udot4(b1, G.kw[j][1], __builtin_amdgcn_udot4(b0, G.kw[j][0], 0u, false), false);
+                    if (j >= 2) { oa = __builtin_amdgcn_udot4(a2, G.kw[j][2], oa, false); ob = __builtin_amdgcn_udot4(b2, G.kw[j][2], ob, false); }
                     wb[j * (HTS / 2) + 6 * k] = oa | (ob << 16);       // <= 255*257 = 65535 per output
                 }
             }
@@ -849,6 +852,11 @@ static void fill_desc_args(const vis_params& p, DescArgs& G, std::vector<uint32_
     G.k1 = (uint32_t)G.kq[4] | ((uint32_t)G.kq[5] << 8) | ((uint32_t)G.kq[6] << 16);
     G.kp[0] = (uint32_t)G.kq[0] | ((uint32_t)G.kq[1] << 16); G.kp[1] = (uint32_t)G.kq[2] | ((uint32_t)G.kq[3] << 16);
     G.kp[2] = (uint32_t)G.kq[4] | ((uint32_t)G.kq[5] << 16); G.kp[3] = (uint32_t)G.kq[6];
+    for (int j = 0; j < 4; j++) {
+        uint8_t wbytes[12] = {0};
+        for (int i = 0; i < 7; i++) wbytes[j + i] = (uint8_t)G.kq[i];
+        for (int d = 0; d < 3; d++) G.kw[j][d] = (uint32_t)wbytes[4 * d] | ((uint32_t)wbytes[4 * d + 1] << 8) | ((uint32_t)wbytes[4 * d + 2] << 16) | ((uint32_t)wbytes[4 * d + 3] << 24);
+    }
     G.rad_per_deg = (float)(M_PI / 180.f);
     G.patch_size = p.patch_size;
     G.angle_tab = nullptr;
