@@ -319,6 +319,26 @@ def main():
                                         f"{B - 1} consecutive pairs of one batch, one persistent workgroup per pair; inputs = the N2 stage outputs",
                                 "ms_per_batch": ta * 1e3, "pairs_per_s": (B - 1) / ta, "iterations_mean_per_level": [float(x) for x in its[1:, :4].mean(0)],
                                 "residual_evals_per_s": evals / ta}
+            # the per-frame sequence of the GPU main, src/VISystemGPU.cpp:137-175, as one pipelined step: Camera::Update +
+            # addGPUKeyframe (detect, match + filters, computeGradient, patch points) + EstimatePoseFeatures, for every frame of the batch
+            def main_step(i):
+                d = stream.ptr((i % R) * B)
+                ctx.batch_run(d, B, vislam.STAGE_DETECT | vislam.STAGE_MATCH)
+                ctx.gradient_batch(d, W, H, W, B, gray.data_ptr(), gxb.data_ptr(), gyb.data_ptr(), gb.data_ptr())
+                ctx.batch_align(apar, d, B, gray.data_ptr(), gxb.data_ptr(), gyb.data_ptr(), 0, outb.data_ptr())
+            for i in range(3):
+                main_step(i)
+            ctx.batch_sync(); torch.cuda.synchronize()
+            tm = time.perf_counter()
+            KM = 20
+            for i in range(KM):
+                main_step(3 + i)
+            ctx.batch_sync(); torch.cuda.synchronize()
+            tm = (time.perf_counter() - tm) / KM
+            legs["gpu_main_sequence"] = {"what": "the GPU main's per-frame sequence (VISystemGPU::AddFrameGPU, src/VISystemGPU.cpp:137-175) for every frame of a batch: half pyramid, "
+                                                 "ORB detect + describe, knn + filters against the previous frame, Scharr gradients, patch points, Gauss-Newton alignment "
+                                                 "(the pose estimator that main calls, instead of the essential-matrix RANSAC of the headline); frames resident in HBM",
+                                         "ms_per_step": tm * 1e3, "frames_per_s": B / tm, "frames_per_step": B}
             del gray, gxb, gyb, gb, outb
         except Exception as e:                            # never let a side measurement break the contract line
             aux["gradient_batch_or_align"] = {"error": repr(e)}

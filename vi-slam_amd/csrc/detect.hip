@@ -415,7 +415,7 @@ __device__ __forceinline__ float funmap(uint32_t m) {
 }
 
 // HarrisResponses(blockSize 7, k 0.04) at integer (x,y) of one level
-__device__ float harris7(const uint8_t* __restrict__ img, int stride, int x, int y) {
+__device__ __forceinline__ float harris7(const uint8_t* __restrict__ img, int stride, int x, int y) {
     int a = 0, b = 0, c = 0;
     const uint8_t* p0 = img + (size_t)(y - 4) * stride + (x - 4);
     // 9 x 9 neighbourhood as 9 x 3 unaligned dwords (27 loads instead of 81 byte loads); every kept
@@ -446,136 +446,22 @@ __device__ float harris7(const uint8_t* __restrict__ img, int stride, int x, int
     return (fa * fb - fc * fc - 0.04f * s * s) * scale_sq_sq;
 }
 
+#define SEL_NT 256
 __global__ __launch_bounds__(256) void k_select(DetLevels D, const int32_t* __restrict__ tile_cnt, int total_tiles,
                                                 int32_t* __restrict__ seg_cnt,
                                                 int32_t* __restrict__ flags, int max_surv, int nframes) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
-    const int tid = threadIdx.x;
-    int l, f;
-    if (!xcd_frame_map(blockIdx.x, D.L, nframes, f, l)) return;
-    const LevelArgs A = D.lv[l];
-    int* sv = reinterpret_cast<int*>(smem + (size_t)max_surv * 8);   // all LDS in the dynamic region (16-B aligned base)
-    int& s_cut = sv[0]; int& s_n = sv[1]; int& s_keep = sv[2];
-    int* lhist = sv + 4;                                            // 256 bins
-    const int seg = f * D.L + l;
-    const int32_t* tc = tile_cnt + (size_t)f * total_tiles + A.tile_base;
-    const uint32_t* cand = A.cand + (size_t)f * A.ntiles * TILE_CAND_CAP;
-    lhist[tid] = 0;
-    if (tid == 0) { s_n = 0; s_keep = 0; }
-    __syncthreads();
-    // tile counts -> exclusive prefix (LDS), so that both passes run over a FLAT candidate index with
-    // independent loads (a thread-per-tile loop chained ~20 dependent loads per thread)
-    int* tpre = lhist + 256;                                       // A.ntiles + 1 entries
-    for (int t = tid; t < A.ntiles; t += 256) tpre[t + 1] = min(tc[t], TILE_CAND_CAP);
-    if (tid == 0) tpre[0] = 0;
-    __syncthreads();
-    if (tid < 64) {                                                // one wave scans (ntiles is a few hundred at most per chunk)
-        int carry = 0;
-        for (int b = 0; b < A.ntiles; b += 64) {
-            const int i = b + tid;
-            int v = i < A.ntiles ? tpre[i + 1] : 0;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o); if (tid >= o) v += u; }
-            if (i < A.ntiles) tpre[i + 1] = v + carry;
-            carry += __shfl(v, 63);
-        }
-    }
-    __syncthreads();
-    const int C = tpre[A.ntiles];
-    auto locate = [&](int j, int& t) {                             // largest t with tpre[t] <= j
-        int lo = 0, hi = A.ntiles;
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tpre[mid] <= j) lo = mid; else hi = mid; }
-        t = lo;
-    };
-    // pass 1: FAST-score histogram of this (frame, level)
-    for (int j = tid; j < C; j += 256) {
-        int t; locate(j, t);
-        atomicAdd(&lhist[cand[(size_t)t * TILE_CAND_CAP + (j - tpre[t])] >> 24], 1);
-    }
-    __syncthreads();
-    {
-        // KeyPointsFilter::retainBest(2*quota) on the FAST score: cut = largest score s with #(score >= s) >= n.
-        // Suffix sums of the 256 bins by a Hillis-Steele scan (8 steps) instead of one thread walking the bins.
-        const int n = 2 * A.quota;
-        int* suf = lhist + 256 + A.ntiles + 2;                     // 256 entries behind the tile prefix
-        int v = lhist[tid];
-        suf[tid] = v;
-        __syncthreads();
-#pragma unroll
-        for (int o = 1; o < 256; o <<= 1) {
-            const int u = tid + o < 256 ? suf[tid + o] : 0;
-            __syncthreads();
-            v += u; suf[tid] = v;
-            __syncthreads();
-        }
-        if (tid == 0) s_cut = C > n ? (n > 0 ? 0 : 256) : 0;       // defaults: everything kept (C <= n) / nothing (n == 0)
-        __syncthreads();
-        // v = number of candidates with score >= tid; the cut is the unique bin where the count crosses n from above
-        if (C > n && n > 0 && v >= n && (tid == 255 || suf[tid + 1] < n)) s_cut = tid;
-    }
-    __syncthreads();
-    const int cut = s_cut;
-    // pass 2: gather the survivors
-    for (int j = tid; j < C; j += 256) {
-        int t; locate(j, t);
-        const uint32_t cv = cand[(size_t)t * TILE_CAND_CAP + (j - tpre[t])];
-        if ((int)(cv >> 24) >= cut) {
-            const int slot = atomicAdd(&s_n, 1);
-            if (slot < A.surv_cap) keys[slot] = cv;
-        }
-    }
-    __syncthreads();
-    int S = s_n;
-    if (S > A.surv_cap) { S = A.surv_cap; if (tid == 0) atomicOr(flags, 2); }
-    int P2 = 2; while (P2 < S) P2 <<= 1;
-    const uint8_t* img = A.img + (size_t)f * A.frame_bytes;
-#pragma unroll 2
-    for (int i = tid; i < P2; i += 256) {
-        uint64_t key = ~0ull;
-        if (i < S) {
-            const uint32_t c = (uint32_t)keys[i];
-            const int x = c & 0xFFF, y = (c >> 12) & 0xFFF;
-            const float r = harris7(img, A.stride, x, y);
-            key = ((uint64_t)(~fmap(r)) << 32) | ((uint64_t)y << 16) | (uint64_t)x;
-        }
-        keys[i] = key;
-    }
-    __syncthreads();
-    for (int k = 2; k <= P2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < P2; i += 256) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const uint64_t a = keys[i], b = keys[ixj];
-                    const bool asc = (i & k) == 0;
-                    if ((a > b) == asc) { keys[i] = b; keys[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    // KeyPointsFilter::retainBest(quota) on the Harris response: keep every response >= the quota-th
-    const int q = A.quota;
-    if (S <= q) { if (tid == 0) s_keep = S; }
-    else if (q > 0) {
-        const uint32_t cutm = (uint32_t)(keys[q - 1] >> 32);
-        for (int i = tid; i < S; i += 256) {
-            const uint32_t m = (uint32_t)(keys[i] >> 32);
-            const uint32_t mn = (i + 1 < S) ? (uint32_t)(keys[i + 1] >> 32) : 0xFFFFFFFFu;
-            if (m <= cutm && (i + 1 == S || mn > cutm)) s_keep = i + 1;
-        }
-    }
-    __syncthreads();
-    int keep = s_keep;
-    if (keep > A.keep_cap) { keep = A.keep_cap; if (tid == 0) atomicOr(flags, 4); }
-    float4* out = A.seg_kp + (size_t)f * A.keep_cap;
-    for (int i = tid; i < keep; i += 256) {
-        const uint64_t k = keys[i];
-        // .w carries the integer coordinates (y << 16 | x) for k_describe's scalar address math
-        out[i] = make_float4((float)(int)(k & 0xFFFF), (float)(int)((k >> 16) & 0xFFFF), funmap(~(uint32_t)(k >> 32)), __uint_as_float((uint32_t)k));
-    }
-    if (tid == 0) seg_cnt[seg] = keep;
+#include "select_body.inc"
 }
+#undef SEL_NT
+// 1024 threads per (frame, level) when a level sorts thousands of survivors (N = 4000 / 8000): the LDS bitonic sort and the
+// gather loops are the critical path of a launch that has only frames x levels workgroups
+#define SEL_NT 1024
+__global__ __launch_bounds__(1024) void k_select_1024(DetLevels D, const int32_t* __restrict__ tile_cnt, int total_tiles,
+                                                int32_t* __restrict__ seg_cnt,
+                                                int32_t* __restrict__ flags, int max_surv, int nframes) {
+#include "select_body.inc"
+}
+#undef SEL_NT
 
 // ------------------------------------------------------------------------------------------------
 // k_describe: one wave per keypoint
@@ -952,11 +838,17 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
     int max_surv = 0; for (int l = 0; l < L; l++) max_surv = std::max(max_surv, pl->lv[l].surv_cap);
     int max_nt = 0; for (int l = 0; l < L; l++) max_nt = std::max(max_nt, pl->lv[l].tiles_x * pl->lv[l].tiles_y);
     const size_t sel_lds = (size_t)max_surv * 8 + 16 + 1024 + ((size_t)max_nt + 2) * 4 + 1024;   // keys | flags | hist | tile prefix | suffix sums
-    if (sel_lds > 65536) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (160 KiB per CU on gfx950)
-        HIPCHK(ctx, hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
+    if (max_surv > 1024) {   // large quotas: 1024 threads per (frame, level)
+        if (sel_lds > 65536)   // > 64 KiB of dynamic LDS needs the opt-in attribute (160 KiB per CU on gfx950)
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)k_select_1024, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
+        hipLaunchKernelGGL(k_select_1024, dim3(xcd_grid(n, L)), dim3(1024), sel_lds, st, D, pl->d_tile_cnt, pl->total_tiles,
+                           pl->d_seg_cnt, pl->d_flags, max_surv, n);
+    } else {
+        if (sel_lds > 65536)
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
+        hipLaunchKernelGGL(k_select, dim3(xcd_grid(n, L)), dim3(256), sel_lds, st, D, pl->d_tile_cnt, pl->total_tiles,
+                           pl->d_seg_cnt, pl->d_flags, max_surv, n);
     }
-    hipLaunchKernelGGL(k_select, dim3(xcd_grid(n, L)), dim3(256), sel_lds, st, D, pl->d_tile_cnt, pl->total_tiles,
-                       pl->d_seg_cnt, pl->d_flags, max_surv, n);
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[3], st);
     hipLaunchKernelGGL(k_describe, dim3(xcd_grid(n, (pl->kcap + 3) / 4)), dim3(256), 0, st, D, G, pl->d_seg_cnt,
                        pl->d_kps, pl->d_desc, pl->d_nkp, pl->kcap, rec0, pl->d_flags, n);

@@ -217,8 +217,10 @@ __device__ __forceinline__ bool ratio_survives(uint32_t k0, uint32_t k1, double 
     return !(d0 > ratio * d1);                                              // src/Matcher.cpp:158
 }
 
-// block per pair.  dynamic LDS: keys[P] (u64) | cell[root*root] (u32) | scan[blockDim] (int) | misc
-__global__ __launch_bounds__(256) void k_filter(const vis_keypoint* __restrict__ kps, const int32_t* __restrict__ nkp, int kcap,
+// block per pair.  dynamic LDS: keys[P] (u64) | cell[root*root] (u32) | scan[NT] (int) | misc.  NT = 256 threads, or 1024 when
+// thousands of matches per pair are sorted (N = 4000 / 8000: the launch has only `pairs` workgroups)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_filter(const vis_keypoint* __restrict__ kps, const int32_t* __restrict__ nkp, int kcap,
                                                 const int32_t* __restrict__ pair_q, const int32_t* __restrict__ pair_t,
                                                 const uint32_t* __restrict__ knn12, const uint32_t* __restrict__ knn21,
                                                 double ratio, int sym_mode, int root,
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256) void k_filter(const vis_keypoint* __restrict__
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
     uint32_t* cell = reinterpret_cast<uint32_t*>(smem + (size_t)keys_cap * 8);
     int* scan = reinterpret_cast<int*>(cell + root * root);
-    int* misc = scan + 256;
+    int* misc = scan + NT;
     const int tid = threadIdx.x, pair = blockIdx.x;
     const int rq = pair_q[pair], rt = pair_t[pair];
     const int ncell = root * root;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256) void k_filter(const vis_keypoint* __restrict__
     const uint32_t* Bk = knn21 + (size_t)pair * kcap * 2;
     vis_dmatch* sym = sym_out + (size_t)pair * kcap;
     // ---- computeSymMatches: ordered compaction over q (chunk per thread + block scan)
-    const int chunk = (n1 + 255) / 256;
+    const int chunk = (n1 + NT - 1) / NT;
     const int qb = tid * chunk, qe = min(n1, qb + chunk);
     int cnt = 0;
     for (int q = qb; q < qe; q++) {
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(256) void k_filter(const vis_keypoint* __restrict__
     }
     scan[tid] = cnt;
     __syncthreads();
-    if (tid == 0) { int acc = 0; for (int i = 0; i < 256; i++) { int c = scan[i]; scan[i] = acc; acc += c; } misc[0] = acc; }
+    if (tid == 0) { int acc = 0; for (int i = 0; i < NT; i++) { int c = scan[i]; scan[i] = acc; acc += c; } misc[0] = acc; }
     __syncthreads();
     const int nsym = misc[0];
     int pos = scan[tid];
@@ -290,18 +292,18 @@ __global__ __launch_bounds__(256) void k_filter(const vis_keypoint* __restrict__
     if (pose_sym) {                                                // VIS_POSE_SYM: the pose stage takes every symmetric match
         float* q1 = p1 + (size_t)pair * pose_mcap * 2;
         float* q2 = p2 + (size_t)pair * pose_mcap * 2;
-        for (int i = tid; i < min(nsym, pose_mcap); i += 256) {
+        for (int i = tid; i < min(nsym, pose_mcap); i += NT) {
             const vis_dmatch m = sym[i];
             q1[2 * i] = K1[m.queryIdx].x; q1[2 * i + 1] = K1[m.queryIdx].y;
             q2[2 * i] = K2[m.trainIdx].x; q2[2 * i + 1] = K2[m.trainIdx].y;
         }
     }
-    for (int i = nsym + tid; i < P2; i += 256) keys[i] = ~0ull;
-    for (int i = tid; i < ncell; i += 256) cell[i] = 0xFFFFFFFFu;
+    for (int i = nsym + tid; i < P2; i += NT) keys[i] = ~0ull;
+    for (int i = tid; i < ncell; i += NT) cell[i] = 0xFFFFFFFFu;
     __syncthreads();
     for (int k = 2; k <= P2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < P2; i += 256) {
+            for (int i = tid; i < P2; i += NT) {
                 const int ixj = i ^ j;
                 if (ixj > i) {
                     const uint64_t a = keys[i], b = keys[ixj];
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(256) void k_filter(const vis_keypoint* __restrict__
         }
     // ---- bestMatchesFilter: band = first j with y <= hf[j]; column = steps until x <= wf[i] (clamped);
     // per cell the strictly smallest distance, first in sorted order wins ties -> min of (dist<<16 | sorted pos)
-    for (int s = tid; s < nsym; s += 256) {
+    for (int s = tid; s < nsym; s += NT) {
         const vis_dmatch m = sym[(uint32_t)keys[s]];
         const float y = K1[m.queryIdx].y, x = K1[m.queryIdx].x;
         int band = -1;
@@ -378,10 +380,12 @@ int launch_match(vis_ctx* ctx, Plan* pl, int npairs) {
 int launch_filter(vis_ctx* ctx, Plan* pl, int npairs) {
     if (npairs <= 0) return VIS_OK;
     int keys_cap = 2; while (keys_cap < pl->kcap) keys_cap <<= 1;
-    const size_t lds = (size_t)keys_cap * 8 + (size_t)pl->root * pl->root * 4 + 256 * 4 + 16;
+    const int nt = pl->kcap > 2048 ? 1024 : 256;
+    const size_t lds = (size_t)keys_cap * 8 + (size_t)pl->root * pl->root * 4 + (size_t)nt * 4 + 16;
     if (lds > 160 * 1024) return VIS_E_CAPACITY;
-    if (lds > 65536) HIPCHK(ctx, hipFuncSetAttribute((const void*)k_filter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_filter, dim3(npairs), dim3(256), lds, ctx->stream, pl->d_kps, pl->d_nkp, pl->kcap,
+    auto kern = nt == 1024 ? k_filter<1024> : k_filter<256>;
+    if (lds > 65536) HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(npairs), dim3(nt), lds, ctx->stream, pl->d_kps, pl->d_nkp, pl->kcap,
                        pl->d_pair_q, pl->d_pair_t, pl->d_knn12, pl->d_knn21, (double)ctx->p.ratio, ctx->p.sym_mode,
                        pl->root, pl->d_hf, pl->d_wf, pl->d_sym, pl->d_nsym, pl->d_good, pl->d_ngood,
                        pl->d_p1, pl->d_p2, keys_cap, pl->pose_mcap ? pl->pose_mcap : pl->root * pl->root,
