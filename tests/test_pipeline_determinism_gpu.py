@@ -1,0 +1,89 @@
+"""GPU: the three-stream batch pipeline (detect | match | pose, double-buffered records, carried last frame, queued D2H of
+results, alignment on the matcher's output) is deterministic and independent of how a stream is cut into batches.
+This is the race check of the build (the reference has none): any missing event between the streams
+shows up as a run-to-run or batching-dependent difference."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+W, H = 752, 480
+
+
+def _run(vislam, frames_dev, n_total, batch, with_align):
+    import torch
+    p = vislam.default_params()
+    p.fy = p.fx
+    c = vislam.Context(0, p)
+    c.batch_plan(W, H, W, batch)
+    root2 = 49
+    poses, goods, ngs, kps, aligns = [], [], [], [], []
+    fe = vislam.gradient_frame_elems(W, H)
+    if with_align:
+        gray = torch.zeros(batch * fe, dtype=torch.uint8, device="cuda")
+        gx = torch.zeros(batch * fe, dtype=torch.int16, device="cuda"); gy = torch.zeros_like(gx)
+        g = torch.zeros(batch * fe, dtype=torch.uint8, device="cuda")
+        aout = torch.zeros(batch * C.sizeof(vislam.AlignResult), dtype=torch.uint8, device="cuda")
+        ap = vislam.default_align_params()
+    pending = None
+    for b0 in range(0, n_total, batch):
+        n = min(batch, n_total - b0)
+        d = frames_dev.data_ptr() + b0 * W * H
+        c.batch_run(d, n)
+        hp = torch.zeros(n * C.sizeof(vislam.PoseResult), dtype=torch.uint8).pin_memory()
+        hg = torch.zeros(n * root2 * 16, dtype=torch.uint8).pin_memory()
+        hn = torch.zeros(n, dtype=torch.int32).pin_memory()
+        c.batch_results_async(hp.data_ptr(), hg.data_ptr(), hn.data_ptr())
+        if with_align:
+            c.gradient_batch(d, W, H, W, n, gray.data_ptr(), gx.data_ptr(), gy.data_ptr(), g.data_ptr())
+            c.batch_align(ap, d, n, gray.data_ptr(), gx.data_ptr(), gy.data_ptr(), 0, aout.data_ptr())
+        if pending is not None and not with_align:
+            pass                                               # the previous batch's download overlaps this batch: no sync in between
+        if with_align:                                         # the alignment output buffer is reused by the next batch
+            c.batch_sync()
+            aligns.append(aout.cpu().numpy()[:n * C.sizeof(vislam.AlignResult)].copy())
+        pending = (hp, hg, hn, n)
+        # keypoints of this batch (synchronises: also exercises sync between batches in one of the two modes)
+        if b0 % (2 * batch) == 0:
+            kps.append(c.batch_keypoints(n - 1)[0].tobytes())
+        else:
+            kps.append(None)
+        # results must be complete once the NEXT batch has been queued and synced; collect at the end of the loop body
+        c.batch_sync()
+        poses.append(np.frombuffer(hp.numpy().tobytes(), vislam.POSE_RESULT_DTYPE).copy())
+        goods.append(np.frombuffer(hg.numpy().tobytes(), vislam.DMATCH_DTYPE).reshape(n, root2).copy())
+        ngs.append(hn.numpy().copy())
+    assert c.batch_status() == 0
+    c.close()
+    return np.concatenate(poses), np.concatenate(goods), np.concatenate(ngs), kps, (np.concatenate(aligns) if with_align else None)
+
+
+def test_batching_independent_and_repeatable(vislam, canvas):
+    import torch
+    n_total = 96
+    frames = np.stack([vislam.synth_frame(canvas, t, W, H, parallax=True) for t in range(n_total)])
+    dev = torch.from_numpy(frames).cuda()
+    ref = _run(vislam, dev, n_total, 96, False)
+    for batch in (16, 32, 96):
+        got = _run(vislam, dev, n_total, batch, False)
+        assert got[0].tobytes() == ref[0].tobytes(), ("pose records differ", batch)
+        assert got[2].tobytes() == ref[2].tobytes(), ("good match counts differ", batch)
+        for t in range(n_total):                                 # rows are dense up to the count; the rest of a row is not written
+            assert got[1][t, :ref[2][t]].tobytes() == ref[1][t, :ref[2][t]].tobytes(), ("good matches differ", batch, t)
+    # pair 0 of the stream has no predecessor; every later frame has a pose record with correspondences
+    assert ref[0]["n_points"][0] == 0 and (ref[0]["n_points"][1:] > 5).all()
+
+
+def test_alignment_in_the_pipeline_is_repeatable(vislam, canvas):
+    import torch
+    n_total = 48
+    frames = np.stack([vislam.synth_frame(canvas, t, W, H) for t in range(n_total)])
+    dev = torch.from_numpy(frames).cuda()
+    a = _run(vislam, dev, n_total, 24, True)
+    b = _run(vislam, dev, n_total, 24, True)
+    assert a[4].tobytes() == b[4].tobytes() and a[0].tobytes() == b[0].tobytes()
+    res = np.frombuffer(a[4].tobytes(), np.uint8).reshape(n_total, -1)
+    nres = np.frombuffer(res[:, 136:156].tobytes(), np.int32).reshape(n_total, 5)
+    assert (nres[[0, 24]] == 0).all()                          # first frame of each batch: no predecessor inside the batch
+    assert (nres[1:24, 0] > 1000).all() and (nres[25:, 0] > 1000).all()

@@ -489,7 +489,7 @@ extern "C" int vis_align_batch(vis_ctx* ctx, const vis_align_params* ap, const u
     if (!ctx || !d_frames || !d_gray || !d_gx || !d_gy || !d_pts || !d_npts || !d_out) return VIS_E_INVALID;
     int rc = check_align_params(ap, w, h);
     if (rc) return rc;
-    if ((w & 15) || (h & 15) || stride < w || n < 1 || max_pts < 1) return VIS_E_INVALID;
+    if ((w & 15) || (h & 15) || stride < w || n < 1 || max_pts < 1) { ctx->err = "vis_align_batch: w, h multiples of 16 (the half pyramid of vis_gradient_batch), stride >= w, n >= 1, max_pts >= 1"; return VIS_E_INVALID; }
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemsetAsync(d_out, 0, sizeof(vis_align_result), st));            // frame 0 has no predecessor in this batch

@@ -381,7 +381,8 @@ static int check_flags(vis_ctx* ctx, Plan* pl) {
 
 // ------------------------------------------------------------------------------------------------ single-frame API
 extern "C" int vis_camera_update(vis_ctx* ctx, const uint8_t* img, int w, int h, int stride, uint8_t* const out_levels[5]) {
-    if (!ctx || !img || !out_levels || w < 16 || h < 16 || (w & 15) || (h & 15) || stride < w) return VIS_E_INVALID;
+    if (!ctx || !img || !out_levels || w < 16 || h < 16 || stride < w) return VIS_E_INVALID;
+    if ((w & 15) || (h & 15)) { ctx->err = "Camera::Update: width and height must be multiples of 16 (four exact halvings; the reference's w_size >> lvl bookkeeping assumes the same)"; return VIS_E_INVALID; }
     (void)hipSetDevice(ctx->device);
     size_t lvl_bytes[5]; size_t total = (size_t)w * h;
     lvl_bytes[0] = (size_t)w * h;
@@ -405,8 +406,10 @@ extern "C" size_t vis_gradient_frame_elems(int w, int h) { return (w < 16 || h <
 extern "C" int vis_gradient_batch(vis_ctx* ctx, const uint8_t* d_frames, int w, int h, int stride, int n, int scale,
                                   uint8_t* d_gray, int16_t* d_gx, int16_t* d_gy, uint8_t* d_g) {
     if (!ctx || !d_frames || !d_gray || !d_gx || !d_gy || !d_g) return VIS_E_INVALID;
-    if (w < 16 || h < 16 || (w & 15) || (h & 15) || stride < w || (stride & 3) || n < 1 || scale < 1 || scale > 8) return VIS_E_INVALID;
-    if (((uintptr_t)d_gx | (uintptr_t)d_gy | (uintptr_t)d_g | (uintptr_t)d_gray) & 15) return VIS_E_INVALID;
+    if (w < 16 || h < 16 || (w & 15) || (h & 15) || stride < w || (stride & 3) || n < 1 || scale < 1 || scale > 8) {
+        ctx->err = "vis_gradient_batch: w, h multiples of 16, stride >= w and % 4 == 0, n >= 1, 1 <= scale <= 8"; return VIS_E_INVALID;
+    }
+    if (((uintptr_t)d_gx | (uintptr_t)d_gy | (uintptr_t)d_g | (uintptr_t)d_gray) & 15) { ctx->err = "vis_gradient_batch: output buffers must be 16-byte aligned"; return VIS_E_INVALID; }
     (void)hipSetDevice(ctx->device);
     const size_t frame_bytes = (size_t)stride * h;
     int rc = launch_half_pyramid_batch(ctx, d_frames, w, h, stride, frame_bytes, n, d_gray);
