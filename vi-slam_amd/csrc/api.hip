@@ -214,7 +214,7 @@ void plan_destroy(Plan* pl) {
         F(pl->d_pyr[l]);
         F(pl->d_cand[l]); F(pl->d_seg_kp[l]);
     }
-    F(pl->d_tile_cnt); F(pl->d_seg_cnt); F(pl->d_flags); F(pl->d_angle_tab);
+    F(pl->d_fast_tiles); F(pl->d_tile_cnt); F(pl->d_seg_cnt); F(pl->d_flags); F(pl->d_angle_tab);
     F(pl->d_kps); F(pl->d_desc); F(pl->d_nkp); F(pl->d_descx);
     for (int i = 0; i < 2; i++) { F(pl->d_pq[i]); F(pl->d_pt[i]); F(pl->d_pqn[i]); }
     F(pl->d_knn12); F(pl->d_knn21);
@@ -254,6 +254,8 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
     }
     pl->total_tiles = pl->lv[L - 1].tile_base + pl->lv[L - 1].tiles_x * pl->lv[L - 1].tiles_y;
     DALLOC(pl->d_tile_cnt, (size_t)B * pl->total_tiles); DALLOC(pl->d_seg_cnt, (size_t)B * L);
+    if (pl->total_tiles > 65535) { plan_destroy(pl); return VIS_E_INVALID; }        // k_fast: gridDim.y
+    { int rc2 = build_fast_tiles(ctx, pl); if (rc2) { plan_destroy(pl); return rc2; } }
     DALLOC(pl->d_flags, 4);
     HIPCHK(ctx, hipMemset(pl->d_flags, 0, 16));
     DALLOC(pl->d_kps, (size_t)nrec * kcap); DALLOC(pl->d_desc, (size_t)nrec * kcap * 32); DALLOC(pl->d_nkp, nrec);

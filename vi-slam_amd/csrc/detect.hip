@@ -248,52 +248,63 @@ __device__ __forceinline__ pk16 pretest_axis(pk16 c, pk16 n, pk16 so, pk16 e, pk
     return pmax((c - T) - mx, (mn - c) - T);
 }
 
-struct FastLevel { const uint8_t* img; uint32_t* cand; size_t frame_bytes; int w, h, stride, ntiles, tiles_x, tile_base; };
+// one record per FAST tile of the pyramid (all levels), built once per plan: everything a workgroup needs arrives with one
+// pair of scalar loads instead of a level search + two integer divisions in SALU code
+struct FastTile { const uint8_t* img; uint32_t* cand; uint32_t frame_bytes; int w, h, stride, ox, oy, ntiles, tile; };
+static_assert(sizeof(FastTile) == 48, "FastTile is read as s_load_dwordx8 + x4");
 #define TILE_CAND_CAP (FT_W * FT_H / 4)     // 3x3 NMS bound per FT_W x FT_H tile: a tile's slot can never overflow
-struct FastArgs { FastLevel lv[VIS_MAX_LEVELS]; int L, total_tiles; };
 
-// ONE launch for all pyramid levels of all frames: blockIdx.x enumerates the 128x32 tiles of every level,
-// blockIdx.y the frame.  Phases: (A) pixel tile + halo -> LDS with dword loads, (B) pretest on every
-// score position, survivors are compacted into an LDS queue, (C) dense full cornerScore on the queue,
-// (D) 3x3 NMS + border cull on the scored survivors -> packed candidates in the tile's own slot.
+// ONE launch for all pyramid levels of all frames.  Grid (8, tiles, ceil(frames / 8)): blockIdx.x is the XCD the workgroup
+// lands on (workgroups are dealt to the 8 XCDs round-robin in x-fastest order), so all tiles of frame 8 z + x meet in one L2
+// -- the same placement as xcd_frame_map() without its integer divisions.  Phases: (A) pixel tile + halo -> LDS with 16-byte
+// loads, (B) pretest on every score position, survivors are compacted into an LDS queue, (C) dense full cornerScore on the
+// queue, (D) 3x3 NMS + border cull on the scored survivors -> packed candidates in the tile's own slot.
+#ifdef VIS_FAST_PROFILE                     // diagnostic build (make EXTRA=-DVIS_FAST_PROFILE): s_memtime stamps between the phases
 #define FAST_STAMP_SLOTS (1 << 20)          // workgroups of the largest stamped launch
 #define FAST_STAMP(i) do { if (stamps && tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tdelta[i] = (unsigned)(t_ - tprev); tprev = t_; } } while (0)
-__global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edge, int32_t* __restrict__ tile_cnt, int nframes,
+#else
+#define FAST_STAMP(i) do { } while (0)
+#endif
+__global__ __launch_bounds__(256) void k_fast(const FastTile* __restrict__ tiles, const uint8_t* __restrict__ frames0, int total_tiles,
+                                              int threshold, int edge, int32_t* __restrict__ tile_cnt, int nframes,
                                               unsigned long long* __restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) uint32_t px[PX_H * PX_W / 4];
     __shared__ __attribute__((aligned(16))) uint8_t sc[(SC_H * SC_S + 15) / 16 * 16];
     __shared__ uint16_t queue[SC_H * SC_W];
     __shared__ int lcount, qn;
     const int tid = threadIdx.x;
-    int f, gtile;
-    if (!xcd_frame_map(blockIdx.x, F.total_tiles, nframes, f, gtile)) return;
-    int level = 0;
-#pragma unroll 1
-    for (int l = 1; l < F.L; l++) if (gtile >= F.lv[l].tile_base) level = l;
-    const FastLevel V = F.lv[level];
-    const int tile = gtile - V.tile_base;
-    // tile grid origin = (edge rounded down to 16, edge): see vis_compute_levels
-    const int ox = (edge & ~15) + (tile % V.tiles_x) * FT_W, oy = edge + (tile / V.tiles_x) * FT_H;
-    const int w = V.w, h = V.h, stride = V.stride;
+    const int f = blockIdx.z * 8 + blockIdx.x, gtile = blockIdx.y;
+    if (f >= nframes) return;
+    const FastTile V = tiles[gtile];
+    const int ox = V.ox, oy = V.oy, w = V.w, h = V.h, stride = V.stride;
     // tiles that cannot emit (entirely inside the culled border) do nothing
     if (ox + FT_W <= edge || ox >= w - edge || oy + FT_H <= edge || oy >= h - edge) return;
-    const uint8_t* base = V.img + (size_t)f * V.frame_bytes;
+    const uint8_t* base = (V.img ? V.img : frames0) + (size_t)f * V.frame_bytes;       // level 0 is the caller's batch
     // every tile owns a fixed slot of TILE_CAND_CAP candidates: no returning atomics, no cross-tile ordering
-    uint32_t* slot = V.cand + ((size_t)f * V.ntiles + tile) * TILE_CAND_CAP;
+    uint32_t* slot = V.cand + ((size_t)f * V.ntiles + V.tile) * TILE_CAND_CAP;
     if (tid == 0) { lcount = 0; qn = 0; }
+#ifdef VIS_FAST_PROFILE
     unsigned long long tprev = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned tdelta[6] = {0, 0, 0, 0, 0, 0};
+#endif
     // tile + halo -> LDS: 10 x 16-byte vectors per row (rows start 16 px left of the tile so every vector
     // is aligned in memory when stride % 16 == 0; otherwise dword loads)
     if ((stride & 15) == 0) {
-        for (int i = tid; i < PX_H * (PX_W / 16); i += 256) {
+        // both vectors of a thread are in flight before the first LDS store
+        static_assert(PX_H * (PX_W / 16) <= 512, "two vectors per thread");
+        uint4 v[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = tid + 256 * k;
             const int r = i / (PX_W / 16), c4 = i - r * (PX_W / 16);
             const int gx = ox - PX_XO + c4 * 16, gy = oy - 4 + r;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (gy >= 0 && gy < h && gx >= 0 && gx + 15 < stride)
-                v = *reinterpret_cast<const uint4*>(base + (size_t)gy * stride + gx);
-            reinterpret_cast<uint4*>(px)[i] = v;
+            v[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (i < PX_H * (PX_W / 16) && gy >= 0 && gy < h && gx >= 0 && gx + 15 < stride)
+                v[k] = *reinterpret_cast<const uint4*>(base + (size_t)gy * stride + gx);
         }
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            if (tid + 256 * k < PX_H * (PX_W / 16)) reinterpret_cast<uint4*>(px)[tid + 256 * k] = v[k];
     } else {
         for (int wv = tid; wv < PX_H * (PX_W / 4); wv += 256) {
             const int r = wv / (PX_W / 4), cw = wv % (PX_W / 4);
@@ -388,12 +399,15 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs F, int threshold, int edg
     }
     __syncthreads();
     FAST_STAMP(3);
-    if (stamps && tid == 0 && blockIdx.x < FAST_STAMP_SLOTS) {          // one private record per workgroup: no contention
-        unsigned long long* rec = stamps + (size_t)blockIdx.x * 8;
+#ifdef VIS_FAST_PROFILE
+    const unsigned wg = (blockIdx.z * gridDim.y + blockIdx.y) * 8 + blockIdx.x;
+    if (stamps && tid == 0 && wg < FAST_STAMP_SLOTS) {                  // one private record per workgroup: no contention
+        unsigned long long* rec = stamps + (size_t)wg * 8;
         for (int i = 0; i < 6; i++) rec[i] = tdelta[i];
         rec[6] = (unsigned long long)nq; rec[7] = 0;
     }
-    if (tid == 0) tile_cnt[(size_t)f * F.total_tiles + gtile] = lcount;
+#endif
+    if (tid == 0) tile_cnt[(size_t)f * total_tiles + gtile] = lcount;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -765,6 +779,7 @@ static void fill_desc_args(const vis_params& p, DescArgs& G, std::vector<uint32_
 // diagnostic: with VIS_FAST_STAMPS set in the environment thread 0 of every k_fast workgroup stores its s_memtime deltas
 // between the phase barriers into a private record; vis_debug_fast_stamps sums and clears them (tools/fast_phases.py).
 // Unset (the default): nullptr, no stamp executes.
+#ifdef VIS_FAST_PROFILE
 static unsigned long long* g_fast_stamps = nullptr;
 static unsigned long long* vis_fast_stamps() {
     static const bool on = getenv("VIS_FAST_STAMPS") != nullptr;
@@ -789,6 +804,30 @@ extern "C" int vis_debug_fast_stamps(unsigned long long out[16]) {
         out[8]++;
     }
     (void)hipMemset(g_fast_stamps, 0, h.size() * sizeof(unsigned long long));
+    return VIS_OK;
+}
+#else
+static unsigned long long* vis_fast_stamps() { return nullptr; }
+extern "C" int vis_debug_fast_stamps(unsigned long long out[16]) { (void)out; return VIS_E_STATE; }   // needs the VIS_FAST_PROFILE build
+#endif
+
+// the per-tile records of k_fast (levels >= 1 point into the plan's pyramid; level 0 is the batch of the call: img = nullptr)
+int build_fast_tiles(vis_ctx* ctx, Plan* pl) {
+    std::vector<FastTile> t((size_t)pl->total_tiles);
+    const int e = ctx->p.edge_threshold;
+    for (int l = 0; l < pl->L; l++) {
+        const LevelInfo& V = pl->lv[l];
+        if (V.frame_bytes > 0xFFFFFFFFull) return VIS_E_INVALID;
+        for (int i = 0; i < V.tiles_x * V.tiles_y; i++) {
+            FastTile& r = t[(size_t)V.tile_base + i];
+            r.img = l == 0 ? nullptr : pl->d_pyr[l]; r.cand = pl->d_cand[l]; r.frame_bytes = (uint32_t)V.frame_bytes;
+            r.w = V.w; r.h = V.h; r.stride = V.stride; r.ntiles = V.tiles_x * V.tiles_y; r.tile = i;
+            // tile grid origin = (edge rounded down to 16, edge): see vis_compute_levels
+            r.ox = (e & ~15) + (i % V.tiles_x) * FT_W; r.oy = e + (i / V.tiles_x) * FT_H;
+        }
+    }
+    HIPCHK(ctx, hipMalloc((void**)&pl->d_fast_tiles, t.size() * sizeof(FastTile)));
+    HIPCHK(ctx, hipMemcpy(pl->d_fast_tiles, t.data(), t.size() * sizeof(FastTile), hipMemcpyHostToDevice));
     return VIS_OK;
 }
 
@@ -821,17 +860,8 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[1], st);
     {
-        FastArgs FA; FA.L = L;
-        for (int l = 0; l < L; l++) {
-            const LevelInfo& V = pl->lv[l];
-            FA.lv[l].img = D.lv[l].img; FA.lv[l].cand = pl->d_cand[l]; FA.lv[l].frame_bytes = V.frame_bytes;
-            FA.lv[l].w = V.w; FA.lv[l].h = V.h; FA.lv[l].stride = V.stride; FA.lv[l].ntiles = V.tiles_x * V.tiles_y;
-            FA.lv[l].tiles_x = V.tiles_x; FA.lv[l].tile_base = V.tile_base;
-        }
-        const int tb = pl->total_tiles;
-        FA.total_tiles = tb;
-        hipLaunchKernelGGL(k_fast, dim3(xcd_grid(n, tb)), dim3(256), 0, st, FA, ctx->p.fast_threshold, ctx->p.edge_threshold,
-                           pl->d_tile_cnt, n, vis_fast_stamps());
+        hipLaunchKernelGGL(k_fast, dim3(8, pl->total_tiles, (n + 7) / 8), dim3(256), 0, st, (const FastTile*)pl->d_fast_tiles, d_frames,
+                           pl->total_tiles, ctx->p.fast_threshold, ctx->p.edge_threshold, pl->d_tile_cnt, n, vis_fast_stamps());
         nfast = 1;
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[2], st);

@@ -46,6 +46,7 @@ struct Plan {
     uint32_t* d_cand[VIS_MAX_LEVELS] = {};   // B x tiles_l x 512 packed (score<<24 | y<<12 | x)
     int32_t* d_tile_cnt = nullptr;           // B x total_tiles candidates per tile
     int total_tiles = 0;
+    void* d_fast_tiles = nullptr;            // total_tiles x FastTile (detect.hip): per-tile record of k_fast
     int32_t* d_seg_cnt = nullptr;            // B x L kept counts
     float4*  d_seg_kp[VIS_MAX_LEVELS] = {};  // B x keep_cap (x, y, response, unused)
     int32_t* d_flags = nullptr;              // device error flags (1 word)
@@ -140,6 +141,7 @@ void plan_destroy(Plan* pl);
 
 // ---- kernel launchers (each enqueues on ctx->stream) ----
 int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int rec0);
+int build_fast_tiles(vis_ctx* ctx, Plan* pl);
 int launch_expand(vis_ctx* ctx, Plan* pl, int rec_first, int rec_count);
 int launch_match(vis_ctx* ctx, Plan* pl, int npairs);
 int launch_filter(vis_ctx* ctx, Plan* pl, int npairs);
