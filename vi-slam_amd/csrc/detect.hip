@@ -241,11 +241,11 @@ __device__ __forceinline__ pk16 pmax(pk16 a, pk16 b) { return __builtin_elementw
 // bytes i and j of the 8-byte string hi:lo as 2 x u16
 #define PICKB(hi, lo, i, j) as_pk(__builtin_amdgcn_perm((hi), (lo), 0x0c000c00u | (uint32_t)(i) | ((uint32_t)(j) << 16)))
 
-// > 0 in a half <=> that pixel passes
-__device__ __forceinline__ pk16 pretest_axis(pk16 c, pk16 n, pk16 so, pk16 e, pk16 w, pk16 T) {
+// > t in a half <=> that pixel passes
+__device__ __forceinline__ pk16 pretest_axis(pk16 c, pk16 n, pk16 so, pk16 e, pk16 w) {
     const pk16 mx = pmax(pmin(n, so), pmin(e, w));     // dark arc: every pair has a ring pixel < c - t
     const pk16 mn = pmin(pmax(n, so), pmax(e, w));     // bright arc: every pair has a ring pixel > c + t
-    return pmax((c - T) - mx, (mn - c) - T);
+    return pmax(c - mx, mn - c);
 }
 
 // one record per FAST tile of the pyramid (all levels), built once per plan: everything a workgroup needs arrives with one
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void k_fast(const FastTile* __restrict__ tiles
                                               unsigned long long* __restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) uint32_t px[PX_H * PX_W / 4];
     __shared__ __attribute__((aligned(16))) uint8_t sc[(SC_H * SC_S + 15) / 16 * 16];
-    __shared__ uint16_t queue[SC_H * SC_W];
+    __shared__ uint16_t queue[SC_H * SC_W + 64];        // + one scratch word per lane (branch-free append)
     __shared__ int lcount, qn;
     const int tid = threadIdx.x;
     const int f = blockIdx.z * 8 + blockIdx.x, gtile = blockIdx.y;
@@ -292,26 +292,27 @@ __global__ __launch_bounds__(256) void k_fast(const FastTile* __restrict__ tiles
     if ((stride & 15) == 0) {
         // both vectors of a thread are in flight before the first LDS store
         static_assert(PX_H * (PX_W / 16) <= 512, "two vectors per thread");
-        uint4 v[2];
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 v[2];
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const int i = tid + 256 * k;
             const int r = i / (PX_W / 16), c4 = i - r * (PX_W / 16);
             const int gx = ox - PX_XO + c4 * 16, gy = oy - 4 + r;
-            v[k] = make_uint4(0u, 0u, 0u, 0u);
+            v[k] = u32x4{0u, 0u, 0u, 0u};
             if (i < PX_H * (PX_W / 16) && gy >= 0 && gy < h && gx >= 0 && gx + 15 < stride)
-                v[k] = *reinterpret_cast<const uint4*>(base + (size_t)gy * stride + gx);
+                v[k] = *(const __attribute__((address_space(1))) u32x4*)(uintptr_t)(base + (size_t)gy * stride + gx);   // global, not flat: the level-0 select hides the address space
         }
 #pragma unroll
         for (int k = 0; k < 2; k++)
-            if (tid + 256 * k < PX_H * (PX_W / 16)) reinterpret_cast<uint4*>(px)[tid + 256 * k] = v[k];
+            if (tid + 256 * k < PX_H * (PX_W / 16)) reinterpret_cast<u32x4*>(px)[tid + 256 * k] = v[k];
     } else {
         for (int wv = tid; wv < PX_H * (PX_W / 4); wv += 256) {
             const int r = wv / (PX_W / 4), cw = wv % (PX_W / 4);
             const int gx = ox - PX_XO + cw * 4, gy = oy - 4 + r;
             uint32_t v = 0;
             if (gy >= 0 && gy < h && gx >= 0 && gx + 3 < stride)
-                v = *reinterpret_cast<const uint32_t*>(base + (size_t)gy * stride + gx);
+                v = *(const __attribute__((address_space(1))) uint32_t*)(uintptr_t)(base + (size_t)gy * stride + gx);
             px[wv] = v;
         }
     }
@@ -323,46 +324,66 @@ __global__ __launch_bounds__(256) void k_fast(const FastTile* __restrict__ tiles
     const int lox = max(3, edge - 1), hix = min(w - 3, w - edge + 1);
     const int loy = max(3, edge - 1), hiy = min(h - 3, h - edge + 1);
     {
-        // score columns 1..64 (the tile's own 64 columns): unit = 4 adjacent positions whose centre pixels
-        // are one aligned LDS dword; 11 dword reads + 4 v_alignbyte give centre and the 8 tested ring
-        // pixels for all four; 34 rows x 16 units
-        const pk16 T = {(short)threshold, (short)threshold};
+        // score columns 1..128 (the tile's own columns): unit = 4 adjacent positions whose centre pixels are one aligned LDS
+        // dword; 5 dword reads + 4 v_perm give centre and the 4 tested ring pixels for all four; 34 rows x 32 units, 8 rows per
+        // iteration.  Range checks are folded in: the x range is a per-lane cap on the test value (loop invariant), the row
+        // range is wave-uniform scalar code that touches the cap only in the (rare) partially valid row pair.
         const int q = tid & (FT_W / 4 - 1);                              // the unit column of a thread is fixed (256 % 32 == 0)
         const int gx0 = ox + 4 * q;                                      // image x of position sx = 4q+1
         const bool x0 = gx0 >= lox && gx0 < hix, x1 = gx0 + 1 >= lox && gx0 + 1 < hix;
         const bool x2 = gx0 + 2 >= lox && gx0 + 2 < hix, x3 = gx0 + 3 >= lox && gx0 + 3 < hix;
+        const uint32_t CAP_OK = 0x7FFFu, CAP_NO = 0x8000u;              // min(value, cap): 0x7fff keeps the value, -32768 fails every threshold
+        const uint32_t cap_ev = (x0 ? CAP_OK : CAP_NO) | ((x2 ? CAP_OK : CAP_NO) << 16);
+        const uint32_t cap_od = (x1 ? CAP_OK : CAP_NO) | ((x3 ? CAP_OK : CAP_NO) << 16);
+        const int sy_lo = max(0, loy - (oy - 1)), sy_hi = min(SC_H, hiy - (oy - 1));     // valid score rows of this tile
         const int lane = tid & 63;
-        for (int sy = tid / (FT_W / 4); sy < SC_H; sy += 256 / (FT_W / 4)) {
-            const int gy = oy - 1 + sy;
-            const bool rowok = gy >= loy && gy < hiy;
-            const uint32_t* r0 = px + (sy + 3) * (PX_W / 4) + q + (PX_XO / 4 - 1);   // r0[1] = the 4 centre pixels
-            const uint32_t c0 = r0[0], C = r0[1], c2 = r0[2];
-            const uint32_t N = r0[3 * (PX_W / 4) + 1], S = r0[-3 * (PX_W / 4) + 1];
-            const uint32_t M = 0x00FF00FFu;
-            // even lanes = positions 0, 2; odd lanes = positions 1, 3.  east = +3 px: bytes 3..6 of c2:C; west = -3 px: bytes 1..4 of C:c0
-            const pk16 pev = pretest_axis(as_pk(C & M), as_pk(N & M), as_pk(S & M), PICKB(c2, C, 3, 5), PICKB(C, c0, 1, 3), T);
-            const pk16 pod = pretest_axis(as_pk((C >> 8) & M), as_pk((N >> 8) & M), as_pk((S >> 8) & M), PICKB(c2, C, 4, 6), PICKB(C, c0, 2, 4), T);
-            const bool p0 = pev.x > 0 && x0 && rowok, p1 = pod.x > 0 && x1 && rowok;
-            const bool p2 = pev.y > 0 && x2 && rowok, p3 = pod.y > 0 && x3 && rowok;
-            // wave-aggregated queue append (queue order is irrelevant: k_select sorts)
-            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(p0), m1 = __builtin_amdgcn_ballot_w64(p1);
-            const unsigned long long m2 = __builtin_amdgcn_ballot_w64(p2), m3 = __builtin_amdgcn_ballot_w64(p3);
-            const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
-            const int tot = n0 + n1 + n2 + n3;
-            if (tot) {
-                int qb = 0;
-                if (lane == 0) qb = atomicAdd(&qn, tot);
-                qb = __builtin_amdgcn_readfirstlane(qb);
-                const int pos = sy * SC_W + 4 * q + 1;
-                // v_mbcnt: number of set mask bits below this lane, accumulated onto the running base
-                const uint32_t i0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, (uint32_t)qb));
-                const uint32_t i1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, (uint32_t)(qb + n0)));
-                const uint32_t i2 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, (uint32_t)(qb + n0 + n1)));
-                const uint32_t i3 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m3, (uint32_t)(qb + n0 + n1 + n2)));
-                if (p0) queue[i0] = (uint16_t)pos;
-                if (p1) queue[i1] = (uint16_t)(pos + 1);
-                if (p2) queue[i2] = (uint16_t)(pos + 2);
-                if (p3) queue[i3] = (uint16_t)(pos + 3);
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const short Tt = (short)threshold;
+        constexpr int NIT = (SC_H + 7) / 8;
+        bool ps[NIT][4];
+        int cnt[NIT][4];
+        int tot = 0;
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { ps[it][j] = false; cnt[it][j] = 0; }
+            const int wr = it * 8 + 2 * wv;                              // the wave's row pair: wr (lanes 0..31), wr + 1 (lanes 32..63)
+            if (wr < sy_hi && wr + 1 >= sy_lo) {
+                const int sy = it * 8 + (tid >> 5);
+                uint32_t ce = cap_ev, co = cap_od;
+                if (wr < sy_lo || wr + 1 >= sy_hi) { const bool v = sy >= sy_lo && sy < sy_hi; ce = v ? ce : (CAP_NO | (CAP_NO << 16)); co = v ? co : (CAP_NO | (CAP_NO << 16)); }
+                const uint32_t* r0 = px + (sy + 3) * (PX_W / 4) + q + (PX_XO / 4 - 1);   // r0[1] = the 4 centre pixels
+                const uint32_t c0 = r0[0], C = r0[1], c2 = r0[2];
+                const uint32_t N = r0[3 * (PX_W / 4) + 1], S = r0[-3 * (PX_W / 4) + 1];
+                const uint32_t M = 0x00FF00FFu;
+                // even lanes = positions 0, 2; odd lanes = positions 1, 3.  east = +3 px: bytes 3..6 of c2:C; west = -3 px: bytes 1..4 of C:c0
+                const pk16 pev = pmin(pretest_axis(as_pk(C & M), as_pk(N & M), as_pk(S & M), PICKB(c2, C, 3, 5), PICKB(C, c0, 1, 3)), as_pk(ce));
+                const pk16 pod = pmin(pretest_axis(as_pk((C >> 8) & M), as_pk((N >> 8) & M), as_pk((S >> 8) & M), PICKB(c2, C, 4, 6), PICKB(C, c0, 2, 4)), as_pk(co));
+                ps[it][0] = pev.x > Tt; ps[it][1] = pod.x > Tt; ps[it][2] = pev.y > Tt; ps[it][3] = pod.y > Tt;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { cnt[it][j] = __popcll(__builtin_amdgcn_ballot_w64(ps[it][j])); tot += cnt[it][j]; }
+            }
+        }
+        // ONE reservation per wave for all its rows, then the wave-aggregated append (queue order is irrelevant: k_select
+        // sorts).  Lanes that did not pass store into a scratch word behind the queue: no exec-mask juggling per store.
+        if (tot) {
+            int qb = 0;
+            if (lane == 0) qb = atomicAdd(&qn, tot);
+            qb = __builtin_amdgcn_readfirstlane(qb);
+            const int pos = (tid >> 5) * SC_W + 4 * q + 1;
+            const uint32_t scratch = SC_H * SC_W + lane;
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (cnt[it][j]) {                                    // wave-uniform
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64(ps[it][j]);
+                        // v_mbcnt: number of set mask bits below this lane, accumulated onto the running base
+                        const uint32_t i = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)qb));
+                        queue[ps[it][j] ? i : scratch] = (uint16_t)(pos + it * 8 * SC_W + j);
+                        qb += cnt[it][j];
+                    }
+                }
             }
         }
         // halo score columns 0 and 65 (NMS neighbours of the first/last tile column): byte-wise test
