@@ -113,6 +113,10 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
     return d;
 }
 
+// NC = column groups of 32 fixed descriptors per wave.  NC = 2: every 16-byte LDS read of a swept row feeds two MFMA chains
+// (the LDS pipe and the staging traffic per MFMA halve, one barrier per 16 MFMAs instead of 8) at the price of 64 + 32
+// operand / accumulator registers per lane.
+template <int NC>
 __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, const int32_t* __restrict__ nkp, int kcap,
                                                   const int32_t* __restrict__ pair_q, const int32_t* __restrict__ pair_t,
                                                   uint32_t* __restrict__ knn12, uint32_t* __restrict__ knn21, int npairs, int nchunks) {
@@ -129,20 +133,21 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, 
     const int rs = dir == 0 ? pair_t[pair] : pair_q[pair];        // swept set
     if (rf < 0 || rs < 0) return;
     const int nf = min(nkp[rf], kcap), ns = min(nkp[rs], kcap);
-    const int fbase = chunk * 128;
+    const int fbase = chunk * (128 * NC);
     if (fbase >= nf) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
-    const int fidx = fbase + wave * 32 + col;
-    v4i bf[8];
-    {
-        const int8_t* xf = X + ((size_t)rf * kcap + min(fidx, nf - 1)) * 256 + 16 * h;
+    const int fidx0 = fbase + wave * (32 * NC) + col;
+    v4i bf[NC][8];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int8_t* xf = X + ((size_t)rf * kcap + min(fidx0 + 32 * c, nf - 1)) * 256 + 16 * h;
 #pragma unroll
         for (int ks = 0; ks < 8; ks++) {
             // the fixed operand is negated (+-1 bytes: x ^ 0xFE swaps 0x01 and 0xFF), so acc = -dot = 2*Hamming - 256
             // and the key is one v_lshl_add_u32 of the accumulator
             const v4i x = *reinterpret_cast<const v4i*>(xf + 32 * ks);
-            bf[ks] = v4i{x[0] ^ (int)0xFEFEFEFE, x[1] ^ (int)0xFEFEFEFE, x[2] ^ (int)0xFEFEFEFE, x[3] ^ (int)0xFEFEFEFE};
+            bf[c][ks] = v4i{x[0] ^ (int)0xFEFEFEFE, x[1] ^ (int)0xFEFEFEFE, x[2] ^ (int)0xFEFEFEFE, x[3] ^ (int)0xFEFEFEFE};
         }
     }
     const int8_t* xs = X + (size_t)rs * kcap * 256;
@@ -157,52 +162,67 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, 
     // running keys: (2*Hamming << 15) | (tile << 4) | accumulator register.  Inside a lane the register order is the
     // row order, so (tile, register) breaks ties exactly like the row index; it is a wave-uniform addend (SGPR).  The
     // true row index is restored before the two half-lanes of a column are merged.
-    uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
+    uint32_t k0[NC], k1[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) { k0[c] = 0xFFFFFFFFu; k1[c] = 0xFFFFFFFFu; }
     if (ntiles > 0) { STAGE_LOAD(0); STAGE_STORE(0); }
     __syncthreads();
     for (int t = 0; t < ntiles; t++) {
         if (t + 1 < ntiles) STAGE_LOAD(t + 1);
         const uint4* tb = tile[t & 1] + col * KM_ROW + h;
-        v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        v16i acc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) acc[c] = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < 8; ks++) {
             const uint4 au = tb[2 * ks];
             const v4i a = {(int)au.x, (int)au.y, (int)au.z, (int)au.w};
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[ks], acc, 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < NC; c++) acc[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[c][ks], acc[c], 0, 0, 0);
         }
         const uint32_t kt = (256u << 15) + ((uint32_t)t << 4);
         if (t * 32 + 32 <= ns) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const uint32_t key = lshl15_add(acc[r], kt + (uint32_t)r);
-                k1 = umed3(k0, k1, key);            // k0 <= k1: second smallest of the three
-                k0 = min(k0, key);
-            }
+            for (int c = 0; c < NC; c++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const uint32_t key = lshl15_add(acc[c][r], kt + (uint32_t)r);
+                    k1[c] = umed3(k0[c], k1[c], key);            // k0 <= k1: second smallest of the three
+                    k0[c] = min(k0[c], key);
+                }
         } else {
             const int toff = t * 32 + 4 * h;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int trow = toff + (r & 3) + 8 * (r >> 2);
-                const uint32_t key = trow < ns ? lshl15_add(acc[r], kt + (uint32_t)r) : 0xFFFFFFFFu;
-                k1 = umed3(k0, k1, key);
-                k0 = min(k0, key);
-            }
+            for (int c = 0; c < NC; c++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int trow = toff + (r & 3) + 8 * (r >> 2);
+                    const uint32_t key = trow < ns ? lshl15_add(acc[c][r], kt + (uint32_t)r) : 0xFFFFFFFFu;
+                    k1[c] = umed3(k0[c], k1[c], key);
+                    k0[c] = min(k0[c], key);
+                }
         }
         if (t + 1 < ntiles) STAGE_STORE((t + 1) & 1);
         __syncthreads();
     }
+#undef STAGE_LOAD
+#undef STAGE_STORE
     auto true_key = [&](uint32_t k) {
         const uint32_t lo = k & 0x7FFFu, r = lo & 15u;
         const uint32_t row = (lo >> 4) * 32u + 4u * (uint32_t)h + (r & 3u) + 8u * (r >> 2);
         return k == 0xFFFFFFFFu ? k : ((k & ~0x7FFFu) | row);
     };
-    k0 = true_key(k0); k1 = true_key(k1);
-    // lanes l and l+32 hold the two row halves of the same column
-    const uint32_t o0 = __shfl_xor(k0, 32), o1 = __shfl_xor(k1, 32);
-    const uint32_t m0 = min(k0, o0), m1 = min(max(k0, o0), min(k1, o1));
-    if (h == 0 && fidx < nf) {
-        uint32_t* outp = (dir == 0 ? knn12 : knn21) + ((size_t)pair * kcap + fidx) * 2;
-        outp[0] = m0; outp[1] = m1;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const uint32_t a0 = true_key(k0[c]), a1 = true_key(k1[c]);
+        // lanes l and l+32 hold the two row halves of the same column
+        const uint32_t o0 = __shfl_xor(a0, 32), o1 = __shfl_xor(a1, 32);
+        const uint32_t m0 = min(a0, o0), m1 = min(max(a0, o0), min(a1, o1));
+        const int fidx = fidx0 + 32 * c;
+        if (h == 0 && fidx < nf) {
+            uint32_t* outp = (dir == 0 ? knn12 : knn21) + ((size_t)pair * kcap + fidx) * 2;
+            outp[0] = m0; outp[1] = m1;
+        }
     }
 }
 
@@ -361,10 +381,16 @@ int launch_match(vis_ctx* ctx, Plan* pl, int npairs) {
     if (npairs <= 0) return VIS_OK;
     static const bool force_popcount = getenv("VIS_KNN_POPCOUNT") != nullptr;     // A/B measurements only
     if (pl->d_descx && pl->kcap < 32768 && !force_popcount) {
-        const int nchunks = (pl->kcap + 127) / 128;
+        static const int nc = getenv("VIS_KNN_NC") ? atoi(getenv("VIS_KNN_NC")) : 2;     // A/B measurements only
+        const int per_wg = 128 * (nc == 1 ? 1 : 2);
+        const int nchunks = (pl->kcap + per_wg - 1) / per_wg;
         dim3 grid(8 * ((npairs + 7) / 8) * 2 * nchunks);
-        hipLaunchKernelGGL(k_knn_mfma, grid, dim3(256), 0, ctx->stream, pl->d_descx, pl->d_nkp, pl->kcap,
-                           pl->d_pair_q, pl->d_pair_t, pl->d_knn12, pl->d_knn21, npairs, nchunks);
+        if (nc == 1)
+            hipLaunchKernelGGL(k_knn_mfma<1>, grid, dim3(256), 0, ctx->stream, pl->d_descx, pl->d_nkp, pl->kcap,
+                               pl->d_pair_q, pl->d_pair_t, pl->d_knn12, pl->d_knn21, npairs, nchunks);
+        else
+            hipLaunchKernelGGL(k_knn_mfma<2>, grid, dim3(256), 0, ctx->stream, pl->d_descx, pl->d_nkp, pl->kcap,
+                               pl->d_pair_q, pl->d_pair_t, pl->d_knn12, pl->d_knn21, npairs, nchunks);
         HIPCHK(ctx, hipGetLastError());
         return VIS_OK;
     }
