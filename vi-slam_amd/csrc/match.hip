@@ -71,9 +71,10 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ desc, 
 // ------------------------------------------------------------------------------------------------
 // MFMA formulation of the same 2-NN (default path).  Every hot kernel of this library is bound by the
 // integer VALU issue rate (~0.62 T wave-instructions/s measured, tools/valu_peak.hip); the matrix pipe is
-// idle.  With descriptor bits expanded to int8 +1/-1, sum_k a_k b_k = 256 - 2*Hamming, so one
-// v_mfma_i32_32x32x32_i8 chain (K = 256 = 8 instructions) yields a 32 x 32 block of exact distances and
-// the VALU only maintains the packed top-2 keys: ~6 VALU instructions per pair instead of 19.
+// idle.  With descriptor bits expanded to int8 +64/-64, sum_k a_k b_k = 4096 * (256 - 2*Hamming), so one
+// v_mfma_i32_32x32x32_i8 chain (K = 256 = 8 instructions) yields a 32 x 32 block of exact distances -- already in
+// key form, because the chain starts from the (tile, register) index in the 13 free low bits -- and the VALU only
+// maintains the top-2 keys: 2 instructions (v_med3_i32, v_min_i32) per distance instead of 19.
 // Columns (lane & 31) = the 32 descriptors whose neighbours this wave tracks (B operand, in registers);
 // rows = the swept set, staged through LDS 32 descriptors at a time (row stride 272 B: conflict-free
 // ds_read_b128).  Results are bit-identical to k_knn2 (same key order): tests/test_match_gpu.py.
@@ -95,21 +96,15 @@ __global__ __launch_bounds__(256) void k_expand(const uint8_t* __restrict__ desc
 #pragma unroll
     for (int n = 0; n < 4; n++) {
         const uint32_t spread = (((bits >> (4 * n)) & 0xFu) * 0x00204081u) & 0x01010101u;     // 4 bits -> 4 bytes of 0/1
-        o[n] = spread | ((spread ^ 0x01010101u) * 0xFFu);                                       // 1 -> +1, 0 -> -1 (0xFF)
+        o[n] = 0xC0C0C0C0u ^ (spread << 7);                                                     // 1 -> +64 (0x40), 0 -> -64 (0xC0)
     }
     *reinterpret_cast<uint4*>(X + ((size_t)rec * kcap + i) * 256 + 16 * part) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
 #define KM_ROW 17            // uint4 per LDS row: 256 B of descriptor + 16 B pad
-// (a << 15) + s with the wave-uniform addend kept in an SGPR (one VALU instruction per key)
-__device__ __forceinline__ uint32_t lshl15_add(int a, uint32_t s) {
-    uint32_t d;
-    asm("v_lshl_add_u32 %0, %1, 15, %2" : "=v"(d) : "v"(a), "s"(s));
-    return d;
-}
-__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t d;
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+__device__ __forceinline__ int imed3(int a, int b, int c) {
+    int d;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
 
@@ -144,10 +139,10 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, 
         const int8_t* xf = X + ((size_t)rf * kcap + min(fidx0 + 32 * c, nf - 1)) * 256 + 16 * h;
 #pragma unroll
         for (int ks = 0; ks < 8; ks++) {
-            // the fixed operand is negated (+-1 bytes: x ^ 0xFE swaps 0x01 and 0xFF), so acc = -dot = 2*Hamming - 256
-            // and the key is one v_lshl_add_u32 of the accumulator
+            // the fixed operand is negated (+-64 bytes: x ^ 0x80 swaps 0x40 and 0xC0), so the chain adds -dot =
+            // 4096 * (2 * Hamming - 256) onto its start value
             const v4i x = *reinterpret_cast<const v4i*>(xf + 32 * ks);
-            bf[c][ks] = v4i{x[0] ^ (int)0xFEFEFEFE, x[1] ^ (int)0xFEFEFEFE, x[2] ^ (int)0xFEFEFEFE, x[3] ^ (int)0xFEFEFEFE};
+            bf[c][ks] = v4i{x[0] ^ (int)0x80808080, x[1] ^ (int)0x80808080, x[2] ^ (int)0x80808080, x[3] ^ (int)0x80808080};
         }
     }
     const int8_t* xs = X + (size_t)rs * kcap * 256;
@@ -159,12 +154,15 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, 
 #define STAGE_LOAD(t_) do { pre0 = *reinterpret_cast<const uint4*>(xs + (size_t)min((t_) * 32 + st_row0, ns - 1) * 256 + 16 * st_c); \
                             pre1 = *reinterpret_cast<const uint4*>(xs + (size_t)min((t_) * 32 + st_row1, ns - 1) * 256 + 16 * st_c); } while (0)
 #define STAGE_STORE(buf_) do { tile[buf_][st_row0 * KM_ROW + st_c] = pre0; tile[buf_][st_row1 * KM_ROW + st_c] = pre1; } while (0)
-    // running keys: (2*Hamming << 15) | (tile << 4) | accumulator register.  Inside a lane the register order is the
-    // row order, so (tile, register) breaks ties exactly like the row index; it is a wave-uniform addend (SGPR).  The
-    // true row index is restored before the two half-lanes of a column are merged.
-    uint32_t k0[NC], k1[NC];
+    // Descriptor bytes are +-64, so the dot products are multiples of 8192 and the 13 low bits of an accumulator are free:
+    // the chain STARTS from (tile << 4) | accumulator register, and the finished accumulator IS the running key
+    // 8192 * Hamming - 2^20 + (tile << 4 | register) -- no per-element key construction.  Inside a lane the register order
+    // is the row order, so (tile, register) breaks ties exactly like the row index; the true row index is restored before
+    // the two half-lanes of a column are merged.  Keys are signed; INT_MAX = none.
+    int k0[NC], k1[NC];
 #pragma unroll
-    for (int c = 0; c < NC; c++) { k0[c] = 0xFFFFFFFFu; k1[c] = 0xFFFFFFFFu; }
+    for (int c = 0; c < NC; c++) { k0[c] = 0x7FFFFFFF; k1[c] = 0x7FFFFFFF; }
+    v16i cstart = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
     if (ntiles > 0) { STAGE_LOAD(0); STAGE_STORE(0); }
     __syncthreads();
     for (int t = 0; t < ntiles; t++) {
@@ -172,7 +170,7 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, 
         const uint4* tb = tile[t & 1] + col * KM_ROW + h;
         v16i acc[NC];
 #pragma unroll
-        for (int c = 0; c < NC; c++) acc[c] = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int c = 0; c < NC; c++) acc[c] = cstart;
 #pragma unroll
         for (int ks = 0; ks < 8; ks++) {
             const uint4 au = tb[2 * ks];
@@ -180,14 +178,14 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, 
 #pragma unroll
             for (int c = 0; c < NC; c++) acc[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[c][ks], acc[c], 0, 0, 0);
         }
-        const uint32_t kt = (256u << 15) + ((uint32_t)t << 4);
+        cstart += 16;
         if (t * 32 + 32 <= ns) {
 #pragma unroll
             for (int c = 0; c < NC; c++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const uint32_t key = lshl15_add(acc[c][r], kt + (uint32_t)r);
-                    k1[c] = umed3(k0[c], k1[c], key);            // k0 <= k1: second smallest of the three
+                    const int key = acc[c][r];
+                    k1[c] = imed3(k0[c], k1[c], key);            // k0 <= k1: second smallest of the three
                     k0[c] = min(k0[c], key);
                 }
         } else {
@@ -197,8 +195,8 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, 
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int trow = toff + (r & 3) + 8 * (r >> 2);
-                    const uint32_t key = trow < ns ? lshl15_add(acc[c][r], kt + (uint32_t)r) : 0xFFFFFFFFu;
-                    k1[c] = umed3(k0[c], k1[c], key);
+                    const int key = trow < ns ? acc[c][r] : 0x7FFFFFFF;
+                    k1[c] = imed3(k0[c], k1[c], key);
                     k0[c] = min(k0[c], key);
                 }
         }
@@ -207,10 +205,11 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, 
     }
 #undef STAGE_LOAD
 #undef STAGE_STORE
-    auto true_key = [&](uint32_t k) {
-        const uint32_t lo = k & 0x7FFFu, r = lo & 15u;
+    // (Hamming << 16) | row: the record format of k_filter / the popcount kernel
+    auto true_key = [&](int k) -> uint32_t {
+        const uint32_t u = (uint32_t)(k + (1 << 20)), lo = u & 8191u, r = lo & 15u;
         const uint32_t row = (lo >> 4) * 32u + 4u * (uint32_t)h + (r & 3u) + 8u * (r >> 2);
-        return k == 0xFFFFFFFFu ? k : ((k & ~0x7FFFu) | row);
+        return k == 0x7FFFFFFF ? 0xFFFFFFFFu : (((u >> 13) << 16) | row);
     };
 #pragma unroll
     for (int c = 0; c < NC; c++) {
@@ -380,7 +379,7 @@ int launch_expand(vis_ctx* ctx, Plan* pl, int rec_first, int rec_count) {
 int launch_match(vis_ctx* ctx, Plan* pl, int npairs) {
     if (npairs <= 0) return VIS_OK;
     static const bool force_popcount = getenv("VIS_KNN_POPCOUNT") != nullptr;     // A/B measurements only
-    if (pl->d_descx && pl->kcap < 32768 && !force_popcount) {
+    if (pl->d_descx && pl->kcap <= 16384 && !force_popcount) {
         static const int nc = getenv("VIS_KNN_NC") ? atoi(getenv("VIS_KNN_NC")) : 2;     // A/B measurements only
         const int per_wg = 128 * (nc == 1 ? 1 : 2);
         const int nchunks = (pl->kcap + per_wg - 1) / per_wg;
