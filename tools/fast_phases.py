@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Per-phase cycle shares of k_fast (diagnostic build path: VIS_FAST_STAMPS=1 makes thread 0 of every workgroup add its
-s_memtime deltas between the phase barriers to 16 device words).  Shares only -- the stamped run is not a timing."""
+"""Per-phase cycle shares of k_fast.  Needs the diagnostic build (`make -C vi-slam_amd/csrc clean all EXTRA=-DVIS_FAST_PROFILE`):
+with VIS_FAST_STAMPS=1 thread 0 of every workgroup then stores its s_memtime deltas between the phase barriers into a
+private record.  Shares only -- the stamped run is not a timing; the default build carries no stamp code."""
 import ctypes as C
 import os
 import sys

@@ -15,6 +15,6 @@ import csv,glob,collections
 acc=collections.defaultdict(list)
 for f in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if r["Kernel_Name"].startswith("$KERNEL"): acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if r["Kernel_Name"].startswith("$KERNEL") or ("void "+"$KERNEL") in r["Kernel_Name"][:len("$KERNEL")+6]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("$KERNEL", {k: round(sum(v)/len(v)) for k,v in sorted(acc.items())})
 PY

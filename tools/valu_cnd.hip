@@ -38,6 +38,9 @@ __global__ __launch_bounds__(256) void k_spin(uint32_t* out, int iters, uint32_t
                 if (MODE == 20) asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %0, %1, %0, vcc\n v_pk_min_i16 %0, %0, %1\n v_pk_max_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
                 if (MODE == 21) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc\n v_cndmask_b32_e64 %0, %1, %0, vcc\n v_pk_min_i16 %0, %0, %1\n v_pk_max_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
                 if (MODE == 22) asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %0, %1, %0, vcc\n v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %0, %1, %0, vcc" : "+v"(a[i]) : "v"(b));
+                if (MODE == 23) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (MODE == 24) asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (MODE == 25) asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(*(unsigned long long*)&a[i & 6]) : "v"(b), "v"(seed) : "s20", "s21");
                 if (MODE == 12) asm volatile("v_cmp_lt_i32_e32 vcc, %0, %1" :: "v"(a[i]), "v"(b) : "vcc");
             }
     }
@@ -82,6 +85,8 @@ int main() {
         run<20>(d, "[2 cndmask vcc + 2 pk ops] per block of 4", m);
         run<21>(d, "[2 cndmask_e64 vcc + 2 pk ops] per block of 4", m);
         run<22>(d, "[4 cndmask vcc, dependent] per block of 4", m);
+        run<23>(d, "v_mul_hi_u32", m);
+        run<24>(d, "v_mul_hi_u32_u24", m);
         run<18>(d, "v_cndmask_b32_sdwa vcc", m);
         run<19>(d, "v_cndmask_b32_dpp vcc", m);
         run<4>(d, "v_xor_b32 (reference)", m);
