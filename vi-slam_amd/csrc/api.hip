@@ -253,7 +253,7 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
         DALLOC(pl->d_seg_kp[l], (size_t)pl->lv[l].keep_cap * B);
     }
     pl->total_tiles = pl->lv[L - 1].tile_base + pl->lv[L - 1].tiles_x * pl->lv[L - 1].tiles_y;
-    DALLOC(pl->d_tile_cnt, (size_t)B * pl->total_tiles); DALLOC(pl->d_seg_cnt, (size_t)B * L);
+    DALLOC(pl->d_tile_cnt, (size_t)B * pl->total_tiles); DALLOC(pl->d_seg_cnt, (size_t)B * L + VIS_MAX_LEVELS);   // + padding: k_describe reads VIS_MAX_LEVELS counts per frame
     if (pl->total_tiles > 65535) { plan_destroy(pl); return VIS_E_INVALID; }        // k_fast: gridDim.y
     { int rc2 = build_fast_tiles(ctx, pl); if (rc2) { plan_destroy(pl); return rc2; } }
     DALLOC(pl->d_flags, 4);

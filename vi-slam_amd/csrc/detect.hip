@@ -597,13 +597,19 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
     __shared__ __attribute__((aligned(16))) unsigned char lds[4 * WAVE_LDS];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    int f, kb;
-    if (!xcd_frame_map(blockIdx.x, (kcap + 3) / 4, nframes, f, kb)) return;
+    // grid (8, keypoint groups, ceil(frames / 8)): blockIdx.x is the XCD (see k_fast)
+    const int f = blockIdx.z * 8 + blockIdx.x, kb = blockIdx.y;
+    if (f >= nframes) return;
     const int g = kb * 4 + wv;
-    // locate (level, index) of packed keypoint g: level-major, canonical order inside a level
+    // locate (level, index) of packed keypoint g: level-major, canonical order inside a level.  All level counts of the
+    // frame arrive with ONE scalar load (the buffer is padded by VIS_MAX_LEVELS words); a loop of dependent s_load_dword
+    // cost every wave eight memory round trips before its first pixel load.
+    struct SegCounts { int c[VIS_MAX_LEVELS]; };
+    const SegCounts SC = *reinterpret_cast<const SegCounts*>(seg_cnt + (size_t)f * D.L);
     int total = 0, lev = -1, idx = 0;
-    for (int l = 0; l < D.L; l++) {
-        const int c = seg_cnt[f * D.L + l];
+#pragma unroll
+    for (int l = 0; l < VIS_MAX_LEVELS; l++) {
+        const int c = l < D.L ? SC.c[l] : 0;
         if (lev < 0 && g < total + c) { lev = l; idx = g - total; }
         total += c;
     }
@@ -901,7 +907,7 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
                            pl->d_seg_cnt, pl->d_flags, max_surv, n);
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[3], st);
-    hipLaunchKernelGGL(k_describe, dim3(xcd_grid(n, (pl->kcap + 3) / 4)), dim3(256), 0, st, D, G, pl->d_seg_cnt,
+    hipLaunchKernelGGL(k_describe, dim3(8, (pl->kcap + 3) / 4, (n + 7) / 8), dim3(256), 0, st, D, G, pl->d_seg_cnt,
                        pl->d_kps, pl->d_desc, pl->d_nkp, pl->kcap, rec0, pl->d_flags, n);
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[4], st);
     ctx->tm.launches_fast = nfast;
