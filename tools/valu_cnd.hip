@@ -41,6 +41,16 @@ __global__ __launch_bounds__(256) void k_spin(uint32_t* out, int iters, uint32_t
                 if (MODE == 23) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
                 if (MODE == 24) asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(b));
                 if (MODE == 25) asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(*(unsigned long long*)&a[i & 6]) : "v"(b), "v"(seed) : "s20", "s21");
+                if (MODE == 30) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(*(double*)&a[i & 6]) : "v"(1.0000001));
+                if (MODE == 31) asm volatile("v_add_f64 %0, %0, %1" : "+v"(*(double*)&a[i & 6]) : "v"(1.0000001));
+                if (MODE == 32) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(*(double*)&a[i & 6]) : "v"(1.0000001));
+                if (MODE == 33) asm volatile("v_rndne_f64 %0, %0" : "+v"(*(double*)&a[i & 6]));
+                if (MODE == 34) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(*(double*)&a[i & 6]) : "v"(b));
+                if (MODE == 35) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a[i]) : "v"(1.0000001));
+                if (MODE == 36) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+                if (MODE == 37) asm volatile("v_rcp_f64 %0, %0" : "+v"(*(double*)&a[i & 6]));
+                if (MODE == 38) asm volatile("v_sqrt_f64 %0, %0" : "+v"(*(double*)&a[i & 6]));
+                if (MODE == 39) asm volatile("v_div_scale_f64 %0, vcc, %0, %1, %0" : "+v"(*(double*)&a[i & 6]) : "v"(1.0000001) : "vcc");
                 if (MODE == 12) asm volatile("v_cmp_lt_i32_e32 vcc, %0, %1" :: "v"(a[i]), "v"(b) : "vcc");
             }
     }
@@ -87,6 +97,16 @@ int main() {
         run<22>(d, "[4 cndmask vcc, dependent] per block of 4", m);
         run<23>(d, "v_mul_hi_u32", m);
         run<24>(d, "v_mul_hi_u32_u24", m);
+        run<30>(d, "v_mul_f64 (4 chains)", m);
+        run<31>(d, "v_add_f64 (4 chains)", m);
+        run<32>(d, "v_fma_f64 (4 chains)", m);
+        run<33>(d, "v_rndne_f64", m);
+        run<34>(d, "v_cvt_f64_f32", m);
+        run<35>(d, "v_cvt_f32_f64", m);
+        run<36>(d, "v_rcp_f32", m);
+        run<37>(d, "v_rcp_f64", m);
+        run<38>(d, "v_sqrt_f64", m);
+        run<39>(d, "v_div_scale_f64", m);
         run<18>(d, "v_cndmask_b32_sdwa vcc", m);
         run<19>(d, "v_cndmask_b32_dpp vcc", m);
         run<4>(d, "v_xor_b32 (reference)", m);

@@ -508,7 +508,9 @@ __global__ __launch_bounds__(1024) void k_select_1024(DetLevels D, const int32_t
                               // stride): the 7 vertical taps of a sample are then 4 consecutive dwords
 #define WAVE_LDS (PW * PS + HW * HTS * 2 + 8)     // bytes per wave, multiple of 4
 
-__device__ const int8_t g_pattern[256 * 4] = {
+// the rBRIEF pattern as floats (x0, y0, x1, y1 per bit): the rotation works on floats, and 1024 int8 -> float conversions
+// per keypoint are not free
+__device__ const float g_pattern[256 * 4] = {
 #include "orb_pattern.inc"
 };
 
@@ -600,30 +602,33 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
     // grid (8, keypoint groups, ceil(frames / 8)): blockIdx.x is the XCD (see k_fast)
     const int f = blockIdx.z * 8 + blockIdx.x, kb = blockIdx.y;
     if (f >= nframes) return;
-    const int g = kb * 4 + wv;
-    // locate (level, index) of packed keypoint g: level-major, canonical order inside a level.  All level counts of the
-    // frame arrive with ONE scalar load (the buffer is padded by VIS_MAX_LEVELS words); a loop of dependent s_load_dword
-    // cost every wave eight memory round trips before its first pixel load.
+    // all level counts of the frame arrive with ONE scalar load (the buffer is padded by VIS_MAX_LEVELS words)
     struct SegCounts { int c[VIS_MAX_LEVELS]; };
     const SegCounts SC = *reinterpret_cast<const SegCounts*>(seg_cnt + (size_t)f * D.L);
-    int total = 0, lev = -1, idx = 0;
+    int total = 0;
+#pragma unroll
+    for (int l = 0; l < VIS_MAX_LEVELS; l++) total += l < D.L ? SC.c[l] : 0;
+    if (total > kcap) { total = kcap; if (kb == 0 && wv == 0 && lane == 0) atomicOr(flags, 8); }
+    if (kb == 0 && wv == 0 && lane == 0) nkp[rec0 + f] = total;
+    uint8_t* raw = lds + wv * WAVE_LDS;
+    uint32_t* hb32 = reinterpret_cast<uint32_t*>(raw + PW * PS);
+    // A wave walks over keypoints g, g + waves-per-frame, ...: the launch has a few ten thousand workgroups instead of one
+    // per four keypoints.  (With 353 k workgroups per 1024 frames the kernel spent half its time in workgroup dispatch:
+    // waves that returned right after the prologue still took 0.54 of its 1.11 ms.)
+    for (int g = kb * 4 + wv; g < total; g += (int)gridDim.y * 4) {
+    // locate (level, index) of packed keypoint g: level-major, canonical order inside a level
+    int lev = 0, idx = g, base_ = 0;
 #pragma unroll
     for (int l = 0; l < VIS_MAX_LEVELS; l++) {
         const int c = l < D.L ? SC.c[l] : 0;
-        if (lev < 0 && g < total + c) { lev = l; idx = g - total; }
-        total += c;
+        if (g >= base_ + c && l + 1 < D.L) { lev = l + 1; idx = g - (base_ + c); }
+        base_ += c;
     }
-    if (total > kcap) { total = kcap; if (g == 0 && lane == 0) atomicOr(flags, 8); }
-    if (g == 0 && lane == 0) nkp[rec0 + f] = total;
-    lev = __builtin_amdgcn_readfirstlane(lev); idx = __builtin_amdgcn_readfirstlane(idx);
-    if (lev < 0 || g >= kcap) return;
     const LevelArgs& A = D.lv[lev];
     const int stride = A.stride;
     const float4 kpr = A.seg_kp[(size_t)f * A.keep_cap + idx];
     const uint32_t xy = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(kpr.w));
     const int x0 = (int)(xy & 0xFFFFu), y0 = (int)(xy >> 16);
-    uint8_t* raw = lds + wv * WAVE_LDS;
-    uint32_t* hb32 = reinterpret_cast<uint32_t*>(raw + PW * PS);
     const uint8_t* img = A.img + (size_t)f * A.frame_bytes + (size_t)(y0 - PR) * stride + (x0 - PR);
     // 43 rows x 44 bytes as 11 unaligned dwords per row; lane = (row % 5, dword), 9 loads cover rows 0..44,
     // all in flight before the first LDS write (the patch of a kept keypoint is >= 9 px inside the image)
@@ -699,11 +704,11 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int bit = lane + 64 * k;
-        const char4 pt = *reinterpret_cast<const char4*>(g_pattern + 4 * bit);
+        const float4 pt = *reinterpret_cast<const float4*>(g_pattern + 4 * bit);
         int val[2];
 #pragma unroll
         for (int e = 0; e < 2; e++) {
-            const float px = (float)(e ? pt.z : pt.x), py = (float)(e ? pt.w : pt.y);
+            const float px = e ? pt.z : pt.x, py = e ? pt.w : pt.y;
             const float fx = px * a - py * b;
             const float fy = px * b + py * a;
             const int ix = __float2int_rn(fx), iy = __float2int_rn(fy);
@@ -732,6 +737,8 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
         kp.size = (float)G.patch_size * A.scale;
         kp.angle = angle; kp.response = kpr.z; kp.octave = lev; kp.class_id = -1;
         kps[(size_t)(rec0 + f) * kcap + g] = kp;
+    }
+    WAVE_SYNC();        // the next keypoint's patch overwrites this wave's LDS region
     }
 }
 
@@ -907,7 +914,9 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
                            pl->d_seg_cnt, pl->d_flags, max_surv, n);
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[3], st);
-    hipLaunchKernelGGL(k_describe, dim3(8, (pl->kcap + 3) / 4, (n + 7) / 8), dim3(256), 0, st, D, G, pl->d_seg_cnt,
+    // workgroups per frame: enough to fill the chip for small batches, a wave walks over many keypoints for large ones
+    const int desc_groups = std::max(1, std::min((pl->kcap + 3) / 4, (16384 + n - 1) / n));
+    hipLaunchKernelGGL(k_describe, dim3(8, desc_groups, (n + 7) / 8), dim3(256), 0, st, D, G, pl->d_seg_cnt,
                        pl->d_kps, pl->d_desc, pl->d_nkp, pl->kcap, rec0, pl->d_flags, n);
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[4], st);
     ctx->tm.launches_fast = nfast;
