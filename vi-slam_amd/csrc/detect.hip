@@ -615,35 +615,43 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
     // A wave walks over keypoints g, g + waves-per-frame, ...: the launch has a few ten thousand workgroups instead of one
     // per four keypoints.  (With 353 k workgroups per 1024 frames the kernel spent half its time in workgroup dispatch:
     // waves that returned right after the prologue still took 0.54 of its 1.11 ms.)
-    for (int g = kb * 4 + wv; g < total; g += (int)gridDim.y * 4) {
-    // locate (level, index) of packed keypoint g: level-major, canonical order inside a level
-    int lev = 0, idx = g, base_ = 0;
+    // lane l < L holds the packed index at which level l starts (INT_MAX beyond the last level): locating a keypoint is then
+    // one compare + ballot + popcount + v_readlane instead of a scalar search over the levels
+    int vstart = 0x7FFFFFFF;
+    {
+        int run = 0;
 #pragma unroll
-    for (int l = 0; l < VIS_MAX_LEVELS; l++) {
-        const int c = l < D.L ? SC.c[l] : 0;
-        if (g >= base_ + c && l + 1 < D.L) { lev = l + 1; idx = g - (base_ + c); }
-        base_ += c;
+        for (int l = 0; l < VIS_MAX_LEVELS; l++) {
+            if (l < D.L && lane == l) vstart = run;
+            run += l < D.L ? SC.c[l] : 0;
+        }
     }
+    const int lrs = (lane * 47) >> 9, lc = lane - lrs * 11;          // patch map: lane = (row % 5 [+ spare rows], dword); lane / 11
+    uint8_t* const lw = raw + lrs * PS + 4 * lc;
+    for (int g = kb * 4 + wv; g < total; g += (int)gridDim.y * 4) {
+    const int lev = __popcll(__builtin_amdgcn_ballot_w64(g >= vstart)) - 1;       // level-major packed index -> (level, index in level)
+    const int idx = g - __builtin_amdgcn_readlane(vstart, lev);
     const LevelArgs& A = D.lv[lev];
     const int stride = A.stride;
     const float4 kpr = A.seg_kp[(size_t)f * A.keep_cap + idx];
     const uint32_t xy = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(kpr.w));
     const int x0 = (int)(xy & 0xFFFFu), y0 = (int)(xy >> 16);
     const uint8_t* img = A.img + (size_t)f * A.frame_bytes + (size_t)(y0 - PR) * stride + (x0 - PR);
-    // 43 rows x 44 bytes as 11 unaligned dwords per row; lane = (row % 5, dword), 9 loads cover rows 0..44,
-    // all in flight before the first LDS write (the patch of a kept keypoint is >= 9 px inside the image)
+    // 43 rows x 44 bytes as 11 unaligned dwords per row; lane = (row % 5, dword), 9 loads cover rows 0..44, all in flight
+    // before the first LDS write.  No predicates: the spare lanes 55..63 copy rows 5, 10, .. 45 once more, rows beyond 42
+    // repeat row 42, and what is stored beyond row 42 lands in the first bytes of the blur buffer, which the horizontal
+    // pass rewrites before anything reads it.
     {
-        const int rs = (lane * 47) >> 9, c = lane - rs * 11;          // lane / 11 for lane < 64
-        const uint32_t goff = (uint32_t)(__mul24(rs, stride) + 4 * c);
+        const uint32_t goff = (uint32_t)(__mul24(lrs, stride) + 4 * lc);
         const int gstep = 5 * stride;
-        uint8_t* lw = raw + rs * PS + 4 * c;
         uint32_t v[9];
 #pragma unroll
-        for (int k = 0; k < 9; k++)
-            v[k] = (lane < 55 && rs + 5 * k < PW) ? *reinterpret_cast<const u32_unaligned*>((img + (size_t)k * gstep) + goff) : 0u;
+        for (int k = 0; k < 8; k++) v[k] = *reinterpret_cast<const u32_unaligned*>((img + (size_t)k * gstep) + goff);
+        // rows 40 .. 45: clamped to the last patch row (with the smallest legal edge_threshold, 22, rows 43 .. 45 may lie
+        // below the image)
+        v[8] = *reinterpret_cast<const u32_unaligned*>(img + (uint32_t)(__mul24(min(lrs + 40, PW - 1), stride) + 4 * lc));
 #pragma unroll
-        for (int k = 0; k < 9; k++)
-            if (lane < 55 && rs + 5 * k < PW) *reinterpret_cast<uint32_t*>(lw + k * 5 * PS) = v[k];
+        for (int k = 0; k < 9; k++) *reinterpret_cast<uint32_t*>(lw + k * 5 * PS) = v[k];
     }
     WAVE_SYNC();
     // IC angle over the radius-15 disc: each (row, dword) item is two byte dot products against a
@@ -675,7 +683,7 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
         uint32_t* wb = hb32 + 4 * g4 * (HTS / 2) + rs;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if (rs + 6 * k < (PW + 1) / 2) {
+            if (k < 3 || rs < 4) {                                     // row pairs 0 .. 21
                 const uint32_t* r0 = reinterpret_cast<const uint32_t*>(rb + k * 12 * PS);
                 const uint32_t* r1 = reinterpret_cast<const uint32_t*>(rb + k * 12 * PS + PS);   // row 43 of the last pair is
                 const uint32_t a0 = r0[0], a1 = r0[1], a2 = r0[2];                               // never sampled with weight != 0
