@@ -84,14 +84,37 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
     int cg = idx - rg * bx_count;
     if (cg < 0) { rg--; cg += bx_count; } else if (cg >= bx_count) { rg++; cg -= bx_count; }
     const int dx4 = cg * 4, dy0 = rg * RS_ROWS;
-    if (dy0 >= dh) return;
-    int sxs[4], a0s[4], a1s[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) resize_coef(min(dx4 + k, dw - 1), scale_x, sw, sxs[k], a0s[k], a1s[k]);
-    uint8_t* dbase = dst + (size_t)f * dframe + dx4;
-    // bytes of the 4-pixel store that lie inside the row (the rest is written as 0, as it always was)
-    const uint32_t keep = dx4 + 3 < dw ? 0xFFFFFFFFu : (0xFFFFFFFFu >> (8 * (dx4 + 4 - dw)));
     if (NARROW) {
+        // The row coefficients (two source row offsets, two Q11 weights) are the same for every thread of a row: the
+        // workgroup computes each destination row it touches ONCE (thread t -> row row_first + t) and shares them through
+        // LDS, instead of 8 double-precision source coordinates per thread (the kernel is VALU-issue bound and the
+        // coefficient arithmetic was 40 % of its instructions).
+        __shared__ uint4 yc[256];
+        const int tid = threadIdx.y * 64 + threadIdx.x;
+        int rg_first = (int)(((float)(inner * 256) + 0.5f) * (1.0f / (float)bx_count));
+        { const int c0 = inner * 256 - rg_first * bx_count; if (c0 < 0) rg_first--; else if (c0 >= bx_count) rg_first++; }
+        int rg_last = (int)(((float)(inner * 256 + 255) + 0.5f) * (1.0f / (float)bx_count));
+        { const int c1 = inner * 256 + 255 - rg_last * bx_count; if (c1 < 0) rg_last--; else if (c1 >= bx_count) rg_last++; }
+        const int row_first = rg_first * RS_ROWS, nrows = (rg_last - rg_first + 1) * RS_ROWS;
+        const bool shared_rows = nrows <= 256;                       // always, unless a level is narrower than 32 pixels
+        if (shared_rows && tid < nrows) {
+            const int dy = min(row_first + tid, dh - 1);
+            // vertical: row indices are clamped, the coefficients are not (resizeGeneric_Invoker)
+            float fy = (float)((dy + 0.5) * scale_y - 0.5);
+            const int sy = (int)floorf(fy);
+            fy -= (float)sy;
+            const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
+            yc[tid] = make_uint4((uint32_t)__umul24(sy0, sstride), (uint32_t)__umul24(sy1, sstride),
+                                 (uint32_t)__float2int_rn((1.f - fy) * 2048.f), (uint32_t)__float2int_rn(fy * 2048.f));
+        }
+        __syncthreads();
+        if (dy0 >= dh) return;
+        int sxs[4], a0s[4], a1s[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) resize_coef(min(dx4 + k, dw - 1), scale_x, sw, sxs[k], a0s[k], a1s[k]);
+        uint8_t* dbase = dst + (size_t)f * dframe + dx4;
+        // bytes of the 4-pixel store that lie inside the row (the rest is written as 0, as it always was)
+        const uint32_t keep = dx4 + 3 < dw ? 0xFFFFFFFFu : (0xFFFFFFFFu >> (8 * (dx4 + 4 - dw)));
         // window start clamped so that the 8-byte fetch stays inside the row; at the right edge the second
         // byte of a pair may fall outside the window: its coefficient is 0 there, so any byte will do
         const int wb = min(sxs[0], sstride - 8);
@@ -106,15 +129,20 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
         uint64_t W0[RS_ROWS], W1[RS_ROWS]; uint32_t B0[RS_ROWS], B1[RS_ROWS];
 #pragma unroll
         for (int r = 0; r < RS_ROWS; r++) {
-            const int dy = min(dy0 + r, dh - 1);
-            // vertical: row indices are clamped, the coefficients are not (resizeGeneric_Invoker)
-            float fy = (float)((dy + 0.5) * scale_y - 0.5);
-            const int sy = (int)floorf(fy);
-            fy -= (float)sy;
-            const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
-            B0[r] = (uint32_t)__float2int_rn((1.f - fy) * 2048.f); B1[r] = (uint32_t)__float2int_rn(fy * 2048.f);
-            W0[r] = *reinterpret_cast<const u64_unaligned*>(sbase + (uint32_t)__umul24(sy0, sstride));
-            W1[r] = *reinterpret_cast<const u64_unaligned*>(sbase + (uint32_t)__umul24(sy1, sstride));
+            uint4 y;
+            if (shared_rows) y = yc[dy0 - row_first + r];
+            else {
+                const int dy = min(dy0 + r, dh - 1);
+                float fy = (float)((dy + 0.5) * scale_y - 0.5);
+                const int sy = (int)floorf(fy);
+                fy -= (float)sy;
+                const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
+                y = make_uint4((uint32_t)__umul24(sy0, sstride), (uint32_t)__umul24(sy1, sstride),
+                               (uint32_t)__float2int_rn((1.f - fy) * 2048.f), (uint32_t)__float2int_rn(fy * 2048.f));
+            }
+            B0[r] = y.z; B1[r] = y.w;
+            W0[r] = *reinterpret_cast<const u64_unaligned*>(sbase + y.x);
+            W1[r] = *reinterpret_cast<const u64_unaligned*>(sbase + y.y);
         }
 #pragma unroll
         for (int r = 0; r < RS_ROWS; r++) {
@@ -133,6 +161,12 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
         }
         return;
     }
+    if (dy0 >= dh) return;
+    int sxs[4], a0s[4], a1s[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) resize_coef(min(dx4 + k, dw - 1), scale_x, sw, sxs[k], a0s[k], a1s[k]);
+    uint8_t* dbase = dst + (size_t)f * dframe + dx4;
+    const uint32_t keep = dx4 + 3 < dw ? 0xFFFFFFFFu : (0xFFFFFFFFu >> (8 * (dx4 + 4 - dw)));
     // the 4 outputs read source bytes sxs[0] .. sxs[3]+1 (span <= 12 for any down-scale factor < 3.6);
     // clamp the window start so the 12-byte fetch stays inside the row (rows are >= 12 bytes)
     const int wb = min(sxs[0], sstride - 12);
