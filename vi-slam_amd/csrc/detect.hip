@@ -742,7 +742,9 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
     sincos_det((double)ang, &sd, &cd);
     const float a = (float)cd, b = (float)sd;
     unsigned long long words[4];
-    const uint8_t* hbb = reinterpret_cast<const uint8_t*>(hb32);
+    // LDS byte address of blur-buffer element (column PR-3, row PR-3) of this wave, as a float (< 2^24: exact)
+    const float tap0_f = (float)((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(hb32)
+                                 + (uint32_t)((PR - 3) * (HTS * 2) + 2 * (PR - 3)));
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int bit = lane + 64 * k;
@@ -753,12 +755,15 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
             const float px = e ? pt.z : pt.x, py = e ? pt.w : pt.y;
             const float fx = px * a - py * b;
             const float fy = px * b + py * a;
-            const int ix = __float2int_rn(fx), iy = __float2int_rn(fy);
-            // vertical 7 taps = 4 consecutive dwords of column (PR+ix-3) starting at row (PR+iy-3)
-            const int row0 = PR + iy - 3;
-            const uint32_t* cw = reinterpret_cast<const uint32_t*>(hbb + __mul24(PR + ix - 3, HTS * 2) + ((row0 >> 1) << 2));
+            // cvRound of both coordinates stays in float (v_rndne), and the LDS byte address of the first vertical tap --
+            // column (PR+ix-3) of the transposed blur buffer, row (PR+iy-3): 92 ix + 2 iy + constant -- is formed there too:
+            // every term is a small integer, so the two fused multiply-adds are exact; one conversion instead of two plus
+            // the integer address arithmetic.  The 7 taps are 4 consecutive dwords from the address rounded down to 4.
+            const float rx = rintf(fx), ry = rintf(fy);
+            const uint32_t ab = (uint32_t)(int)__fmaf_rn(rx, (float)(HTS * 2), __fmaf_rn(ry, 2.f, tap0_f));
+            const uint32_t* cw = (const uint32_t*)(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(ab & ~3u);
+            const uint32_t sh = ab & 2u;
             const uint32_t w0 = cw[0], w1 = cw[1], w2 = cw[2], w3 = cw[3];
-            const uint32_t sh = (uint32_t)(row0 & 1) * 2u;
             typedef unsigned short us2 __attribute__((ext_vector_type(2)));
             const uint32_t t0 = __builtin_amdgcn_alignbyte(w1, w0, sh), t1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
             const uint32_t t2 = __builtin_amdgcn_alignbyte(w3, w2, sh), t3 = __builtin_amdgcn_alignbyte(0u, w3, sh);
