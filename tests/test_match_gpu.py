@@ -5,7 +5,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n1,n2", [(1000, 1000), (1, 1), (2, 1), (1, 7), (257, 63), (4000, 4000), (1000, 3)])
+@pytest.mark.parametrize("n1,n2", [(1000, 1000), (1, 1), (2, 1), (1, 7), (257, 63), (4000, 4000), (1000, 3), (128, 128), (129, 65), (513, 31), (255, 256)])
 def test_knn2_random_descriptors(vislam, orc, ctx, n1, n2):
     rng = np.random.default_rng(n1 * 31 + n2)
     d1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)
@@ -26,6 +26,21 @@ def test_knn2_ties_lowest_index_first(vislam, orc, ctx):
     o12, o21 = orc.knn2_hamming(d1, d2)
     assert g12.tobytes() == o12.tobytes() and g21.tobytes() == o21.tobytes()
     assert (g12["distance"][:, 0] == 0).all()
+
+
+def test_knn2_extreme_distances(vislam, orc, ctx):
+    """Hamming 0 and 256 (the ends of the MFMA key range: 8192 * H - 2^20 + index) next to ordinary rows"""
+    rng = np.random.default_rng(5)
+    d1 = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    d1[::7] = 0
+    d1[3::11] = 255
+    d2 = rng.integers(0, 256, (200, 32), dtype=np.uint8)
+    d2[::5] = 255
+    d2[2::9] = 0
+    g12, g21 = ctx.bf_knn2_hamming_host(d1, d2)
+    o12, o21 = orc.knn2_hamming(d1, d2)
+    assert g12.tobytes() == o12.tobytes() and g21.tobytes() == o21.tobytes()
+    assert g12["distance"].min() == 0 and float(np.unpackbits(d1[3] ^ d2[2]).sum()) == 256.0
 
 
 def test_knn2_empty(vislam, ctx):
