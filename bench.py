@@ -220,7 +220,7 @@ def cpu_baseline(p, frames, budget_s, what):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=200)   # 200 x 3.7 ms: a timed region long enough for an outside observer (rocm-smi) to see
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="frames per step (per GPU)")
     ap.add_argument("--ring", type=int, default=2, help="distinct batches resident in HBM")
