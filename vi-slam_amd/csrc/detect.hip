@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
             fy -= (float)sy;
             const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
             yc[tid] = make_uint4((uint32_t)__umul24(sy0, sstride), (uint32_t)__umul24(sy1, sstride),
-                                 (uint32_t)__float2int_rn((1.f - fy) * 2048.f), (uint32_t)__float2int_rn(fy * 2048.f));
+                                 (uint32_t)__float2int_rn((1.f - fy) * 2048.f) << 16, (uint32_t)__float2int_rn(fy * 2048.f) << 16);
         }
         __syncthreads();
         if (dy0 >= dh) return;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
                 fy -= (float)sy;
                 const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
                 y = make_uint4((uint32_t)__umul24(sy0, sstride), (uint32_t)__umul24(sy1, sstride),
-                               (uint32_t)__float2int_rn((1.f - fy) * 2048.f), (uint32_t)__float2int_rn(fy * 2048.f));
+                               (uint32_t)__float2int_rn((1.f - fy) * 2048.f) << 16, (uint32_t)__float2int_rn(fy * 2048.f) << 16);
             }
             B0[r] = y.z; B1[r] = y.w;
             W0[r] = *reinterpret_cast<const u64_unaligned*>(sbase + y.x);
@@ -146,17 +146,17 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
         }
 #pragma unroll
         for (int r = 0; r < RS_ROWS; r++) {
-            uint32_t out = 0;
+            uint32_t v[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t p0 = __builtin_amdgcn_perm((uint32_t)(W0[r] >> 32), (uint32_t)W0[r], sel[k]);
                 const uint32_t p1 = __builtin_amdgcn_perm((uint32_t)(W1[r] >> 32), (uint32_t)W1[r], sel[k]);
                 const uint32_t r0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, p0), __builtin_bit_cast(us2_t, coef[k]), 0u, false);
                 const uint32_t r1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, p1), __builtin_bit_cast(us2_t, coef[k]), 0u, false);
-                // B <= 2048 and r >> 4 <= 32640: 24-bit multiplies are exact
-                const uint32_t v = ((__umul24(B0[r], r0 >> 4) >> 16) + (__umul24(B1[r], r1 >> 4) >> 16) + 2u) >> 2;
-                out |= (v & 255u) << (8 * k);
+                // (B * (r >> 4)) >> 16 as ONE v_mul_hi_u32 with the weight pre-shifted by 16 (B <= 2048, r >> 4 <= 32640)
+                v[k] = (__umulhi(B0[r], r0 >> 4) + __umulhi(B1[r], r1 >> 4) + 2u) >> 2;         // <= 255
             }
+            const uint32_t out = ((v[3] << 8 | v[2]) << 16) | (v[1] << 8 | v[0]);
             if (dy0 + r < dh) *reinterpret_cast<uint32_t*>(dbase + (uint32_t)__umul24(dy0 + r, dstride)) = out & keep;
         }
         return;

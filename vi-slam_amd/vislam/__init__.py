@@ -26,7 +26,8 @@ except ImportError:  # pragma: no cover
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "..", "lib", "libvislam_hip.so")
+# VISLAM_HIP_LIB: another build of the same library (A/B measurements); there is no fallback either way
+LIB_PATH = os.environ.get("VISLAM_HIP_LIB") or os.path.join(_HERE, "..", "lib", "libvislam_hip.so")
 
 
 class VisError(RuntimeError):
