@@ -62,7 +62,9 @@ __device__ __forceinline__ void resize_coef(int d, double scale, int slen, int& 
     c1 = __float2int_rn(fx * 2048.f);
 }
 
+#ifndef RS_ROWS
 #define RS_ROWS 8            // destination rows per thread: the column coefficients are computed once per thread
+#endif
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 
