@@ -107,3 +107,24 @@ def test_batch_matches_single(vislam, orc, canvas):
     og, osym = orc.good_matches(p, res[2][0], res[3][0], o12, o21)
     assert nsym == len(osym) and g.tobytes() == og.tobytes()
     c.close()
+
+
+@pytest.mark.parametrize("n", [21, 150])
+def test_batch_frame_tails_and_keypoint_walk(vislam, orc, canvas, n):
+    """batches whose size is not a multiple of 8 (the (xcd, item, frame/8) grids have idle workgroups) and, at n = 150,
+    large enough that a describe wave walks over several keypoints (16384 / n workgroups per frame < kcap / 4): every frame
+    of the batch against the oracle"""
+    import torch
+    p = _params(vislam, n=300, levels=6, w=320, h=240)
+    c = vislam.Context(0, p)
+    frames = np.stack([vislam.synth_frame(canvas, t, 320, 240) for t in range(n)])
+    dev = torch.from_numpy(frames).cuda()
+    c.batch_plan(320, 240, 320, n)
+    c.batch_run(dev.data_ptr(), n, vislam.STAGE_DETECT)
+    c.batch_sync()
+    assert c.batch_status() == 0
+    for t in range(n):
+        k, d = c.batch_keypoints(t)
+        ok, od = orc.orb_detect_compute(p, frames[t])
+        _assert_same(k, d, ok, od)
+    c.close()
