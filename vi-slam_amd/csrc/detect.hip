@@ -517,6 +517,15 @@ __device__ __forceinline__ float harris7(const uint8_t* __restrict__ img, int st
     return (fa * fb - fc * fc - 0.04f * s * s) * scale_sq_sq;
 }
 
+#ifdef VIS_FAST_PROFILE
+__device__ unsigned long long g_sel_stamps[VIS_MAX_LEVELS * 8];      // diagnostic build: cycles per (level, phase) summed over workgroups
+extern "C" int vis_debug_select_stamps(unsigned long long out[VIS_MAX_LEVELS * 8]) {
+    if (hipDeviceSynchronize() != hipSuccess) return VIS_E_HIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sel_stamps), sizeof(g_sel_stamps)) != hipSuccess) return VIS_E_HIP;
+    unsigned long long z[VIS_MAX_LEVELS * 8] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_sel_stamps), z, sizeof(z)) == hipSuccess ? VIS_OK : VIS_E_HIP;
+}
+#endif
 #define SEL_NT 256
 __global__ __launch_bounds__(256) void k_select(DetLevels D, const int32_t* __restrict__ tile_cnt, int total_tiles,
                                                 int32_t* __restrict__ seg_cnt,
