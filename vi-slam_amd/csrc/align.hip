@@ -148,32 +148,55 @@ HD Se3 se3_mul(const Se3& a, const Se3& b) {
     return r;
 }
 
-// hal::LU32f as cv::invert(DECOMP_LU) uses it: A (6x6, LDS) is destroyed, B receives the inverse; false = singular
-__device__ bool lu_invert6(float* A, float* B) {
-    const int n = 6;
-    for (int i = 0; i < 36; i++) B[i] = (i % 7 == 0) ? 1.f : 0.f;
+// hal::LU32f as cv::invert(DECOMP_LU) uses it: A (6x6, row-major, LDS) -> B = inverse; false = singular.  The matrices are
+// held in registers for the factorisation (fully unrolled; a row exchange with the runtime pivot row is a chain of selects):
+// the same operations in the same order as the in-place version, without ~800 dependent LDS round trips of one thread.
+__device__ bool lu_invert6(const float* Ain, float* Bout) {
+    constexpr int n = 6;
+    float A[n][n], B[n][n];
+#pragma unroll
+    for (int i = 0; i < n; i++)
+#pragma unroll
+        for (int j = 0; j < n; j++) { A[i][j] = Ain[i * n + j]; B[i][j] = i == j ? 1.f : 0.f; }
+    bool ok = true;
+#pragma unroll
     for (int i = 0; i < n; i++) {
-        int k = i;
-        for (int j = i + 1; j < n; j++) if (fabsf(A[j * n + i]) > fabsf(A[k * n + i])) k = j;
-        if (fabsf(A[k * n + i]) < FLT_EPSILON * 10) return false;
-        if (k != i) {
-            for (int j = i; j < n; j++) { const float t = A[i * n + j]; A[i * n + j] = A[k * n + j]; A[k * n + j] = t; }
-            for (int j = 0; j < n; j++) { const float t = B[i * n + j]; B[i * n + j] = B[k * n + j]; B[k * n + j] = t; }
-        }
-        const float d = -1.f / A[i * n + i];
+        int k = i; float best = fabsf(A[i][i]);
+#pragma unroll
+        for (int j = i + 1; j < n; j++) { const float v = fabsf(A[j][i]); if (v > best) { best = v; k = j; } }
+        if (best < FLT_EPSILON * 10) ok = false;
+#pragma unroll
+        for (int j = i + 1; j < n; j++)
+            if (k == j) {
+#pragma unroll
+                for (int c = i; c < n; c++) { const float t = A[i][c]; A[i][c] = A[j][c]; A[j][c] = t; }
+#pragma unroll
+                for (int c = 0; c < n; c++) { const float t = B[i][c]; B[i][c] = B[j][c]; B[j][c] = t; }
+            }
+        const float d = -1.f / A[i][i];
+#pragma unroll
         for (int j = i + 1; j < n; j++) {
-            const float alpha = A[j * n + i] * d;
-            for (int c = i + 1; c < n; c++) A[j * n + c] += alpha * A[i * n + c];
-            for (int c = 0; c < n; c++) B[j * n + c] += alpha * B[i * n + c];
+            const float alpha = A[j][i] * d;
+#pragma unroll
+            for (int c = i + 1; c < n; c++) A[j][c] += alpha * A[i][c];
+#pragma unroll
+            for (int c = 0; c < n; c++) B[j][c] += alpha * B[i][c];
         }
     }
+#pragma unroll
     for (int i = n - 1; i >= 0; i--)
+#pragma unroll
         for (int j = 0; j < n; j++) {
-            float s = B[i * n + j];
-            for (int k = i + 1; k < n; k++) s -= A[i * n + k] * B[k * n + j];
-            B[i * n + j] = s / A[i * n + i];
+            float s_ = B[i][j];
+#pragma unroll
+            for (int k = i + 1; k < n; k++) s_ -= A[i][k] * B[k][j];
+            B[i][j] = s_ / A[i][i];
         }
-    return true;
+#pragma unroll
+    for (int i = 0; i < n; i++)
+#pragma unroll
+        for (int j = 0; j < n; j++) Bout[i * n + j] = B[i][j];
+    return ok;
 }
 
 // sum over the 64 lanes of a wave in the oracle's tree order (stride 32, 16, ... 1): lane 0 holds the result
@@ -235,11 +258,20 @@ __global__ __launch_bounds__(AL_THREADS) void k_align(AlignArgs G) {
                         if (i > 0 && i < cols && j > 0 && j < rows) cnt++;
             }
             __syncthreads();                                                         // previous level done with plist / s_pre
-            s_pre[tid + 1] = cnt;
-            if (tid == 0) s_pre[0] = 0;
-            __syncthreads();
-            if (tid == 0) for (int k = 1; k <= AL_THREADS; k++) s_pre[k] += s_pre[k - 1];
-            __syncthreads();
+            // exclusive prefix of the per-keypoint counts: wave scans by shuffles + the three wave totals (one thread walking
+            // the 256 entries was 256 dependent LDS round trips per level)
+            {
+                int v = cnt;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
+                if (lane == 63) s_cnt[wv] = v;
+                __syncthreads();
+                int base = 0;
+                for (int w = 0; w < wv; w++) base += s_cnt[w];
+                s_pre[tid + 1] = base + v;
+                if (tid == 0) s_pre[0] = 0;
+                __syncthreads();
+            }
             if (tid < m) {
                 int o = s_pre[tid];
                 for (int i = (int)(x - (float)sp); (float)i <= x + (float)sp; i++)
@@ -267,58 +299,77 @@ __global__ __launch_bounds__(AL_THREADS) void k_align(AlignArgs G) {
 #pragma unroll
             for (int s = 0; s < 27; s++) S[s] = 0.0;
             unsigned long long sumsq = 0; int cnt = 0;
+            // Four candidates per thread per round: first the warp of all four and their image / gradient loads (clamped
+            // addresses for the ones that will be skipped), then the accumulation in the original order i, i + T, i + 2T,
+            // i + 3T -- the per-thread sums see the same operations in the same order, but a round costs one memory round
+            // trip instead of four.
 #pragma unroll 1
-            for (int i = tid; i < N; i += AL_THREADS) {
-                float x1, y1, z1, w1;
-                if (GEN) { const uint32_t pw = plist[i]; x1 = (float)(pw & 0xFFFFu); y1 = (float)(pw >> 16); z1 = 1.f; w1 = 1.f; }
-                else { const float4 c = reinterpret_cast<const float4*>(V.cand)[i]; x1 = c.x; y1 = c.y; z1 = c.z; w1 = c.w; }
-                const float X = ((x1 - cx) * invfx) * z1, Y = ((y1 - cy) * invfy) * z1;
-                const float P0 = (float)(((m00 * (double)X + m01 * (double)Y) + m02 * (double)z1) + m03 * (double)w1);
-                const float P1 = (float)(((m10 * (double)X + m11 * (double)Y) + m12 * (double)z1) + m13 * (double)w1);
-                const float P2 = (float)(((m20 * (double)X + m21 * (double)Y) + m22 * (double)z1) + m23 * (double)w1);
-                const float P3 = (float)(((0.0 * (double)X + 0.0 * (double)Y) + 0.0 * (double)z1) + 1.0 * (double)w1);
-                float x2 = P0 * fx; x2 = x2 / P2; x2 = x2 + cx;
-                float y2 = P1 * fy; y2 = y2 / P2; y2 = y2 + cy;
-                x2 = x2 * P3; y2 = y2 * P3;
-                const float z2 = P2;
-                float inv_z2 = 1 / z2;
-                if (!(y2 > 0 && y2 < rows && x2 > 0 && x2 < cols)) continue;
-                if (!(z2 != 0)) continue;
-                if (inv_z2 < 0) inv_z2 = 0;
-                float Jw0[6], Jw1[6];
-                Jw0[0] = fx * inv_z2; Jw0[1] = 0.f;
-                Jw0[2] = -(fx * x2 * inv_z2 * inv_z2) * G.zf;
-                Jw0[3] = -(fx * x2 * y2 * inv_z2 * inv_z2);
-                Jw0[4] = (fx * (1 + x2 * x2 * inv_z2 * inv_z2));
-                Jw0[5] = -fx * y2 * inv_z2;
-                Jw1[0] = 0.f; Jw1[1] = fy * inv_z2;
-                Jw1[2] = -(fy * y2 * inv_z2 * inv_z2) * G.zf;
-                Jw1[3] = -(fy * (1 + y2 * y2 * inv_z2 * inv_z2));
-                Jw1[4] = fy * x2 * y2 * inv_z2 * inv_z2;
-                Jw1[5] = -fy * x2 * inv_z2;
-                const int ix1 = (int)x1, iy1 = (int)y1;
-                if (ix1 < 0 || ix1 >= cols || iy1 < 0 || iy1 >= rows) continue;
-                int rx = (int)roundf(x2), ry = (int)roundf(y2);
-                if (rx > cols - 1) rx = cols - 1;
-                if (ry > rows - 1) ry = rows - 1;
-                const int intensity1 = I1[(size_t)iy1 * V.rowstride + ix1];
-                const int intensity2 = I2[(size_t)ry * V.rowstride + rx];
-                const int ri = intensity2 - intensity1;
-                const float resf = (float)ri;
-                const size_t go = (size_t)iy1 * cols + ix1;                        // gradients are dense
-                const float jl0 = (float)GX[go], jl1 = (float)GY[go];
-                double J[6];
+            for (int i0 = tid; i0 < N; i0 += 4 * AL_THREADS) {
+                float x2a[4], y2a[4], iza[4]; bool ok[4]; int i1v[4], i2v[4]; float gxv[4], gyv[4];
 #pragma unroll
-                for (int c = 0; c < 6; c++) J[c] = (double)(float)((double)jl0 * (double)Jw0[c] + (double)jl1 * (double)Jw1[c]);
-                int s = 0;
+                for (int u = 0; u < 4; u++) {
+                    const int i = i0 + u * AL_THREADS;
+                    ok[u] = false; x2a[u] = y2a[u] = iza[u] = 0.f;
+                    size_t o1 = 0, o2 = 0, go = 0;
+                    if (i < N) {
+                        float x1, y1, z1, w1;
+                        if (GEN) { const uint32_t pw = plist[i]; x1 = (float)(pw & 0xFFFFu); y1 = (float)(pw >> 16); z1 = 1.f; w1 = 1.f; }
+                        else { const float4 c = reinterpret_cast<const float4*>(V.cand)[i]; x1 = c.x; y1 = c.y; z1 = c.z; w1 = c.w; }
+                        const float X = ((x1 - cx) * invfx) * z1, Y = ((y1 - cy) * invfy) * z1;
+                        const float P0 = (float)(((m00 * (double)X + m01 * (double)Y) + m02 * (double)z1) + m03 * (double)w1);
+                        const float P1 = (float)(((m10 * (double)X + m11 * (double)Y) + m12 * (double)z1) + m13 * (double)w1);
+                        const float P2 = (float)(((m20 * (double)X + m21 * (double)Y) + m22 * (double)z1) + m23 * (double)w1);
+                        const float P3 = (float)(((0.0 * (double)X + 0.0 * (double)Y) + 0.0 * (double)z1) + 1.0 * (double)w1);
+                        float x2 = P0 * fx; x2 = x2 / P2; x2 = x2 + cx;
+                        float y2 = P1 * fy; y2 = y2 / P2; y2 = y2 + cy;
+                        x2 = x2 * P3; y2 = y2 * P3;
+                        const float z2 = P2;
+                        float inv_z2 = 1 / z2;
+                        const int ix1 = (int)x1, iy1 = (int)y1;
+                        bool v = (y2 > 0 && y2 < rows && x2 > 0 && x2 < cols) && (z2 != 0);
+                        if (inv_z2 < 0) inv_z2 = 0;
+                        v = v && !(ix1 < 0 || ix1 >= cols || iy1 < 0 || iy1 >= rows);
+                        if (v) {
+                            int rx = (int)roundf(x2), ry = (int)roundf(y2);
+                            if (rx > cols - 1) rx = cols - 1;
+                            if (ry > rows - 1) ry = rows - 1;
+                            o1 = (size_t)iy1 * V.rowstride + ix1; o2 = (size_t)ry * V.rowstride + rx; go = (size_t)iy1 * cols + ix1;   // gradients are dense
+                        }
+                        ok[u] = v; x2a[u] = x2; y2a[u] = y2; iza[u] = inv_z2;
+                    }
+                    i1v[u] = I1[o1]; i2v[u] = I2[o2]; gxv[u] = (float)GX[go]; gyv[u] = (float)GY[go];
+                }
 #pragma unroll
-                for (int a = 0; a < 6; a++)
+                for (int u = 0; u < 4; u++) {
+                    if (!ok[u]) continue;
+                    const float x2 = x2a[u], y2 = y2a[u], inv_z2 = iza[u];
+                    float Jw0[6], Jw1[6];
+                    Jw0[0] = fx * inv_z2; Jw0[1] = 0.f;
+                    Jw0[2] = -(fx * x2 * inv_z2 * inv_z2) * G.zf;
+                    Jw0[3] = -(fx * x2 * y2 * inv_z2 * inv_z2);
+                    Jw0[4] = (fx * (1 + x2 * x2 * inv_z2 * inv_z2));
+                    Jw0[5] = -fx * y2 * inv_z2;
+                    Jw1[0] = 0.f; Jw1[1] = fy * inv_z2;
+                    Jw1[2] = -(fy * y2 * inv_z2 * inv_z2) * G.zf;
+                    Jw1[3] = -(fy * (1 + y2 * y2 * inv_z2 * inv_z2));
+                    Jw1[4] = fy * x2 * y2 * inv_z2 * inv_z2;
+                    Jw1[5] = -fy * x2 * inv_z2;
+                    const int ri = i2v[u] - i1v[u];
+                    const float resf = (float)ri;
+                    const float jl0 = gxv[u], jl1 = gyv[u];
+                    double J[6];
 #pragma unroll
-                    for (int b = a; b < 6; b++) S[s++] += J[a] * J[b];
+                    for (int c = 0; c < 6; c++) J[c] = (double)(float)((double)jl0 * (double)Jw0[c] + (double)jl1 * (double)Jw1[c]);
+                    int s = 0;
 #pragma unroll
-                for (int a = 0; a < 6; a++) S[21 + a] += J[a] * (double)resf;
-                sumsq += (unsigned long long)(ri * ri);
-                cnt++;
+                    for (int a = 0; a < 6; a++)
+#pragma unroll
+                        for (int b = a; b < 6; b++) S[s++] += J[a] * J[b];
+#pragma unroll
+                    for (int a = 0; a < 6; a++) S[21 + a] += J[a] * (double)resf;
+                    sumsq += (unsigned long long)(ri * ri);
+                    cnt++;
+                }
             }
             // reduction in the oracle's order: inside a wave strides 32..1, then (W0 + W1) + (W2 + W3)
 #pragma unroll
