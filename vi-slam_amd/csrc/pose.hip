@@ -586,8 +586,10 @@ DEV void roots_level_rt(const double* cl, int deg, int d, double B, int j, int g
 }
 
 // real roots of every hypothesis polynomial: 16 lanes per hypothesis, 16 hypotheses (one sub-item) per block
+// only_reduced != 0: handle only the (rare) polynomials whose degree-10 coefficient vanished; k_hyp_roots_lane did the others
 __global__ __launch_bounds__(256) void k_hyp_roots(PoseParams P, int h0, int h_end, int npairs, const int32_t* __restrict__ rstate,
-                                                   double* __restrict__ hyp, size_t S, const int32_t* __restrict__ worklist, int chunks) {
+                                                   double* __restrict__ hyp, size_t S, const int32_t* __restrict__ worklist, int chunks,
+                                                   int only_reduced) {
     __shared__ double sh_prev[16][10];
     __shared__ double sh_c[16][11];
     const int g = threadIdx.x >> 4, j = threadIdx.x & 15, gshift = (threadIdx.x & 63) & ~15;
@@ -605,7 +607,7 @@ __global__ __launch_bounds__(256) void k_hyp_roots(PoseParams P, int h0, int h_e
         for (int i = 0; i <= 10; i++) c[i] = flag ? hyp[slot + (size_t)i * S] : (i == 10 ? 1.0 : 0.0);
         double* prev = sh_prev[g];
         int np = 0;
-        if (__any(flag == 1)) {
+        if (!only_reduced && __any(flag == 1)) {
             double B = 0;
 #pragma unroll
             for (int i = 0; i < 10; i++) B = fmax(B, fabs(c[i] / c[10]));
@@ -617,7 +619,8 @@ __global__ __launch_bounds__(256) void k_hyp_roots(PoseParams P, int h0, int h_e
             roots_level<7>(c, B, j, gshift, prev, np); roots_level<8>(c, B, j, gshift, prev, np);
             roots_level<9>(c, B, j, gshift, prev, np); roots_level<10>(c, B, j, gshift, prev, np);
         }
-        if (flag == 1) {
+        if (only_reduced) { if (!__any(flag == 2)) { if (!worklist) return; continue; } }
+        else if (flag == 1) {
             if (j < np) hyp[slot + (size_t)(HR_ROOTS + j) * S] = prev[j];
             if (j == 0) nrs[slot] = np;
         } else if (active && flag == 0 && j == 0) nrs[slot] = 0;
@@ -651,6 +654,92 @@ __global__ __launch_bounds__(256) void k_hyp_roots(PoseParams P, int h0, int h_e
         }
         HYP_SYNC();
         if (!worklist) return;
+    }
+}
+
+// ---- the same root finder with ONE HYPOTHESIS PER LANE, for the work-list chunks (hundreds of hypotheses per pair: throughput
+// matters, not latency).  With 16 lanes per polynomial every level costs its 40 bisection steps whatever the number of
+// sign-change intervals, and most of the 16 lanes idle; here a wave walks the intervals j = 0, 1, .. of a level for 64
+// polynomials at once and skips an interval no lane needs.  Same arithmetic per interval (oracle/pose.cpp real_roots).  The
+// previous level's roots live in LDS ([root][lane]); interval j reads root j before anything of this level can overwrite it
+// (at most j roots have been stored by then), so one buffer serves both levels.
+template <int D>
+DEV void roots_level_lane(const double (&c)[11], double B, double (*prev)[64], int lane, int& nprev) {
+    constexpr int K = 10 - D;
+    double q[D + 1];
+#pragma unroll
+    for (int i = 0; i <= D; i++) {
+        double f = 1.0;
+#pragma unroll
+        for (int jj = 0; jj < K; jj++) f *= (double)(i + K - jj);
+        q[i] = c[i + K] * f;
+    }
+    constexpr int NIT = (D == 10) ? BISECT_FINAL : BISECT_INNER;
+    int ncur = 0;
+    double lo_next = -B;
+#pragma unroll
+    for (int j = 0; j < D; j++) {                                  // the degree D-1 level left at most D-1 roots: D intervals
+        const bool mine = j <= nprev;
+        double lo = lo_next;
+        const double pj = (D > 1 && j < D - 1) ? prev[j][lane] : B;   // root j of the previous level (unused when j >= nprev)
+        double hi = (j >= nprev) ? B : pj;
+        lo_next = pj;
+        double flo = q[D], fhi = q[D];
+#pragma unroll
+        for (int i = D - 1; i >= 0; i--) { flo = flo * lo + q[i]; fhi = fhi * hi + q[i]; }
+        const bool neg = flo < 0;
+        const bool act = mine && ((flo < 0) != (fhi < 0));
+        if (__any(act)) {
+            for (int it = 0; it < NIT; it++) {
+                const double m = 0.5 * (lo + hi);
+                double fm = q[D];
+#pragma unroll
+                for (int i = D - 1; i >= 0; i--) fm = fm * m + q[i];
+                const bool go = act && (m > lo) && (m < hi);       // "break" of the reference loop == no-op from here on
+                const bool left = (fm < 0) == neg;
+                if (go && left) lo = m;
+                if (go && !left) hi = m;
+                if (!__any(go)) break;
+            }
+        }
+        if (act) { prev[ncur][lane] = 0.5 * (lo + hi); ncur++; }
+    }
+    nprev = ncur;
+}
+
+__global__ __launch_bounds__(256) void k_hyp_roots_lane(PoseParams P, int h0, int h_end, const int32_t* __restrict__ rstate,
+                                                        double* __restrict__ hyp, size_t S, const int32_t* __restrict__ worklist, int chunks) {
+    __shared__ double sh_prev[4][10][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double (*prev)[64] = sh_prev[wv];
+    const int total = worklist[0] * chunks;                        // items of 64 consecutive hypotheses of one pair
+    int32_t* flags = reinterpret_cast<int32_t*>(hyp + (size_t)HR_DOUBLES * S);
+    int32_t* nrs = flags + S;
+    for (int item = blockIdx.x * 4 + wv; item < total; item += gridDim.x * 4) {
+        const int pair = worklist[1 + item / chunks];
+        const int h = h0 + (item % chunks) * 64 + lane;
+        const bool active = h < rstate[(size_t)pair * RS] && h < h_end && h < max(P.max_iters, 1);
+        const size_t slot = (size_t)pair * P.max_iters + (active ? h : 0);       // inactive lanes never dereference it; kept in range anyway
+        const int flag = active ? flags[slot] : 0;
+        double c[11];
+#pragma unroll
+        for (int i = 0; i <= 10; i++) c[i] = flag == 1 ? hyp[slot + (size_t)i * S] : (i == 10 ? 1.0 : 0.0);
+        int np = 0;
+        if (__any(flag == 1)) {
+            double B = 0;
+#pragma unroll
+            for (int i = 0; i < 10; i++) B = fmax(B, fabs(c[i] / c[10]));
+            B += 1.0;
+            roots_level_lane<1>(c, B, prev, lane, np); roots_level_lane<2>(c, B, prev, lane, np);
+            roots_level_lane<3>(c, B, prev, lane, np); roots_level_lane<4>(c, B, prev, lane, np);
+            roots_level_lane<5>(c, B, prev, lane, np); roots_level_lane<6>(c, B, prev, lane, np);
+            roots_level_lane<7>(c, B, prev, lane, np); roots_level_lane<8>(c, B, prev, lane, np);
+            roots_level_lane<9>(c, B, prev, lane, np); roots_level_lane<10>(c, B, prev, lane, np);
+        }
+        if (flag == 1) {
+            for (int j = 0; j < np; j++) hyp[slot + (size_t)(HR_ROOTS + j) * S] = prev[j][lane];
+            nrs[slot] = np;
+        } else if (active && flag == 0) nrs[slot] = 0;
     }
 }
 
@@ -1047,7 +1136,7 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
         HIPCHK(ctx, hipMemsetAsync(d_worklist, 0, sizeof(int32_t), st));
         hipLaunchKernelGGL(k_ransac_hyp, dim3(1, (npairs + ppb - 1) / ppb), dim3(64), HYP_LDS_BYTES, st, P, 0, hc, first, npairs, d_n1, d_n2,
                            d_samples, d_rstate, d_hyp, S);
-        hipLaunchKernelGGL(k_hyp_roots, dim3(npairs), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_hyp, S, (const int32_t*)nullptr, 0);
+        hipLaunchKernelGGL(k_hyp_roots, dim3(npairs), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_hyp, S, (const int32_t*)nullptr, 0, 0);
         hipLaunchKernelGGL(k_hyp_score, dim3(npairs), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_n1, d_n2, d_hyp, S, d_models,
                            d_counts, (const int32_t*)nullptr, 0);
         hipLaunchKernelGGL(k_ransac_scan, dim3(npairs), dim3(64), 0, st, P, first, d_counts, d_rstate, d_worklist);
@@ -1057,8 +1146,17 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
             const int nsub = (int)std::min<long long>(2048, (long long)npairs * chunks * 4);
             hipLaunchKernelGGL(k_ransac_hyp_list, dim3(nb), dim3(64), HYP_LDS_BYTES, st, P, first, max_iters,
                                npairs, d_n1, d_n2, d_samples, d_rstate, d_hyp, S, (const int32_t*)d_worklist, chunks);
-            hipLaunchKernelGGL(k_hyp_roots, dim3(nsub), dim3(256), 0, st, P, first, max_iters, npairs, d_rstate, d_hyp, S,
-                               (const int32_t*)d_worklist, chunks);
+            static const bool roots16 = getenv("VIS_ROOTS_16LANE") != nullptr;      // A/B knob: the 16-lanes-per-polynomial kernel for every chunk
+            if (roots16)
+                hipLaunchKernelGGL(k_hyp_roots, dim3(nsub), dim3(256), 0, st, P, first, max_iters, npairs, d_rstate, d_hyp, S,
+                                   (const int32_t*)d_worklist, chunks, 0);
+            else {
+                // one hypothesis per lane; the rare polynomials of reduced degree go through the 16-lane kernel afterwards
+                hipLaunchKernelGGL(k_hyp_roots_lane, dim3(std::min(2048, (npairs * chunks + 3) / 4)), dim3(256), 0, st, P, first, max_iters, d_rstate,
+                                   d_hyp, S, (const int32_t*)d_worklist, chunks);
+                hipLaunchKernelGGL(k_hyp_roots, dim3(nsub), dim3(256), 0, st, P, first, max_iters, npairs, d_rstate, d_hyp, S,
+                                   (const int32_t*)d_worklist, chunks, 1);
+            }
             hipLaunchKernelGGL(k_hyp_score, dim3(nsub), dim3(256), 0, st, P, first, max_iters, npairs, d_rstate, d_n1, d_n2, d_hyp, S,
                                d_models, d_counts, (const int32_t*)d_worklist, chunks);
             hipLaunchKernelGGL(k_ransac_scan, dim3(npairs), dim3(64), 0, st, P, max_iters, d_counts, d_rstate, (int32_t*)nullptr);
