@@ -602,6 +602,7 @@ __global__ __launch_bounds__(256) void k_hyp_roots(PoseParams P, int h0, int h_e
         int32_t* flags = reinterpret_cast<int32_t*>(hyp + (size_t)HR_DOUBLES * S);
         int32_t* nrs = flags + S;
         const int flag = active ? flags[slot] : 0;
+        if (only_reduced && !__any(flag == 2)) { if (!worklist) return; continue; }     // nothing of reduced degree in this wave: no loads
         double c[11];
 #pragma unroll
         for (int i = 0; i <= 10; i++) c[i] = flag ? hyp[slot + (size_t)i * S] : (i == 10 ? 1.0 : 0.0);
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(256) void k_hyp_roots(PoseParams P, int h0, int h_e
             roots_level<7>(c, B, j, gshift, prev, np); roots_level<8>(c, B, j, gshift, prev, np);
             roots_level<9>(c, B, j, gshift, prev, np); roots_level<10>(c, B, j, gshift, prev, np);
         }
-        if (only_reduced) { if (!__any(flag == 2)) { if (!worklist) return; continue; } }
+        if (only_reduced) { }
         else if (flag == 1) {
             if (j < np) hyp[slot + (size_t)(HR_ROOTS + j) * S] = prev[j];
             if (j == 0) nrs[slot] = np;
