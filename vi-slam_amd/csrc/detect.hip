@@ -361,73 +361,106 @@ __global__ __launch_bounds__(256) void k_fast(const FastTile* __restrict__ tiles
     const int loy = max(3, edge - 1), hiy = min(h - 3, h - edge + 1);
     {
         // score columns 1..128 (the tile's own columns): unit = 4 adjacent positions whose centre pixels are one aligned LDS
-        // dword; 5 dword reads + 4 v_perm give centre and the 4 tested ring pixels for all four; 34 rows x 32 units, 8 rows per
-        // iteration.  Range checks are folded in: the x range is a per-lane cap on the test value (loop invariant), the row
-        // range is wave-uniform scalar code that touches the cap only in the (rare) partially valid row pair.
-        const int q = tid & (FT_W / 4 - 1);                              // the unit column of a thread is fixed (256 % 32 == 0)
+        // dword; 34 rows x 32 units, 8 rows per iteration, the unit column of a thread is fixed (256 % 32 == 0).
+        //
+        // Byte-SWAR pretest on plain 32-bit integer instructions (4 pixels per instruction, the full-rate class: add / sub /
+        // and / or / shift) instead of 2 pixels per half-rate v_pk_*_i16.  Pixels are reduced to 7 bits (p >> 1), so bit 7 of
+        // every byte is free to hold the sign of a per-byte difference.  With K = ceil(t / 2):
+        //     ring pixel darker than c - t    =>  c7 - r7 >= K        ring pixel brighter than c + t  =>  r7 - c7 >= K
+        // (necessary conditions: the test may pass more pixels than the exact one, never fewer; cornerScore decides.)
+        //     cD = c7 + (128 - (K-1))   per byte, no carry        D = cD - r7:  bit 7 set <=> c7 - r7 >= K-1   ("dark")
+        //     B  = D + (2K-3):  bit 7 CLEAR <=> r7 - c7 >= K-1 + (0 or 1)                                         ("bright")
+        // A byte whose subtraction wraps (|difference| > 118) borrows 1 from / carries 1 into its left neighbour: the tests
+        // use K-1 resp. 2K-3 instead of K and 2K-2, which absorbs exactly that unit, and the wrapped byte itself reads
+        // "pass".  tests/test_fast_pretest_model.py replays these formulas in numpy exhaustively over (c, r, t).
+        // The axis test itself is unchanged: both opposite pairs (N,S) and (E,W) must show a dark pixel, or both a bright one.
+        const int q = tid & (FT_W / 4 - 1);
         const int gx0 = ox + 4 * q;                                      // image x of position sx = 4q+1
-        const bool x0 = gx0 >= lox && gx0 < hix, x1 = gx0 + 1 >= lox && gx0 + 1 < hix;
-        const bool x2 = gx0 + 2 >= lox && gx0 + 2 < hix, x3 = gx0 + 3 >= lox && gx0 + 3 < hix;
-        const uint32_t CAP_OK = 0x7FFFu, CAP_NO = 0x8000u;              // min(value, cap): 0x7fff keeps the value, -32768 fails every threshold
-        const uint32_t cap_ev = (x0 ? CAP_OK : CAP_NO) | ((x2 ? CAP_OK : CAP_NO) << 16);
-        const uint32_t cap_od = (x1 ? CAP_OK : CAP_NO) | ((x3 ? CAP_OK : CAP_NO) << 16);
+        uint32_t capmask = 0;                                            // bit 7 of byte j: position j of the unit is inside the x range
+#pragma unroll
+        for (int j = 0; j < 4; j++) capmask |= (gx0 + j >= lox && gx0 + j < hix) ? (0x80u << (8 * j)) : 0u;
         const int sy_lo = max(0, loy - (oy - 1)), sy_hi = min(SC_H, hiy - (oy - 1));     // valid score rows of this tile
         const int lane = tid & 63;
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const short Tt = (short)threshold;
+        const uint32_t HB = 0x80808080u, M7 = 0x7f7f7f7fu;
+        const int K = (threshold + 1) >> 1;
+        const bool swar = K >= 3 && K <= 128;                            // t < 5: every position goes to cornerScore
+        const uint32_t kD = HB - (uint32_t)(K - 1) * 0x01010101u;
+        const uint32_t kB = (uint32_t)(2 * K - 3) * 0x01010101u;
+        const uint32_t passall = swar ? 0u : 0xFFFFFFFFu;
         constexpr int NIT = (SC_H + 7) / 8;
-        bool ps[NIT][4];
-        int cnt[NIT][4];
-        int tot = 0;
+        uint32_t pm[NIT];                                                // pass bits of the thread's unit in iteration it (bits 7, 15, 23, 31)
+        int n = 0;                                                       // candidates of this thread
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) { ps[it][j] = false; cnt[it][j] = 0; }
+            pm[it] = 0;
             const int wr = it * 8 + 2 * wv;                              // the wave's row pair: wr (lanes 0..31), wr + 1 (lanes 32..63)
             if (wr < sy_hi && wr + 1 >= sy_lo) {
                 const int sy = it * 8 + (tid >> 5);
-                uint32_t ce = cap_ev, co = cap_od;
-                if (wr < sy_lo || wr + 1 >= sy_hi) { const bool v = sy >= sy_lo && sy < sy_hi; ce = v ? ce : (CAP_NO | (CAP_NO << 16)); co = v ? co : (CAP_NO | (CAP_NO << 16)); }
+                uint32_t cm = capmask;
+                if (wr < sy_lo || wr + 1 >= sy_hi) cm = (sy >= sy_lo && sy < sy_hi) ? cm : 0u;
                 const uint32_t* r0 = px + (sy + 3) * (PX_W / 4) + q + (PX_XO / 4 - 1);   // r0[1] = the 4 centre pixels
-                const uint32_t c0 = r0[0], C = r0[1], c2 = r0[2];
-                const uint32_t N = r0[3 * (PX_W / 4) + 1], S = r0[-3 * (PX_W / 4) + 1];
-                const uint32_t M = 0x00FF00FFu;
-                // even lanes = positions 0, 2; odd lanes = positions 1, 3.  east = +3 px: bytes 3..6 of c2:C; west = -3 px: bytes 1..4 of C:c0
-                const pk16 pev = pmin(pretest_axis(as_pk(C & M), as_pk(N & M), as_pk(S & M), PICKB(c2, C, 3, 5), PICKB(C, c0, 1, 3)), as_pk(ce));
-                const pk16 pod = pmin(pretest_axis(as_pk((C >> 8) & M), as_pk((N >> 8) & M), as_pk((S >> 8) & M), PICKB(c2, C, 4, 6), PICKB(C, c0, 2, 4)), as_pk(co));
-                ps[it][0] = pev.x > Tt; ps[it][1] = pod.x > Tt; ps[it][2] = pev.y > Tt; ps[it][3] = pod.y > Tt;
-#pragma unroll
-                for (int j = 0; j < 4; j++) { cnt[it][j] = __popcll(__builtin_amdgcn_ballot_w64(ps[it][j])); tot += cnt[it][j]; }
+                const uint32_t c0 = r0[0], Cc = r0[1], c2 = r0[2];
+                const uint32_t Nn = r0[3 * (PX_W / 4) + 1], Ss = r0[-3 * (PX_W / 4) + 1];
+                const uint32_t Ee = __builtin_amdgcn_alignbyte(c2, Cc, 3);               // +3 px: bytes 3..6 of c2:C
+                const uint32_t Ww = __builtin_amdgcn_alignbyte(Cc, c0, 1);               // -3 px: bytes 1..4 of C:c0
+                const uint32_t cD = ((Cc >> 1) & M7) + kD;
+                const uint32_t dn = cD - ((Nn >> 1) & M7), ds = cD - ((Ss >> 1) & M7);
+                const uint32_t de = cD - ((Ee >> 1) & M7), dw = cD - ((Ww >> 1) & M7);
+                const uint32_t dark = (dn | ds) & (de | dw);
+                const uint32_t nbright = ((dn + kB) & (ds + kB)) | ((de + kB) & (dw + kB));   // bit 7 set: a pair without a bright pixel
+                const uint32_t pass = (dark | ~nbright | passall) & cm;
+                pm[it] = pass;
+                n += __popc(pass);
             }
         }
-        // ONE reservation per wave for all its rows, then the wave-aggregated append (queue order is irrelevant: k_select
-        // sorts).  Lanes that did not pass store into a scratch word behind the queue: no exec-mask juggling per store.
+        // halo score columns 0 and 129 (NMS neighbours of the first/last tile column): byte-wise test by the first 2*SC_H threads
+        bool hp = false;
+        int hpos = 0;
+        if (tid < 2 * SC_H) {
+            const int sy = tid >> 1, sx = (tid & 1) ? SC_W - 1 : 0;
+            const int gx = ox - 1 + sx, gy = oy - 1 + sy;
+            hp = gy >= loy && gy < hiy && gx >= lox && gx < hix && fast_pretest(pxb + (sy + 3) * PX_W + (sx + PX_XO - 1), threshold);
+            hpos = sy * SC_W + sx;
+            n += hp ? 1 : 0;
+        }
+        // Queue append without ballots: wave-wide exclusive prefix sum of the per-thread counts (DPP row shifts + row
+        // broadcasts), ONE LDS reservation per wave, then every thread writes its candidates to consecutive entries.  A
+        // thread whose bit is clear stores into its own scratch entry behind the queue (no exec-mask juggling); the entry
+        // index advances by the bit.  Queue order is irrelevant: k_select sorts.
+        int incl = n;
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);      // row_shr:1
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);      // row_shr:2
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);      // row_shr:4
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);      // row_shr:8
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, true);      // row_bcast:15 -> rows 1, 3
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, true);      // row_bcast:31 -> rows 2, 3
+        const int tot = __builtin_amdgcn_readlane(incl, 63);
         if (tot) {
-            int qb = 0;
-            if (lane == 0) qb = atomicAdd(&qn, tot);
-            qb = __builtin_amdgcn_readfirstlane(qb);
-            const int pos = (tid >> 5) * SC_W + 4 * q + 1;
-            const uint32_t scratch = SC_H * SC_W + lane;
+            typedef __attribute__((address_space(3))) uint16_t lds_u16;
+            const uint32_t q_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)queue;      // LDS byte addresses
+            const uint32_t qn_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&qn;
+            uint32_t qb = 0;
+            if (lane == 0)        // one returning LDS add per wave (inline: the compiler's atomic optimizer would wrap it in a second wave reduction)
+                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(qb) : "v"(qn_addr), "v"(tot) : "memory");
+            qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
+            uint32_t a_idx = q_base + 2u * (uint32_t)(qb + incl - n);           // byte address of the thread's next entry
+            const uint32_t a_scr = q_base + 2u * (uint32_t)(SC_H * SC_W + lane);
+            const int pos0 = (tid >> 5) * SC_W + 4 * q + 1;
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    if (cnt[it][j]) {                                    // wave-uniform
-                        const unsigned long long m = __builtin_amdgcn_ballot_w64(ps[it][j]);
-                        // v_mbcnt: number of set mask bits below this lane, accumulated onto the running base
-                        const uint32_t i = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)qb));
-                        queue[ps[it][j] ? i : scratch] = (uint16_t)(pos + it * 8 * SC_W + j);
-                        qb += cnt[it][j];
-                    }
+                    // 4 instructions per entry.  mk = the sign-extended 2-bit field (pass bit, 0) = -2 / 0: as a v_bfi_b32 mask it
+                    // takes everything but bit 0 from the queue address (both addresses are even), and it is the address step.
+                    const int mk = __builtin_amdgcn_sbfe((int)pm[it], 8 * j + 6, 2);
+                    uint32_t a;
+                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(a) : "v"(mk), "v"(a_idx), "v"(a_scr));
+                    *(lds_u16*)(uintptr_t)a = (uint16_t)(pos0 + it * 8 * SC_W + j);
+                    a_idx -= (uint32_t)mk;
                 }
             }
-        }
-        // halo score columns 0 and 65 (NMS neighbours of the first/last tile column): byte-wise test
-        if (tid < 2 * SC_H) {
-            const int sy = tid >> 1, sx = (tid & 1) ? SC_W - 1 : 0;
-            const int gx = ox - 1 + sx, gy = oy - 1 + sy;
-            if (gy >= loy && gy < hiy && gx >= lox && gx < hix && fast_pretest(pxb + (sy + 3) * PX_W + (sx + PX_XO - 1), threshold))
-                queue[atomicAdd(&qn, 1)] = (uint16_t)(sy * SC_W + sx);
+            if (wv < 2) *(lds_u16*)(uintptr_t)(hp ? a_idx : a_scr) = (uint16_t)hpos;    // waves 0 and 1 hold the halo threads
         }
     }
     __syncthreads();
