@@ -234,11 +234,15 @@ __device__ __forceinline__ int fast_score16_full(const uint8_t* c, int t) {
     const int off[16] = {3 * S, 3 * S + 1, 2 * S + 2, S + 3, 3, -S + 3, -2 * S + 2, -3 * S + 1,
                          -3 * S, -3 * S - 1, -2 * S - 2, -S - 3, -3, S - 3, 2 * S - 2, 3 * S - 1};
     pk16 X[16], m2[16], m4[16];
+    // X[k] = (v - p_k, p_k - v) in ONE instruction per ring pixel: v_pk_mad_i16 (p_k, p_k) * (-1, +1) + (v, -v); the ring byte is
+    // used as loaded (both halves of the product read its low half: op_sel), no (v, p_k) register has to be assembled first
+    const uint32_t vpair = v - (v << 16);                                              // (v, -v)
+    const uint32_t sgn = 0x0001FFFFu;                                                  // (-1, +1)
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const uint32_t w = v | ((uint32_t)c[off[k]] << 16);                             // (v, p_k)
-        uint32_t x;                                                                      // (v - p_k, p_k - v): the half swap is an operand modifier
-        asm("v_pk_sub_i16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(x) : "v"(w));
+        const uint32_t pk = c[off[k]];
+        uint32_t x;
+        asm("v_pk_mad_i16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(x) : "v"(pk), "s"(sgn), "v"(vpair));
         X[k] = __builtin_bit_cast(pk16, x);
     }
 #pragma unroll
