@@ -39,7 +39,8 @@ from vislam import dist as vdist  # noqa: E402
 
 W, H, NFEAT, LEVELS = 752, 480, 1000, 8
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy)
-FAM = ("ms_pyramid", "ms_fast", "ms_select", "ms_describe", "ms_knn", "ms_filter", "ms_pose", "ms_total")
+FAM = ("ms_update", "ms_pyramid", "ms_fast", "ms_select", "ms_describe", "ms_knn", "ms_filter", "ms_pose", "ms_total")
+SIMD_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2       # wave-instr/s: 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md)
 
 
 def algorithmic_bytes(px, n):
@@ -140,7 +141,9 @@ def kernel_rooflines(fam, launches_fast, px, nfeat, B, nlevels):
     return out, alg
 
 
-def run_leg(dev, w, h, B, R, params, seed, canvas_dim, steps, warmup, stages=vislam.STAGE_ALL, parallax=False, want_pose=True, d2h=False):
+def run_leg(dev, w, h, B, R, params, seed, canvas_dim, steps, warmup, stages=None, parallax=False, want_pose=True, d2h=False):
+    if stages is None:                                   # Camera::Update needs w, h multiples of 16 (752x480 and 3840x2160 are, 1920x1080 is not)
+        stages = vislam.STAGE_FRAME if (w % 16 == 0 and h % 16 == 0) else vislam.STAGE_ALL
     ctx = vislam.Context(dev.index or 0, params)
     try:
         st = Stream(ctx, dev, w, h, B * R, seed, canvas_dim, parallax)
@@ -151,7 +154,7 @@ def run_leg(dev, w, h, B, R, params, seed, canvas_dim, steps, warmup, stages=vis
             hp = torch.empty(B * C.sizeof(vislam.PoseResult), dtype=torch.uint8).pin_memory()
             hg = torch.empty(B * root2 * 16, dtype=torch.uint8).pin_memory()
             hn = torch.empty(B, dtype=torch.int32).pin_memory()
-            after = lambda i: ctx.batch_results_async(hp.data_ptr(), hg.data_ptr(), hn.data_ptr())   # noqa: E731
+            after = lambda i: ctx.batch_results_async(B, hp.data_ptr(), hg.data_ptr(), hn.data_ptr())   # noqa: E731
         dt, step = timed_steps(ctx, st, B, R, stages, steps, warmup, after_step=after)
         fam, lf = family_times(ctx, step, 4)
         ws, hs, sc, q = ctx.level_geometry(w, h)
@@ -226,7 +229,7 @@ def main():
     ap.add_argument("--ring", type=int, default=2, help="distinct batches resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the side legs (profiling runs)")
-    ap.add_argument("--stages", type=int, default=vislam.STAGE_ALL, help="debug: bitmask of stages (1 detect, 2 match, 4 pose); the reported metric needs all 7")
+    ap.add_argument("--stages", type=int, default=vislam.STAGE_FRAME, help="debug: bitmask of stages (1 detect, 2 match, 4 pose, 8 Camera::Update); the reported metric needs all 15")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -428,28 +431,54 @@ def main():
         per_launch_bytes = bytes_per_frame * B / nlaunch
         per_launch_s = fam[dom] * 1e-3 / nlaunch
         achieved = per_launch_bytes / per_launch_s / 1e9
-        # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/profile_workload.py, separate
-        # FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE correction calibrated on a 256 MiB copy); measured at
-        # profiles/pmc_traffic.json["batch_frames"] frames per launch and scaled linearly to this run's batch
-        traffic, valu, pmc_commit = None, None, None
+        # Counter-side figures come from the committed rocprofv3 --pmc passes (tools/final_profile.sh -> tools/pmc_summarize.py ->
+        # profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE in separate runs with the gfx950 FETCH_SIZE correction calibrated on
+        # a 256 MiB copy, SQ instruction counts, LDS conflict cycles, and the VALU issue ceilings tools/valu_peak.hip measured in
+        # the same lease), taken at pj["batch_frames"] frames per launch and scaled linearly to this run's batch; the TIMES are
+        # this run's HIP events.  A missing or stale file is reported in the line, never silently skipped.
+        traffic, valu, detect_kernels, pmc_commit, limited_by = None, None, None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                pj = json.load(open(pmc))
-                pmc_commit = pj.get("measured_at_commit")
-                traffic = pj[kname]["hbm_bytes_per_launch"] * (B / pj["batch_frames"])
-                # the detect kernels are bound by integer VALU issue, not by bytes: instruction counts from the committed
-                # SQ_INSTS_VALU pass against (a) the issue rate of this kernel's own instruction mix measured by
-                # tools/valu_rates.hip and (b) the SIMD-32 issue peak of the guide (one wave64 VALU instruction per 2 cycles)
-                vi = pj["raw"][kname]["SQ_INSTS_VALU"]["mean"] * (B / pj["batch_frames"])
-                peak_mix = pj["valu_peak_measured"]["wave_insts_per_s"]
-                peak_issue = 256 * 4 * 2.4e9 / 2
-                valu = {"kernel": kname, "wave_insts_per_launch": vi, "achieved": vi / per_launch_s, "unit": "wave-instr/s",
-                        "peak_issue": peak_issue, "frac_of_issue_peak": vi / per_launch_s / peak_issue,
-                        "peak_measured_for_this_instruction_mix": peak_mix, "frac_of_mix_peak": vi / per_launch_s / peak_mix,
-                        "pmc_measured_at_commit": pmc_commit}
-            except Exception:
-                pass
+        try:
+            pj = json.load(open(pmc))
+            pmc_commit = pj.get("measured_at_commit")
+            scale = B / pj["batch_frames"]
+            peaks = pj["valu_peak_measured"]
+            detect_kernels = {}
+            fam_of = {"k_fast": ("ms_fast", launches_fast, alg["k_fast"]), "k_resize": ("ms_pyramid", LEVELS - 1, alg["k_resize"]),
+                      "k_describe": ("ms_describe", 1, alg["k_describe"]), "k_select": ("ms_select", 1, None)}
+            for kn, (fk, nl, ab) in fam_of.items():
+                r = pj[kn]
+                t = fam[fk] * 1e-3                                   # all launches of the family, this run
+                calls = nl                                           # per-launch counter means x launches of the family
+                vi = r["valu_wave_insts_per_launch"] * scale * calls
+                hbm = r["hbm_bytes_per_launch"] * scale * calls
+                d = {"ms": round(fam[fk], 4), "launches": nl,
+                     "hbm_traffic_bytes": hbm, "hbm_traffic_frac": hbm / t / 1e9 / HBM_PEAK_GBS,
+                     "valu_wave_insts": vi, "valu_issue_frac": vi / t / SIMD_ISSUE_PEAK,
+                     "valu_frac_of_half_rate_ceiling": vi / t / peaks["half_rate_class"],
+                     "valu_frac_of_full_rate_ceiling": vi / t / peaks["full_rate_class"],
+                     "salu_wave_insts": (r.get("salu_wave_insts_per_launch") or 0) * scale * calls,
+                     "lds_bank_conflict_cycles": (r.get("lds_bank_conflict_cycles") or 0) * scale * calls}
+                if ab is not None:
+                    d["algorithmic_bytes"] = ab * B
+                    d["hbm_frac"] = ab * B / t / 1e9 / HBM_PEAK_GBS
+                    d["traffic_over_algorithmic"] = hbm / (ab * B)
+                # what the counters say limits the kernel: the larger of (HBM traffic / peak) and (VALU issue / measured ceiling of
+                # the half-rate class, the class most of these kernels' instructions belong to)
+                d["limited_by"] = "valu-issue" if d["valu_frac_of_half_rate_ceiling"] > d["hbm_traffic_frac"] else "hbm"
+                detect_kernels[kn] = d
+            dk = detect_kernels[kname]
+            traffic = pj[kname]["hbm_bytes_per_launch"] * scale
+            limited_by = dk["limited_by"]
+            valu = {"kernel": kname, "wave_insts_per_launch": dk["valu_wave_insts"] / nlaunch, "achieved": dk["valu_wave_insts"] / (fam[dom] * 1e-3),
+                    "unit": "wave-instr/s", "peak_issue": SIMD_ISSUE_PEAK, "frac_of_issue_peak": dk["valu_issue_frac"],
+                    "peak_measured_half_rate_class": peaks["half_rate_class"], "frac_of_half_rate_ceiling": dk["valu_frac_of_half_rate_ceiling"],
+                    "peak_measured_full_rate_class": peaks["full_rate_class"], "frac_of_full_rate_ceiling": dk["valu_frac_of_full_rate_ceiling"],
+                    "peak_measured_by": peaks.get("what"), "pmc_measured_at_commit": pmc_commit,
+                    "note": "instruction counts from the committed SQ_INSTS_VALU pass (same kernels, same workload, other run); "
+                            "times from this run; a kernel made of both instruction classes sits between the two measured ceilings"}
+        except Exception as e:                                  # loud: the record says what is missing
+            valu = {"error": f"profiles/pmc_traffic.json unusable: {e!r}"}
         fps = vdist.aggregate_fps(world, a.steps, B, dt)
         out = {
             "metric": "frames/sec detect+match+pose, 752x480 mono8", "value": fps, "unit": "frames/s",
@@ -460,12 +489,15 @@ def main():
                                    "crop under pure image translation: every grid match is an exact inlier, the adaptive stop ends RANSAC after "
                                    "<= 4 hypotheses (see pose_load) and the recovered pose is degenerate; legs.s752_fixed1000 / legs.s752_parallax load "
                                    "the pose kernels.  Results stay on the device inside the timed region (legs.s752_results_d2h adds the download); "
-                                   "Camera::Update's half pyramid is not part of the step (aux_kernels.gradient_batch), the CPU baseline includes it",
+                                   "Camera::Update's half pyramid (4 levels per frame) is part of the step, as it is of the CPU baseline",
                        "frames_per_step_per_gpu": B, "parallelism": f"stream-per-gpu x{world}" if world > 1 else "single-gpu"},
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # `bound` names the roofline `frac` is priced against (north_star asks for the HBM roofline of detect/describe);
+            # `limited_by` is what the counters say actually limits this kernel (see valu_roofline / detect_kernels)
+            "roofline": {"bound": "hbm", "limited_by": limited_by, "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": per_launch_s * 1e3},
             "valu_roofline": valu,
+            "detect_kernels": detect_kernels,
             "pose_load": headline_pose,
             "aux_kernels": aux,
             "legs": legs,

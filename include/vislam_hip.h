@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VIS_ABI_VERSION 2
+#define VIS_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -112,6 +112,8 @@ typedef struct vis_timings {
     float ms_pose;         /* essential RANSAC + recoverPose   */
     int32_t launches_fast; /* number of FAST kernel launches in the last call */
     int32_t launches_total;
+    float ms_update;       /* Camera::Update half pyramid (VIS_STAGE_UPDATE), 0 when the stage did not run */
+    float reserved_;
 } vis_timings;
 
 typedef struct vis_ctx vis_ctx;
@@ -291,7 +293,10 @@ int  vis_feeder_release(vis_feeder* f, int which);
  * (carried on device), or not at all after vis_batch_reset. */
 int  vis_batch_plan(vis_ctx* ctx, int w, int h, int stride, int max_frames);
 int  vis_batch_reset(vis_ctx* ctx);
-enum { VIS_STAGE_DETECT = 1, VIS_STAGE_MATCH = 2, VIS_STAGE_POSE = 4, VIS_STAGE_ALL = 7 };
+enum { VIS_STAGE_DETECT = 1, VIS_STAGE_MATCH = 2, VIS_STAGE_POSE = 4, VIS_STAGE_ALL = 7,
+       /* Camera::Update (src/Camera.cpp:63-72) for every frame of the batch: the 4 half-resolution levels into a plan-owned
+        * buffer (vis_batch_half_pyramid), at the head of the detect chain.  Needs w, h multiples of 16. */
+       VIS_STAGE_UPDATE = 8, VIS_STAGE_FRAME = 15 };
 /* Asynchronous: d_frames = n_frames images resident in HBM (dev ptr, row stride from the plan, frame stride =
  * stride*h).  The context runs three streams: the detect chain (the stream set with vis_set_stream / the context's
  * own), the matcher, and the RANSAC/pose stage; consecutive calls overlap (detect of batch i+1 with match and pose of
@@ -299,6 +304,10 @@ enum { VIS_STAGE_DETECT = 1, VIS_STAGE_MATCH = 2, VIS_STAGE_POSE = 4, VIS_STAGE_
  * recorded on the detect stream after the call; vis_feeder_release does exactly that). */
 int  vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n_frames, int stages);
 int  vis_batch_sync(vis_ctx* ctx);
+/* the half pyramids the last vis_batch_run(... | VIS_STAGE_UPDATE) wrote: DEVICE pointer to n * *frame_elems bytes, laid out
+ * like d_gray of vis_gradient_batch (levels dense and back to back inside a frame, level 0's part untouched);
+ * VIS_E_STATE if the stage has not run.  Valid until the next vis_batch_run / vis_batch_plan. */
+int  vis_batch_half_pyramid(vis_ctx* ctx, const uint8_t** d_half, size_t* frame_elems);
 /* copy results of the last batch to host (synchronises). Any pointer may be NULL. */
 int  vis_batch_get_keypoints(vis_ctx* ctx, int frame, vis_keypoint* kps, uint8_t* desc,
                              int cap, int* n_out);
@@ -318,9 +327,12 @@ typedef struct vis_pose_result {
 } vis_pose_result;
 /* Queue the device-to-host copy of the last batch's results -- n pose records, the good matches (n x root^2, dense
  * rows) and their counts -- behind the batch's own work; any pointer may be NULL; pinned host memory makes the copy
- * overlap the next vis_batch_run.  The reference downloads its results every frame (src/CameraGPU.cpp:103, the
- * DMatch vectors of src/MatcherGPU.cpp:54-56); vis_batch_sync() (or the next vis_batch_results_async) completes it. */
-int  vis_batch_results_async(vis_ctx* ctx, vis_pose_result* h_pose, vis_dmatch* h_good, int32_t* h_ngood);
+ * overlap the next vis_batch_run.  n_cap = the number of frames the caller's buffers hold: VIS_E_CAPACITY (nothing is
+ * copied) if the last batch had more.  The reference downloads its results every frame (src/CameraGPU.cpp:103, the
+ * DMatch vectors of src/MatcherGPU.cpp:54-56).  The copies are only QUEUED: the host may read the buffers after
+ * vis_batch_sync() (or after waiting for an event recorded behind this call); a later vis_batch_results_async is
+ * ordered behind this one on the device but does not make this one visible to the host by itself. */
+int  vis_batch_results_async(vis_ctx* ctx, vis_pose_result* h_pose, vis_dmatch* h_good, int32_t* h_ngood, int n_cap);
 /* device-side error/overflow flags of the last batch (0 = clean) */
 int  vis_batch_status(vis_ctx* ctx, int* flags);
 

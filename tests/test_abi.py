@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported(vislam):
 def test_pod_layouts(vislam):
     assert vislam.KEYPOINT_DTYPE.itemsize == 28      # cv::KeyPoint
     assert vislam.DMATCH_DTYPE.itemsize == 16        # cv::DMatch
-    assert C.sizeof(vislam.Timings) == 40
+    assert C.sizeof(vislam.Timings) == 48
 
 
 def test_default_params_are_the_reference_constants(vislam):

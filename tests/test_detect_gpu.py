@@ -81,6 +81,45 @@ def test_camera_update_half_pyramid(vislam, orc, ctx, canvas):
         assert (got[l] == ref[l]).all(), l
 
 
+def test_batch_update_stage_writes_the_half_pyramids(vislam, orc, canvas):
+    """VIS_STAGE_UPDATE (Camera::Update inside the batched step): every frame's 4 half levels == the oracle's, and the detect
+    results of the same call are unchanged by it"""
+    import torch
+    p = _params(vislam)
+    c = vislam.Context(0, p)
+    n = 3
+    frames = np.stack([vislam.synth_frame(canvas, 10 + t, 752, 480) for t in range(n)])
+    dev = torch.from_numpy(frames).cuda()
+    c.batch_plan(752, 480, 752, 4)
+    with pytest.raises(vislam.VisError):                       # nothing written yet
+        c.batch_half_pyramid()
+    c.batch_run(dev.data_ptr(), n, vislam.STAGE_FRAME)
+    c.batch_sync()
+    assert c.batch_status() == 0
+    assert c.timings().ms_update > 0
+    ptr, fe = c.batch_half_pyramid()
+    assert fe == vislam.gradient_frame_elems(752, 480)
+    class _Dev:                                                  # the plan's buffer as a torch view (no copy API needed)
+        __cuda_array_interface__ = {"data": (ptr, False), "shape": (n * fe,), "typestr": "|u1", "version": 2}
+    buf = torch.as_tensor(_Dev(), device="cuda")
+    half = buf.cpu().numpy().reshape(n, fe)
+    for t in range(n):
+        ref = orc.half_pyramid(frames[t])
+        off = 752 * 480
+        for l in range(1, 5):
+            sz = ref[l].size
+            assert np.array_equal(half[t, off:off + sz].reshape(ref[l].shape), ref[l]), (t, l)
+            off += sz
+        k, d = c.batch_keypoints(t)
+        ok, od = orc.orb_detect_compute(p, frames[t])
+        _assert_same(k, d, ok, od)
+    c.batch_run(dev.data_ptr(), n, vislam.STAGE_ALL)            # without the stage the accessor refuses again
+    c.batch_sync()
+    with pytest.raises(vislam.VisError):
+        c.batch_half_pyramid()
+    c.close()
+
+
 def test_batch_matches_single(vislam, orc, canvas):
     """batched device path == single-frame path == oracle, including the carried frame across batches"""
     import torch

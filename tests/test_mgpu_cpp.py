@@ -16,6 +16,26 @@ def test_usage(built):
     assert out.returncode == 2 and "usage" in out.stderr
 
 
+def test_more_ranks_than_devices_fails_fast(built):
+    """a rank that cannot get its device must end the whole job promptly (the others would block in ncclCommInitRank forever):
+    here (no GPU, or one GPU on a test box) --gpus 3 has to come back non-zero within seconds, with no rank left behind"""
+    import time
+    t0 = time.time()
+    out = subprocess.run([EXE, "--gpus", "3", "--steps", "1", "--warmup", "0", "--batch", "8", "--timeout", "120"], capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0, out.stdout + out.stderr
+    assert time.time() - t0 < 60
+    assert "HIP device(s) visible" in out.stderr or "hipSetDevice" in out.stderr or "hipGetDeviceCount" in out.stderr, out.stderr[-500:]
+    assert "{" not in out.stdout                                     # no result line from a failed job
+    left = subprocess.run(["pgrep", "-x", "vislam_mgpu"], capture_output=True, text=True).stdout.split()
+    assert left == [], left
+
+
+def test_wall_clock_limit(built):
+    """--timeout bounds the job even when nothing fails by itself"""
+    out = subprocess.run([EXE, "--gpus", "1", "--timeout", "0"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 2 and "usage" in out.stderr
+
+
 @pytest.mark.gpu
 def test_world_size_one(built):
     env = dict(os.environ)

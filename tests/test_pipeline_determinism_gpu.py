@@ -34,7 +34,7 @@ def _run(vislam, frames_dev, n_total, batch, with_align):
         hp = torch.zeros(n * C.sizeof(vislam.PoseResult), dtype=torch.uint8).pin_memory()
         hg = torch.zeros(n * root2 * 16, dtype=torch.uint8).pin_memory()
         hn = torch.zeros(n, dtype=torch.int32).pin_memory()
-        c.batch_results_async(hp.data_ptr(), hg.data_ptr(), hn.data_ptr())
+        c.batch_results_async(n, hp.data_ptr(), hg.data_ptr(), hn.data_ptr())
         if with_align:
             c.gradient_batch(d, W, H, W, n, gray.data_ptr(), gx.data_ptr(), gy.data_ptr(), g.data_ptr())
             c.batch_align(ap, d, n, gray.data_ptr(), gx.data_ptr(), gy.data_ptr(), 0, aout.data_ptr())

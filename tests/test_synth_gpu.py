@@ -39,7 +39,9 @@ def test_batch_results_download(vislam, orc, canvas):
     hp = torch.zeros(n * C.sizeof(vislam.PoseResult), dtype=torch.uint8).pin_memory()
     hg = torch.zeros(n * 49 * 16, dtype=torch.uint8).pin_memory()
     hn = torch.zeros(n, dtype=torch.int32).pin_memory()
-    c.batch_results_async(hp.data_ptr(), hg.data_ptr(), hn.data_ptr())
+    with pytest.raises(vislam.VisError):                               # buffers for fewer frames than the batch had: refused, nothing copied
+        c.batch_results_async(n - 1, hp.data_ptr(), hg.data_ptr(), hn.data_ptr())
+    c.batch_results_async(n, hp.data_ptr(), hg.data_ptr(), hn.data_ptr())
     c.batch_run(dev.data_ptr(), n)                                     # the next batch must not disturb the queued copy
     c.batch_sync()
     pose = np.frombuffer(hp.numpy().tobytes(), vislam.POSE_RESULT_DTYPE)

@@ -16,7 +16,9 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_
   n=$(echo $c | cut -d' ' -f1)
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/pipe/pass_$n -- python3 $R/tools/profile_workload.py > $R/$OUT/pipe_$n.log 2>&1
 done
-python3 $R/tools/pmc_summarize.py $R/$OUT/pipe 512 $COMMIT > $R/$OUT/pmc_summary.log 2>&1
+# the measured VALU issue ceilings of this box, same lease (vi-slam_amd/lib/valu_peak is built by `make -C vi-slam_amd/csrc tools`)
+$R/vi-slam_amd/lib/valu_peak > $R/$OUT/valu_peak.log 2>&1
+python3 $R/tools/pmc_summarize.py $R/$OUT/pipe 512 $COMMIT $R/$OUT/valu_peak.log > $R/$OUT/pmc_summary.log 2>&1
 export VIS_PROFILE_BATCH=1024 VIS_PROFILE_STEPS=3
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
   n=$(echo $c | cut -d' ' -f1)

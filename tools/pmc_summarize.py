@@ -10,6 +10,7 @@ from collections import defaultdict
 
 out_dir, B = sys.argv[1], int(sys.argv[2])
 commit = sys.argv[3] if len(sys.argv) > 3 else None      # the build the counters were taken on (stamp it)
+peak_log = sys.argv[4] if len(sys.argv) > 4 else None    # stdout of lib/valu_peak run in the same lease (its last line is JSON)
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -31,6 +32,10 @@ res = {"batch_frames": B, "measured_at_commit": commit, "raw": summary,
                        "write_bytes_per_unit": known / cal["WRITE_SIZE"] if cal.get("WRITE_SIZE") else None,
                        "note": "MI355X_MICROARCH.md 'HBM': on gfx950 FETCH_SIZE (KB) reports half of a coalesced streaming read, "
                                "WRITE_SIZE (KB) is exact; the factors here are measured on a 256 MiB copy in the same run"}}
+if peak_log and os.path.exists(peak_log):
+    for line in open(peak_log):
+        if line.startswith("{"):
+            res.update(json.loads(line))
 fb = res["calibration"]["fetch_bytes_per_unit"] or 2048.0
 wb = res["calibration"]["write_bytes_per_unit"] or 1024.0
 for k in ("k_fast", "k_resize", "k_describe", "k_knn2", "k_knn_mfma", "k_expand", "k_select", "k_filter", "k_ransac_hyp", "k_hyp_roots", "k_hyp_score",
@@ -44,5 +49,7 @@ for k in ("k_fast", "k_resize", "k_describe", "k_knn2", "k_knn_mfma", "k_expand"
             res[k]["valu_wave_insts_per_launch"] = sq["SQ_INSTS_VALU"]["mean"]
             res[k]["lds_wave_insts_per_launch"] = sq.get("SQ_INSTS_LDS", {}).get("mean")
             res[k]["lds_bank_conflict_cycles"] = sq.get("SQ_LDS_BANK_CONFLICT", {}).get("mean")
+            res[k]["salu_wave_insts_per_launch"] = sq.get("SQ_INSTS_SALU", {}).get("mean")
+            res[k]["launches_counted"] = sq["SQ_INSTS_VALU"]["calls"]
 json.dump(res, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "raw"}, indent=1))

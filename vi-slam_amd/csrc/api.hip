@@ -88,7 +88,7 @@ extern "C" int vis_create(int device, vis_ctx** out) {
         hipEventCreateWithFlags(&ctx->ev_match_done[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_match_done[1], hipEventDisableTiming) != hipSuccess) { delete ctx; return VIS_E_HIP; }
     ctx->ev_ok = true;
-    for (int i = 0; i < 10; i++) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) ctx->ev_ok = false;
+    for (int i = 0; i < 12; i++) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) ctx->ev_ok = false;
     *out = ctx;
     return VIS_OK;
 }
@@ -102,7 +102,7 @@ extern "C" void vis_destroy(vis_ctx* ctx) {
     plan_destroy(ctx->single); plan_destroy(ctx->batch);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_sample_table) (void)hipFree(ctx->d_sample_table);
-    for (int i = 0; i < 10; i++) (void)hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < 12; i++) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->pose_stream) { (void)hipStreamSynchronize(ctx->pose_stream); (void)hipStreamDestroy(ctx->pose_stream); }
     if (ctx->ev_filter_done) (void)hipEventDestroy(ctx->ev_filter_done);
     if (ctx->ev_pose_done) (void)hipEventDestroy(ctx->ev_pose_done);
@@ -157,6 +157,9 @@ extern "C" int vis_set_params(vis_ctx* ctx, const vis_params* p) {
             return VIS_OK;
         }
         plan_destroy(np);
+        // the parameters are set, but the keyframe slots could not be carried over: say so (callers that rely on the slots see
+        // VIS_E_STATE from the next matcher call; the reason is here)
+        ctx->err = std::string("vis_set_params: keyframe slots dropped, re-planning failed (") + vis_strerror(rc) + ")" + (ctx->err.empty() ? "" : ": " + ctx->err);
     }
     plan_destroy(old);
     for (int i = 0; i < VIS_NSLOTS; i++) ctx->slot_valid[i] = 0;
@@ -214,7 +217,7 @@ void plan_destroy(Plan* pl) {
         F(pl->d_pyr[l]);
         F(pl->d_cand[l]); F(pl->d_seg_kp[l]);
     }
-    F(pl->d_fast_tiles); F(pl->d_tile_cnt); F(pl->d_seg_cnt); F(pl->d_flags); F(pl->d_angle_tab);
+    F(pl->d_fast_tiles); F(pl->d_tile_cnt); F(pl->d_seg_cnt); F(pl->d_flags); F(pl->d_angle_tab); F(pl->d_half);
     F(pl->d_kps); F(pl->d_desc); F(pl->d_nkp); F(pl->d_descx);
     for (int i = 0; i < 2; i++) { F(pl->d_pq[i]); F(pl->d_pt[i]); F(pl->d_pqn[i]); }
     F(pl->d_knn12); F(pl->d_knn21);
@@ -817,6 +820,17 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
             have_prev = true;
         }
     }
+    // Camera::Update (src/Camera.cpp:63-72) at the head of the detect chain: the half pyramid of every frame of the batch
+    pl->half_valid = false;
+    if (stages & VIS_STAGE_UPDATE) {
+        if ((pl->w & 15) || (pl->h & 15)) { ctx->err = "VIS_STAGE_UPDATE: w, h must be multiples of 16"; return VIS_E_INVALID; }
+        if (!pl->d_half) HIPCHK(ctx, hipMalloc((void**)&pl->d_half, (size_t)pl->B * vis_grad_frame_elems(pl->w, pl->h)));
+        if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[10], sA);
+        rc = launch_half_pyramid_batch(ctx, d_frames, pl->w, pl->h, pl->stride, (size_t)pl->stride * pl->h, n, pl->d_half);
+        if (rc) return rc;
+        if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[11], sA);
+        pl->half_valid = true;
+    }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[0], sA);
     if (detect) { rc = launch_detect(ctx, pl, d_frames, n, base + 1); if (rc) return rc; }
     else if (ctx->ev_ok) for (int i = 1; i <= 4; i++) (void)hipEventRecord(ctx->ev[i], sA);
@@ -874,18 +888,32 @@ extern "C" int vis_batch_sync(vis_ctx* ctx) {
         if (hipEventElapsedTime(&a, ctx->ev[5], ctx->ev[6]) == hipSuccess) ctx->tm.ms_filter = a;
         ctx->tm.ms_pose = 0;
         if (had_pose && hipEventElapsedTime(&a, ctx->ev_pose_start, ctx->ev_pose_done) == hipSuccess) ctx->tm.ms_pose = a;
-        if (hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[8]) == hipSuccess) ctx->tm.ms_total = a;
-        if (hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[6]) == hipSuccess && a > ctx->tm.ms_total) ctx->tm.ms_total = a;
-        if (had_pose && hipEventElapsedTime(&a, ctx->ev[0], ctx->ev_pose_done) == hipSuccess && a > ctx->tm.ms_total) ctx->tm.ms_total = a;
+        ctx->tm.ms_update = 0;
+        const bool upd = ctx->batch && ctx->batch->half_valid;
+        if (upd && hipEventElapsedTime(&a, ctx->ev[10], ctx->ev[11]) == hipSuccess) ctx->tm.ms_update = a;
+        hipEvent_t e0 = upd ? ctx->ev[10] : ctx->ev[0];
+        if (hipEventElapsedTime(&a, e0, ctx->ev[8]) == hipSuccess) ctx->tm.ms_total = a;
+        if (hipEventElapsedTime(&a, e0, ctx->ev[6]) == hipSuccess && a > ctx->tm.ms_total) ctx->tm.ms_total = a;
+        if (had_pose && hipEventElapsedTime(&a, e0, ctx->ev_pose_done) == hipSuccess && a > ctx->tm.ms_total) ctx->tm.ms_total = a;
     }
     return VIS_OK;
 }
 
-extern "C" int vis_batch_results_async(vis_ctx* ctx, vis_pose_result* h_pose, vis_dmatch* h_good, int32_t* h_ngood) {
+extern "C" int vis_batch_half_pyramid(vis_ctx* ctx, const uint8_t** d_half, size_t* frame_elems) {
+    if (!ctx || !ctx->batch || !d_half) return VIS_E_STATE;
+    Plan* pl = ctx->batch;
+    if (!pl->half_valid || !pl->d_half) return VIS_E_STATE;
+    *d_half = pl->d_half;
+    if (frame_elems) *frame_elems = vis_grad_frame_elems(pl->w, pl->h);
+    return VIS_OK;
+}
+
+extern "C" int vis_batch_results_async(vis_ctx* ctx, vis_pose_result* h_pose, vis_dmatch* h_good, int32_t* h_ngood, int n_cap) {
     if (!ctx || !ctx->batch) return VIS_E_STATE;
     Plan* pl = ctx->batch;
     const int n = pl->last_n;
     if (n < 1) return VIS_E_STATE;
+    if (n_cap < n) { ctx->err = "vis_batch_results_async: caller buffers hold fewer frames than the last batch"; return VIS_E_CAPACITY; }
     (void)hipSetDevice(ctx->device);
     // the pose stream is ordered behind the matcher of the same batch (ev_filter_done); without a pose stage the matcher's own stream
     hipStream_t s = ctx->pose_pending ? ctx->pose_stream : ctx->match_stream;

@@ -51,6 +51,8 @@ struct Plan {
     float4*  d_seg_kp[VIS_MAX_LEVELS] = {};  // B x keep_cap (x, y, response, unused)
     int32_t* d_flags = nullptr;              // device error flags (1 word)
     uint32_t* d_angle_tab = nullptr;         // IC-angle byte weight/mask table for k_describe
+    uint8_t* d_half = nullptr;               // VIS_STAGE_UPDATE: B x vis_grad_frame_elems(w, h) half pyramids (allocated on first use)
+    bool half_valid = false;
     // records
     vis_keypoint* d_kps = nullptr;           // nrec x kcap
     uint8_t* d_desc = nullptr;               // nrec x kcap x 32
@@ -107,7 +109,7 @@ struct vis_ctx {
     Plan* single = nullptr;
     Plan* batch = nullptr;
     vis_timings tm;
-    hipEvent_t ev[10];
+    hipEvent_t ev[12];
     bool ev_ok = false;
     // grow-only scratch for the *_host entry points
     void* d_scratch = nullptr; size_t scratch_bytes = 0;

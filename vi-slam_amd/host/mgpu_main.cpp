@@ -1,7 +1,7 @@
 // mgpu_main.cpp -- the C++ multi-GPU launcher of the frame-sharded path (BASELINE configs[3]): host code in
 // C++ like the reference's (src/main_vi_slamGPU.cpp), HIP through the C ABI, the ONE collective through RCCL directly.
 //
-//   vislam_mgpu --gpus N [--steps K] [--warmup W] [--batch B]
+//   vislam_mgpu --gpus N [--steps K] [--warmup W] [--batch B] [--timeout SECONDS]
 //
 // The parent never touches the GPU: it forks N ranks (one process per GPU, rank r <-> device r <-> camera stream r).
 // Rank 0 creates the ncclUniqueId and hands it to the others through a file; every rank then
@@ -9,11 +9,17 @@
 //   3. generates its own S-752 stream on its device (seed 0xE0C00010 + r), plans, warms up,
 //   4. barrier (ncclAllReduce of one int), times K steps of vis_batch_run over frames resident in HBM, barrier,
 //   5. ncclAllReduce(MAX) of the elapsed time; rank 0 prints one JSON line: frames of ALL ranks / slowest rank's time.
+// Failure handling: every rank checks the visible device count before it touches the communicator; the parent reaps its ranks
+// as they exit (waitpid(-1)), and on the FIRST rank that fails, is killed or outlives --timeout it kills the others (a rank whose
+// peer died would otherwise block in ncclCommInitRank / a collective forever) and returns that rank's code.  Ranks die with the
+// parent (PR_SET_PDEATHSIG).  Nothing is ever re-exec'ed.
 // No data-path collective exists: streams are independent (a frame needs only the previous frame of its own stream,
 // src/Camera.cpp:149-150); xGMI bandwidth is irrelevant at this payload.  bench.py (the driver's contract) does the same
 // through torch.distributed; this program is the path a C++ deployment of the reference would use.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <signal.h>
+#include <sys/prctl.h>
 #include <sys/wait.h>
 #include <unistd.h>
 #include <chrono>
@@ -31,6 +37,9 @@
 static int run_rank(int rank, int world, int steps, int warmup, int B, const std::string& id_path) {
     vis_ctx* ctx = nullptr;
     const int W = 752, H = 480, R = 2, DIM = 4096;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
+    if (ndev < world) { std::fprintf(stderr, "rank %d: --gpus %d but %d HIP device(s) visible\n", rank, world, ndev); return 3; }
     CK_HIP(hipSetDevice(rank));
     // ---- communicator: rank 0 publishes the unique id, the others poll for the file
     ncclUniqueId id;
@@ -75,7 +84,7 @@ static int run_rank(int rank, int world, int steps, int warmup, int B, const std
     for (int t0 = 0; t0 < B * R; t0 += 256)
         CK_VIS(vis_synth_frames_device(ctx, d_canvas, DIM, seed, t0, std::min(256, B * R - t0), W, H, W, 0, d_frames + fb * t0));
     CK_VIS(vis_batch_plan(ctx, W, H, W, B));
-    for (int i = 0; i < warmup; i++) CK_VIS(vis_batch_run(ctx, d_frames + fb * B * (i % R), B, VIS_STAGE_ALL));
+    for (int i = 0; i < warmup; i++) CK_VIS(vis_batch_run(ctx, d_frames + fb * B * (i % R), B, VIS_STAGE_FRAME));
     CK_VIS(vis_batch_sync(ctx));
     int flags = 0;
     CK_VIS(vis_batch_status(ctx, &flags));
@@ -87,7 +96,7 @@ static int run_rank(int rank, int world, int steps, int warmup, int B, const std
     CK_HIP(hipDeviceSynchronize());
     CK_NCCL(ncclAllReduce(d_one, d_one, 1, ncclInt, ncclSum, comm, cs)); CK_HIP(hipStreamSynchronize(cs));
     const auto t0 = std::chrono::steady_clock::now();
-    for (int i = 0; i < steps; i++) CK_VIS(vis_batch_run(ctx, d_frames + fb * B * ((warmup + i) % R), B, VIS_STAGE_ALL));
+    for (int i = 0; i < steps; i++) CK_VIS(vis_batch_run(ctx, d_frames + fb * B * ((warmup + i) % R), B, VIS_STAGE_FRAME));
     CK_VIS(vis_batch_sync(ctx));
     CK_HIP(hipDeviceSynchronize());
     CK_NCCL(ncclAllReduce(d_one, d_one, 1, ncclInt, ncclSum, comm, cs)); CK_HIP(hipStreamSynchronize(cs));
@@ -112,29 +121,63 @@ static int run_rank(int rank, int world, int steps, int warmup, int B, const std
 }
 
 int main(int argc, char** argv) {
-    int gpus = 1, steps = 40, warmup = 5, B = 1024;
+    int gpus = 1, steps = 40, warmup = 5, B = 1024, timeout_s = 900;
     for (int i = 1; i + 1 < argc; i += 2) {
         const std::string k = argv[i];
         if (k == "--gpus") gpus = std::atoi(argv[i + 1]);
         else if (k == "--steps") steps = std::atoi(argv[i + 1]);
         else if (k == "--warmup") warmup = std::atoi(argv[i + 1]);
         else if (k == "--batch") B = std::atoi(argv[i + 1]);
+        else if (k == "--timeout") timeout_s = std::atoi(argv[i + 1]);
     }
-    if (gpus < 1 || gpus > 64 || steps < 1 || B < 1) { std::fprintf(stderr, "usage: vislam_mgpu --gpus N [--steps K] [--warmup W] [--batch B]\n"); return 2; }
+    if (gpus < 1 || gpus > 64 || steps < 1 || B < 1 || timeout_s < 1) {
+        std::fprintf(stderr, "usage: vislam_mgpu --gpus N [--steps K] [--warmup W] [--batch B] [--timeout SECONDS]\n"); return 2;
+    }
     char tmpl[] = "/tmp/vislam_nccl_id_XXXXXX";
     const int fd = mkstemp(tmpl);
     if (fd >= 0) { close(fd); unlink(tmpl); }
     const std::string id_path = tmpl;
     // one process per GPU, forked BEFORE anything initialises HIP in this process
+    const pid_t parent = getpid();
     std::vector<pid_t> kids;
     for (int r = 0; r < gpus; r++) {
         const pid_t pid = fork();
-        if (pid < 0) { std::perror("fork"); return 2; }
-        if (pid == 0) _exit(run_rank(r, gpus, steps, warmup, B, id_path));
+        if (pid < 0) { std::perror("fork"); for (pid_t k : kids) kill(k, SIGKILL); return 2; }
+        if (pid == 0) {
+            prctl(PR_SET_PDEATHSIG, SIGKILL);                        // a rank never outlives the launcher
+            if (getppid() != parent) _exit(2);
+            _exit(run_rank(r, gpus, steps, warmup, B, id_path));
+        }
         kids.push_back(pid);
     }
-    int rc = 0;
-    for (pid_t k : kids) { int st = 0; waitpid(k, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st)) rc = WIFEXITED(st) ? WEXITSTATUS(st) : 1; }
+    // reap in completion order; first failure (or the wall-clock limit) ends the job for everyone
+    int rc = 0, alive = gpus;
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::seconds(timeout_s);
+    while (alive > 0) {
+        int st = 0;
+        const pid_t done = waitpid(-1, &st, WNOHANG);
+        if (done > 0) {
+            alive--;
+            for (pid_t& k : kids) if (k == done) k = -1;
+            const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+            if (code != 0 && rc == 0) {
+                rc = code;
+                std::fprintf(stderr, "vislam_mgpu: a rank ended with code %d: stopping the other %d\n", code, alive);
+                for (pid_t k : kids) if (k > 0) kill(k, SIGKILL);
+            }
+            continue;
+        }
+        if (done < 0) break;                                         // no children left
+        if (std::chrono::steady_clock::now() > t_end) {
+            if (rc == 0) rc = 124;
+            std::fprintf(stderr, "vislam_mgpu: %d s wall-clock limit reached: stopping %d rank(s)\n", timeout_s, alive);
+            for (pid_t k : kids) if (k > 0) kill(k, SIGKILL);
+            while (waitpid(-1, &st, 0) > 0) { }
+            break;
+        }
+        usleep(20000);
+    }
     unlink(id_path.c_str());
+    unlink((id_path + ".tmp").c_str());
     return rc;
 }

@@ -89,7 +89,7 @@ class Timings(C.Structure):
     _fields_ = [("ms_total", C.c_float), ("ms_pyramid", C.c_float), ("ms_fast", C.c_float),
                 ("ms_select", C.c_float), ("ms_describe", C.c_float), ("ms_knn", C.c_float),
                 ("ms_filter", C.c_float), ("ms_pose", C.c_float),
-                ("launches_fast", C.c_int32), ("launches_total", C.c_int32)]
+                ("launches_fast", C.c_int32), ("launches_total", C.c_int32), ("ms_update", C.c_float), ("reserved_", C.c_float)]
 
 
 KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
@@ -99,6 +99,7 @@ assert KEYPOINT_DTYPE.itemsize == 28 and DMATCH_DTYPE.itemsize == 16
 
 SYM_REFERENCE_EFFECTIVE, SYM_INTENDED = 0, 1
 STAGE_DETECT, STAGE_MATCH, STAGE_POSE, STAGE_ALL = 1, 2, 4, 7
+STAGE_UPDATE, STAGE_FRAME = 8, 15          # Camera::Update's half pyramid at the head of the detect chain; FRAME = ALL | UPDATE
 
 # every symbol include/vislam_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -113,7 +114,7 @@ ABI_SYMBOLS = [
     "vis_image_list", "vis_image_time", "vis_pgm_info", "vis_image_read",
     "vis_feeder_create", "vis_feeder_destroy", "vis_feeder_host_buffer", "vis_feeder_submit", "vis_feeder_release",
     "vis_default_align_params", "vis_estimate_pose_features", "vis_align_batch", "vis_batch_align",
-    "vis_synth_frame_parallax", "vis_synth_frames_device", "vis_batch_results_async",
+    "vis_synth_frame_parallax", "vis_synth_frames_device", "vis_batch_results_async", "vis_batch_half_pyramid",
     "vis_se3_exp", "vis_se3_mul", "vis_se3_from_rt", "vis_se3_matrix",
 ]
 
@@ -179,7 +180,8 @@ def _load():
     lib.vis_feeder_release.argtypes = [vp, ci]
     lib.vis_synth_frame_parallax.argtypes = [vp, ci, C.c_uint64, ci, ci, ci, vp, ci]
     lib.vis_synth_frames_device.argtypes = [vp, vp, ci, C.c_uint64, ci, ci, ci, ci, ci, ci, vp]
-    lib.vis_batch_results_async.argtypes = [vp, vp, vp, vp]
+    lib.vis_batch_results_async.argtypes = [vp, vp, vp, vp, ci]
+    lib.vis_batch_half_pyramid.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.vis_se3_exp.argtypes = [vp, C.POINTER(Se3f)]; lib.vis_se3_exp.restype = None
     lib.vis_se3_mul.argtypes = [C.POINTER(Se3f), C.POINTER(Se3f), C.POINTER(Se3f)]; lib.vis_se3_mul.restype = None
     lib.vis_se3_from_rt.argtypes = [vp, vp, C.POINTER(Se3f)]; lib.vis_se3_from_rt.restype = None
@@ -548,17 +550,24 @@ class Context:
     def batch_sync(self):
         self._chk(lib.vis_batch_sync(self._h), "vis_batch_sync")
 
-    def batch_results_async(self, h_pose_ptr=None, h_good_ptr=None, h_ngood_ptr=None):
-        """queue the D2H copy of the last batch's results (raw host pointers, ideally pinned); completed by batch_sync()"""
+    def batch_results_async(self, n_cap, h_pose_ptr=None, h_good_ptr=None, h_ngood_ptr=None):
+        """queue the D2H copy of the last batch's results (raw host pointers, ideally pinned, holding n_cap frames); the host may
+        read them after batch_sync()"""
         self._chk(lib.vis_batch_results_async(self._h, C.c_void_p(h_pose_ptr) if h_pose_ptr else None,
                                               C.c_void_p(h_good_ptr) if h_good_ptr else None,
-                                              C.c_void_p(h_ngood_ptr) if h_ngood_ptr else None), "vis_batch_results_async")
+                                              C.c_void_p(h_ngood_ptr) if h_ngood_ptr else None, n_cap), "vis_batch_results_async")
+
+    def batch_half_pyramid(self):
+        """(device pointer, frame_elems) of the half pyramids the last batch_run(..., STAGE_UPDATE) wrote"""
+        d, fe = C.c_void_p(0), C.c_size_t(0)
+        self._chk(lib.vis_batch_half_pyramid(self._h, C.byref(d), C.byref(fe)), "vis_batch_half_pyramid")
+        return d.value, fe.value
 
     def batch_results(self, n):
         """synchronous convenience: (pose records, good matches n x root^2, counts) of the last batch"""
         root2 = int(np.floor(np.sqrt(self.params.n_cells))) ** 2
         pose = np.zeros(n, POSE_RESULT_DTYPE); good = np.zeros((n, root2), DMATCH_DTYPE); ng = np.zeros(n, np.int32)
-        self.batch_results_async(pose.ctypes.data, good.ctypes.data, ng.ctypes.data)
+        self.batch_results_async(n, pose.ctypes.data, good.ctypes.data, ng.ctypes.data)
         self.batch_sync()
         return pose, good, ng
 
