@@ -159,7 +159,11 @@ static int real_roots(const double* cin, int deg, double* roots) {
 
 // ---------------------------------------------------------------------------- five-point solver
 // q1xy/q2xy: 5 x 2 normalised image points.  Es: up to 10 matrices, row-major, x2^T E x1 = 0.
-int five_point(const double* q1, const double* q2, double* Es) {
+static int five_point_ex(const double* q1, const double* q2, double* Es, double* poly_out, double* roots_out, int* nroots_out);
+int five_point(const double* q1, const double* q2, double* Es) { return five_point_ex(q1, q2, Es, nullptr, nullptr, nullptr); }
+// poly_out (11 ascending coefficients of det B(z)), roots_out / nroots_out (its real roots as found by real_roots): test hooks
+static int five_point_ex(const double* q1, const double* q2, double* Es, double* poly_out, double* roots_out, int* nroots_out) {
+    if (nroots_out) *nroots_out = 0;
     // A = Q^T (9 x 5), Q row i = [x2x1, x2y1, x2, y2x1, y2y1, y2, x1, y1, 1]
     double A[9][5];
     for (int i = 0; i < 5; i++) {
@@ -282,6 +286,9 @@ int five_point(const double* q1, const double* q2, double* Es) {
     }
     double roots[10];
     int nr = real_roots(c10, 10, roots);
+    if (poly_out) for (int i = 0; i <= 10; i++) poly_out[i] = c10[i];
+    if (roots_out) for (int i = 0; i < nr; i++) roots_out[i] = roots[i];
+    if (nroots_out) *nroots_out = nr;
     int count = 0;
     for (int ri = 0; ri < nr && count < 10; ri++) {
         double z = roots[ri];
@@ -512,6 +519,10 @@ int recover_pose(const vis_params& p, const double* E, const float* p1xy, const 
 
 using namespace orc;
 
+extern "C" int orc_five_point_poly(const double* q1xy, const double* q2xy, double* Es, double* poly11, double* roots10, int* n_roots) {
+    if (!q1xy || !q2xy || !Es || !poly11 || !roots10 || !n_roots) return VIS_E_INVALID;
+    return orc::five_point_ex(q1xy, q2xy, Es, poly11, roots10, n_roots);
+}
 extern "C" int orc_five_point(const double* q1xy, const double* q2xy, double* Es) {
     if (!q1xy || !q2xy || !Es) return VIS_E_INVALID;
     return five_point(q1xy, q2xy, Es);

@@ -59,6 +59,9 @@ int orc_good_matches(const vis_params* p, const vis_keypoint* kps1, int n1,
 /* 5-point minimal solver on 5 normalised correspondences: up to 10 E (row-major, unit
  * Frobenius norm, x2^T E x1 = 0), ordered by ascending root z. returns count */
 int orc_five_point(const double* q1xy, const double* q2xy, double* Es);
+/* test hook: the same call + the degree-10 polynomial det B(z) (11 ascending coefficients) and the real roots the
+ * derivative-interlacing bisection found for it (ascending) */
+int orc_five_point_poly(const double* q1xy, const double* q2xy, double* Es, double* poly11, double* roots10, int* n_roots);
 /* findEssentialMat(..., RANSAC, prob, thr), src/VISystem.cpp:1679-1680 */
 int orc_essential_ransac(const vis_params* p, const float* p1xy, const float* p2xy, int m,
                          double E[9], uint8_t* mask, int* n_inliers, int* iters_run);

@@ -160,6 +160,16 @@ def five_point(q1, q2):
     return Es[:n].reshape(-1, 3, 3).copy()
 
 
+def five_point_poly(q1, q2):
+    """(E models, the 11 ascending coefficients of the degree-10 polynomial, its real roots as the oracle found them)"""
+    q1 = np.ascontiguousarray(q1, np.float64).reshape(5, 2)
+    q2 = np.ascontiguousarray(q2, np.float64).reshape(5, 2)
+    Es = np.zeros((10, 9), np.float64); poly = np.zeros(11); roots = np.zeros(10); nr = ci(0)
+    n = lib.orc_five_point_poly(_p(q1), _p(q2), _p(Es), _p(poly), _p(roots), C.byref(nr))
+    assert n >= 0
+    return Es[:n].reshape(-1, 3, 3).copy(), poly, roots[:nr.value].copy()
+
+
 def essential_ransac(p, p1, p2):
     p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
     p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)

@@ -86,6 +86,47 @@ def test_ties_beyond_the_slack_are_reported(vislam, ctx):
     assert len(k) == 384
 
 
+def _one_over_f(h, w, seed):
+    """1/f ("pink") texture: white noise shaped by 1/f in the Fourier domain, stretched to the full 8-bit range"""
+    rng = np.random.default_rng(seed)
+    fy = np.fft.fftfreq(h)[:, None]; fx = np.fft.fftfreq(w)[None, :]
+    f = np.sqrt(fx * fx + fy * fy); f[0, 0] = 1.0
+    img = np.fft.ifft2(np.fft.fft2(rng.normal(0, 1, (h, w))) / f).real
+    img = (img - img.min()) / (img.max() - img.min())
+    return np.clip(img * 255.0 + rng.integers(-3, 4, (h, w)), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("kind", ["uniform_noise", "one_over_f"])
+def test_headline_geometry_on_corner_dense_images(vislam, orc, ctx, kind):
+    """752x480, N = 1000, 8 levels -- the bench geometry -- on images with far more FAST corners (and far more ties at the
+    retainBest cuts) than S-752: no capacity flag (VIS_E_CAPACITY is a failure mode the reference does not have) and
+    bit-exact parity"""
+    rng = np.random.default_rng(17)
+    img = rng.integers(0, 256, (480, 752), dtype=np.uint8) if kind == "uniform_noise" else _one_over_f(480, 752, 18)
+    p = vislam.default_params()
+    p.nfeatures, p.nlevels, p.w_size, p.h_size = 1000, 8, 752, 480
+    k, d = _check(vislam, orc, ctx, p, img)
+    assert len(k) >= 900
+
+
+def test_headline_geometry_saturated_ties_are_reported(vislam, orc, ctx):
+    """isolated 0 / 255 pixels on a flat background: 8119 IDENTICAL FAST scores at the retainBest(2 * quota) cut of level 0, all
+    of which KeyPointsFilter::retainBest (and the oracle) pass on to the Harris stage, which then keeps its quota of 217.  8119
+    survivors are beyond the LDS sort a plan is sized for (2.5 * quota + 256 -> 1024 entries): the device
+    path fails with VIS_E_CAPACITY, it never returns a silently cut set"""
+    rng = np.random.default_rng(17)
+    rng.integers(0, 256, (480, 752), dtype=np.uint8)               # (same stream position as the CPU-side analysis in DESIGN.md)
+    img = np.where(rng.random((480, 752)) < 0.08, rng.integers(0, 2, (480, 752)) * 255, 128).astype(np.uint8)
+    p = vislam.default_params()
+    p.nfeatures, p.nlevels, p.w_size, p.h_size = 1000, 8, 752, 480
+    ok, od = orc.orb_detect_compute(p, img, cap=40000)
+    assert (ok["octave"] == 0).sum() == 217                        # the oracle handles it: the Harris cut brings level 0 back to its quota
+    ctx.set_params(p)
+    with pytest.raises(vislam.VisError) as ei:
+        ctx.orb_detect_compute(img, slot=0, cap=40000)
+    assert ei.value.code == -4
+
+
 def test_context_reuse_and_param_changes(vislam, orc, ctx, canvas):
     img = vislam.synth_frame(canvas, 2, 752, 480)
     p = vislam.default_params()

@@ -1,0 +1,201 @@
+"""CPU: independent re-derivations (numpy only) of whole oracle stages, and the numpy model of k_fast's byte-SWAR pretest.
+
+These do NOT pin the oracle against OpenCV (nothing here can: OpenCV is absent and the reference ships no fixture -- parity
+stays UNPINNED).  They shrink the surface where the oracle could be wrong about the *published
+algorithms*: a second implementation written from the definition, not from the oracle's code, has to agree with it.
+  (a) FAST-9/16: definitional score (largest threshold for which a 9-arc exists) + 3x3 NMS    vs orc_fast_detect
+  (b) five-point: numpy.roots of the degree-10 polynomial                                     vs the bisection roots
+  (c) cv::resize INTER_LINEAR: float64 bilinear interpolation at the same sample positions    vs orc_resize_linear (+-1 LSB)
+  (d) k_fast's SWAR pretest (vi-slam_amd/csrc/detect.hip) replayed in numpy uint32 arithmetic: it never rejects a FAST corner
+"""
+import numpy as np
+import pytest
+
+RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+def _images(rng, n=96):
+    yy, xx = np.mgrid[0:n, 0:n]
+    noise = rng.integers(0, 256, (n, n)).astype(np.uint8)                                   # uniform noise: corners everywhere
+    blocks = (rng.integers(0, 2, (n // 8, n // 8)) * 200 + 20).astype(np.uint8).repeat(8, 0).repeat(8, 1)
+    blocks = np.clip(blocks.astype(int) + rng.integers(-6, 7, (n, n)), 0, 255).astype(np.uint8)   # checkerboard-like + noise
+    ramp = np.clip(xx * 2 + yy + rng.integers(-30, 31, (n, n)), 0, 255).astype(np.uint8)     # gradient + strong noise
+    extreme = (rng.integers(0, 2, (n, n)) * 255).astype(np.uint8)                            # 0 / 255 only: every wrap case of the SWAR bytes
+    return {"noise": noise, "blocks": blocks, "ramp": ramp, "extreme": extreme}
+
+
+def _definitional_fast(img, t):
+    """score[y, x] = largest t' such that 9 contiguous ring pixels are all > c + t' or all < c - t' (0 if t' < t)"""
+    h, w = img.shape
+    c = img[3:h - 3, 3:w - 3].astype(np.int32)
+    d = np.stack([img[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx].astype(np.int32) for dx, dy in RING]) - c[None]
+    dd = np.concatenate([d, d[:8]])
+    bright = np.max(np.stack([dd[k:k + 9].min(0) for k in range(16)]), 0)       # max over arcs of the smallest (ring - c)
+    dark = np.max(np.stack([(-dd[k:k + 9]).min(0) for k in range(16)]), 0)
+    s = np.maximum(bright, dark) - 1
+    score = np.zeros((h, w), np.int32)
+    score[3:h - 3, 3:w - 3] = np.where(s >= t, s, 0)
+    return score
+
+
+@pytest.mark.parametrize("t", [5, 20, 60])
+def test_definitional_fast_matches_the_oracle(orc, t):
+    rng = np.random.default_rng(100 + t)
+    for name, img in _images(rng).items():
+        score = _definitional_fast(img, t)
+        xs, ys, sc, smap = orc.fast_detect(img, t)
+        assert np.array_equal(smap.astype(np.int32), np.minimum(score, 255)), name
+        pad = np.pad(score, 1)
+        h, w = score.shape
+        nb = np.stack([pad[1 + dy:1 + dy + h, 1 + dx:1 + dx + w] for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dx, dy) != (0, 0)])
+        keep = (score > 0) & (score[None] > nb).all(0)
+        ky, kx = np.nonzero(keep)                                                # row-major, like cv::FAST emits
+        assert np.array_equal(xs, kx) and np.array_equal(ys, ky), name
+        assert np.array_equal(sc, score[ky, kx]), name
+
+
+def test_degree10_roots_are_complete(orc):
+    """numpy.roots (companion-matrix eigenvalues) vs the oracle's derivative-interlacing bisection on 200 random minimal
+    samples: same number of real roots, same values; and every returned E satisfies the five epipolar constraints"""
+    rng = np.random.default_rng(7)
+    checked = 0
+    for trial in range(200):
+        # a random two-view geometry: 5 points in front of both cameras
+        ang = rng.normal(0, 0.2, 3)
+        K = np.array([[0, -ang[2], ang[1]], [ang[2], 0, -ang[0]], [-ang[1], ang[0], 0]])
+        R = np.eye(3) + K + K @ K / 2
+        U, _, Vt = np.linalg.svd(R); R = U @ Vt
+        tvec = rng.normal(0, 1, 3); tvec /= np.linalg.norm(tvec)
+        X = np.column_stack([rng.uniform(-1, 1, 5), rng.uniform(-1, 1, 5), rng.uniform(2, 6, 5)])
+        X2 = X @ R.T + tvec
+        q1, q2 = X[:, :2] / X[:, 2:], X2[:, :2] / X2[:, 2:]
+        Es, poly, roots = orc.five_point_poly(q1, q2)
+        if np.abs(poly).max() == 0:
+            continue
+        allr = np.roots(poly[::-1])
+        scale = max(1.0, np.abs(allr).max())
+        real = np.sort(allr[np.abs(allr.imag) < 1e-7 * scale].real)
+        # a double root that numpy splits into a complex pair (or vice versa) is not a disagreement: skip near-degenerate cases
+        gaps = np.abs(allr.imag[np.abs(allr.imag) >= 1e-7 * scale])
+        if len(gaps) and gaps.min() < 1e-4 * scale:
+            continue
+        assert len(real) == len(roots), (trial, real, roots)
+        assert np.allclose(real, roots, rtol=1e-6, atol=1e-8), (trial, real, roots)
+        assert len(Es) == len(roots)
+        h1 = np.column_stack([q1, np.ones(5)]); h2 = np.column_stack([q2, np.ones(5)])
+        for E, z in zip(Es, roots):
+            assert np.abs(np.einsum("ni,ij,nj->n", h2, E, h1)).max() < 1e-8      # always: E is in the null space by construction
+            # the cubic constraints hold to rounding unless the root is nearly double (back-substitution through the cofactors of
+            # B(z) is ill-conditioned there: one such sample, roots 1.07711 / 1.07768, reaches 5e-5)
+            others = np.abs(allr - z); others = np.sort(others)[1] if len(allr) > 1 else 1.0
+            if others < 1e-2 * max(1.0, abs(z)):
+                continue
+            assert abs(np.linalg.det(E)) < 1e-8
+            assert np.abs(2 * E @ E.T @ E - np.trace(E @ E.T) * E).max() < 1e-7
+        # the true essential matrix is among the solutions
+        Etrue = np.array([[0, -tvec[2], tvec[1]], [tvec[2], 0, -tvec[0]], [-tvec[1], tvec[0], 0]]) @ R
+        Etrue /= np.linalg.norm(Etrue)
+        assert min(min(np.abs(E - Etrue).max(), np.abs(E + Etrue).max()) for E in Es) < 1e-6, trial
+        checked += 1
+    assert checked >= 150
+
+
+@pytest.mark.parametrize("sw,sh,dw,dh", [(752, 480, 627, 400), (627, 400, 522, 333), (96, 64, 80, 53), (64, 64, 32, 32), (100, 37, 34, 13)])
+def test_float64_bilinear_within_one_lsb(orc, sw, sh, dw, dh):
+    """cv::resize INTER_LINEAR is a bilinear interpolation at ((d + 0.5) * scale - 0.5) with clamped borders, evaluated in
+    11-bit fixed point: the float64 evaluation of the same formula may differ by rounding only"""
+    rng = np.random.default_rng(sw * 7 + dw)
+    src = rng.integers(0, 256, (sh, sw)).astype(np.uint8)
+    got = orc.resize_linear(src, dw, dh).astype(np.float64)
+
+    def axis(n_dst, n_src):
+        f = (np.arange(n_dst) + 0.5) * (n_src / n_dst) - 0.5
+        i0 = np.floor(f).astype(int)
+        a = f - i0
+        a = np.where(i0 < 0, 0.0, a); i0 = np.maximum(i0, 0)
+        a = np.where(i0 >= n_src - 1, 0.0, a); i0 = np.minimum(i0, n_src - 1)
+        return i0, np.minimum(i0 + 1, n_src - 1), a
+    # rows: the reference implementation clamps the row INDICES but keeps the fraction (resizeGeneric_Invoker)
+    fy = (np.arange(dh) + 0.5) * (sh / dh) - 0.5
+    y0f = np.floor(fy).astype(int); ay = fy - y0f
+    y0 = np.clip(y0f, 0, sh - 1); y1 = np.clip(y0f + 1, 0, sh - 1)
+    x0, x1, ax = axis(dw, sw)
+    s = src.astype(np.float64)
+    top = s[y0][:, x0] * (1 - ax) + s[y0][:, x1] * ax
+    bot = s[y1][:, x0] * (1 - ax) + s[y1][:, x1] * ax
+    ref = top * (1 - ay)[:, None] + bot * ay[:, None]
+    assert np.abs(got - ref).max() <= 1.0 + 1e-9
+
+
+# ---- (d) the SWAR pretest of k_fast, formula for formula ---------------------------------------------------------------------
+H = np.uint32(0x80808080); M7 = np.uint32(0x7F7F7F7F)
+
+
+def _swar_unit_pass(C, N, S, E, W, t):
+    """C, N, S, E, W: uint32 arrays, 4 pixels per word (centre and the ring pixels 3 px up / down / right / left).
+    Returns the pass word (bit 7 of byte j = position j goes to cornerScore), exactly as detect.hip computes it."""
+    K = (t + 1) >> 1
+    assert 3 <= K <= 128
+    kD = np.uint32((0x80808080 - (K - 1) * 0x01010101) & 0xFFFFFFFF)
+    kB = np.uint32(((2 * K - 3) * 0x01010101) & 0xFFFFFFFF)
+    one = np.uint32(1)
+    cD = ((C >> one) & M7) + kD
+    dn, ds = cD - ((N >> one) & M7), cD - ((S >> one) & M7)
+    de, dw = cD - ((E >> one) & M7), cD - ((W >> one) & M7)
+    dark = (dn | ds) & (de | dw)
+    nbright = ((dn + kB) & (ds + kB)) | ((de + kB) & (dw + kB))
+    return (dark | ~nbright) & H
+
+
+def _pack4(a):
+    a = a.astype(np.uint32)
+    return a[..., 0] | (a[..., 1] << np.uint32(8)) | (a[..., 2] << np.uint32(16)) | (a[..., 3] << np.uint32(24))
+
+
+@pytest.mark.parametrize("t", [5, 6, 7, 20, 21, 60, 120, 200, 255])
+def test_swar_pretest_never_rejects_a_corner(t):
+    rng = np.random.default_rng(t)
+    with np.errstate(over="ignore"):
+        for name, img in _images(rng, 128).items():
+            h, w = img.shape
+            score = _definitional_fast(img, t)
+            wq = (w - 6) // 4 * 4
+            cy, cx = np.mgrid[3:h - 3, 3:3 + wq:4]                               # first pixel of every 4-pixel unit
+            def word(dy, dx):
+                return _pack4(np.stack([img[cy + dy, cx + dx + j] for j in range(4)], -1))
+            ps = _swar_unit_pass(word(0, 0), word(3, 0), word(-3, 0), word(0, 3), word(0, -3), t)
+            for j in range(4):
+                bit = (ps >> np.uint32(8 * j + 7)) & np.uint32(1)
+                corner = score[cy, cx + j] > 0
+                assert not (corner & (bit == 0)).any(), (name, t, j)
+                # and it is a useful test, not "pass everything" (except on the 0/255 image, where every pixel is extreme)
+            if name == "blocks" and 20 <= t <= 120:          # beyond that the wrap cases (|difference| > 128 - K) dominate: still safe, no longer selective
+                allbits = sum(((ps >> np.uint32(8 * j + 7)) & np.uint32(1)).sum() for j in range(4))
+                assert allbits < 0.6 * 4 * ps.size
+
+
+def test_swar_byte_tests_exhaustive():
+    """every (centre, ring) byte pair in one lane, neighbours at the wrap-prone extremes, all thresholds 5..255: a ring pixel
+    that is darker than c - t (brighter than c + t) always sets the dark bit (clears the not-bright bit)"""
+    c1, r1 = np.meshgrid(np.arange(256, dtype=np.uint32), np.arange(256, dtype=np.uint32), indexing="ij")
+    one = np.uint32(1)
+    ext = np.array([0, 1, 127, 128, 254, 255], np.uint32)
+    with np.errstate(over="ignore"):
+        for t in list(range(5, 256, 3)) + [20, 255]:
+            K = (t + 1) >> 1
+            kD = np.uint32((0x80808080 - (K - 1) * 0x01010101) & 0xFFFFFFFF)
+            kB = np.uint32(((2 * K - 3) * 0x01010101) & 0xFFFFFFFF)
+            for lane in range(4):
+                for oc in ext:
+                    for orr in ext:
+                        C = np.zeros((256, 256), np.uint32); R = np.zeros((256, 256), np.uint32)
+                        for L in range(4):
+                            C |= (c1 if L == lane else oc) << np.uint32(8 * L)
+                            R |= (r1 if L == lane else orr) << np.uint32(8 * L)
+                        D = (((C >> one) & M7) + kD) - ((R >> one) & M7)
+                        B = D + kB
+                        dbit = (D >> np.uint32(8 * lane + 7)) & one
+                        nb = (B >> np.uint32(8 * lane + 7)) & one
+                        ci, ri = c1.astype(np.int64), r1.astype(np.int64)
+                        assert not ((ri < ci - t) & (dbit == 0)).any(), (t, lane, oc, orr)
+                        assert not ((ri > ci + t) & (nb == 1)).any(), (t, lane, oc, orr)

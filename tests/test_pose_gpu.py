@@ -72,20 +72,54 @@ def test_ransac_fixed_iterations(vislam, orc, ctx):
     assert _cmpE(E, oE) <= TOL
 
 
-def test_f2f_ransac(vislam, orc, ctx):
-    p = vislam.default_params()
-    ctx.set_params(p)
-    x1, x2, R, t = two_view(40, 21, 0.1, 0.2)
+def _f2f_inputs(vislam, m, seed, outliers, noise):
+    x1, x2, R, t = two_view(max(m, 5), seed, outliers, noise)
     KP = vislam.KEYPOINT_DTYPE
-    a, b = np.zeros(40, KP), np.zeros(40, KP)
-    a["x"], a["y"], b["x"], b["y"] = x1[:, 0], x1[:, 1], x2[:, 0], x2[:, 1]
-    rng = np.random.default_rng(3)
-    idx = rng.integers(0, 39, (1000, 2)).astype(np.int32)       # rand() % (n-1), src/VISystem.cpp:712-713
-    got, cg = ctx.f2f_ransac(a, b, R.T.astype(np.float32), idx, 0.37)
-    ref, co = orc.f2f_ransac(p, a, b, R.T.astype(np.float32), idx, 0.37)
-    assert cg == co
+    a, b = np.zeros(m, KP), np.zeros(m, KP)
+    a["x"], a["y"], b["x"], b["y"] = x1[:m, 0], x1[:m, 1], x2[:m, 0], x2[:m, 1]
+    return a, b, R.T.astype(np.float32)
+
+
+@pytest.mark.parametrize("m,seed,outl,noise,thr", [(40, 21, 0.1, 0.2, 370.0), (40, 5, 0.3, 0.5, 370.0), (120, 6, 0.5, 1.0, 370.0), (15, 7, 0.0, 0.0, 370.0),
+                                                   (40, 8, 0.2, 0.3, 250.0), (40, 9, 0.2, 0.3, 600.0), (3, 10, 0.0, 0.1, 370.0), (2, 11, 0.0, 0.0, 370.0)])
+def test_f2f_ransac(vislam, orc, ctx, m, seed, outl, noise, thr):
+    """VISystem::F2FRansac (src/VISystem.cpp:612-769): the inlier test -1000 / log10(|d . n_i|) < threshold compares a
+    transcendental (device libm vs host libm) against a constant, and the winner is the strictly larger COUNT: seeds, noise
+    levels, thresholds and M down to 2 (M = 1 divides by zero in the reference; specified as the zero vector)"""
+    p = vislam.default_params()
+    p.f2f_threshold = thr
+    ctx.set_params(p)
+    a, b, rot = _f2f_inputs(vislam, m, seed, outl, noise)
+    rng = np.random.default_rng(seed)
+    idx = rng.integers(0, max(m - 1, 1), (1000, 2)).astype(np.int32)       # rand() % (n-1), src/VISystem.cpp:712-713
+    got, cg = ctx.f2f_ransac(a, b, rot, idx, 0.37)
+    ref, co = orc.f2f_ransac(p, a, b, rot, idx, 0.37)
+    assert cg == co, (cg, co)
     assert np.abs(got - ref).max() <= 1e-6
-    z, c0 = ctx.f2f_ransac(a[:1], b[:1], np.eye(3, dtype=np.float32), idx[:0], 1.0)
+
+
+def test_f2f_ransac_counts_near_a_tie(vislam, orc, ctx):
+    """thresholds swept through the value at which the best hypothesis's count changes: whatever side of a boundary a
+    correspondence falls on, both implementations must put it on the same side (the count compare is exact)"""
+    p = vislam.default_params()
+    a, b, rot = _f2f_inputs(vislam, 60, 33, 0.25, 0.4)
+    idx = np.random.default_rng(33).integers(0, 59, (1000, 2)).astype(np.int32)
+    seen = set()
+    for thr in np.linspace(150.0, 900.0, 26):
+        p.f2f_threshold = float(thr)
+        ctx.set_params(p)
+        got, cg = ctx.f2f_ransac(a, b, rot, idx, 1.0)
+        ref, co = orc.f2f_ransac(p, a, b, rot, idx, 1.0)
+        assert cg == co, (thr, cg, co)
+        assert np.abs(got - ref).max() <= 1e-6
+        seen.add(cg)
+    assert len(seen) >= 5                                          # the sweep really crossed count boundaries
+
+
+def test_f2f_ransac_degenerate(vislam, ctx):
+    ctx.set_params(vislam.default_params())
+    KP = vislam.KEYPOINT_DTYPE
+    z, c0 = ctx.f2f_ransac(np.zeros(1, KP), np.zeros(1, KP), np.eye(3, dtype=np.float32), np.zeros((0, 2), np.int32), 1.0)
     assert (z == 0).all() and c0 == 0
 
 
