@@ -97,10 +97,27 @@ def _f32(line):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,nframes", [("plain", 45), ("parallax", 12)])
+@pytest.mark.parametrize("mode,nframes", [("plain", 45), ("parallax", 12), ("rectified", 8)])
 def test_main_loop_matches_oracle(vislam, orc, canvas, tmp_path, mode, nframes):
+    """"rectified": a calibration WITH distortion coefficients (the EuRoC values the reference ships): the adapters then run on
+    K' = getOptimalNewCameraMatrix(alpha = 1) and on the ROI dimensions like src/VISystemGPU.cpp:60-76 (frames stay un-remapped,
+    as in the reference's GPU main); the oracle side of this test gets K' and the ROI from camera_model_probe, whose values
+    tests/test_camera_model.py checks against an independent evaluation"""
     f = tmp_path / "cal.xml"
-    f.write_text(CAL_XML)
+    xml = CAL_XML
+    Ws, Hs = 752, 480                                                # the system's w, h (ROI with a rectifying calibration)
+    Kc = [458.654, 457.296, 367.215, 248.375]
+    if mode == "rectified":
+        xml = xml.replace("<data> 0 0 0 0 </data></rectification>", "<data> -0.28340811 0.07395907 0.00019359 1.76187114e-05 </data></rectification>")
+        assert "-0.28340811" in xml
+        f.write_text(xml)
+        import json
+        pj = json.loads([l for l in subprocess.run([os.path.join(os.path.dirname(EXE), "camera_model_probe"), str(f)], capture_output=True, text=True,
+                                                   timeout=60).stdout.splitlines() if l.startswith("{")][-1])
+        Ws, Hs = pj["roi"][2] - pj["roi"][0], pj["roi"][3] - pj["roi"][1]
+        Kc = pj["K"]
+        assert pj["valid"] == 1 and Ws < 752 and Hs < 480
+    f.write_text(xml)
     csv = tmp_path / "out.csv"
     args = [EXE, str(f), str(nframes), str(csv)] + (["parallax"] if mode == "parallax" else [])
     out = subprocess.run(args, capture_output=True, text=True, timeout=600)
@@ -119,10 +136,12 @@ def test_main_loop_matches_oracle(vislam, orc, canvas, tmp_path, mode, nframes):
     assert abs(float((init[:4].astype(np.float64) ** 2).sum()) - 1) < 1e-6
 
     p = vislam.default_params()
-    p.fx = p.fy = float(np.float32(458.654))
-    p.cx, p.cy = float(np.float32(367.215)), float(np.float32(248.375))
+    p.fx = p.fy = float(np.float32(Kc[0]))
+    p.cx, p.cy = float(np.float32(Kc[2])), float(np.float32(Kc[3]))
+    p.w_size, p.h_size = Ws, Hs                                       # Matcher::setImageDimensions gets the system's w, h
     ap = orc.default_align_params()
-    ap.fx, ap.fy, ap.cx, ap.cy = np.float32(458.654), np.float32(457.296), np.float32(367.215), np.float32(248.375)
+    ap.fx, ap.fy, ap.cx, ap.cy = np.float32(Kc[0]), np.float32(Kc[1]), np.float32(Kc[2]), np.float32(Kc[3])
+    win = lambda levels: [np.ascontiguousarray(a[:Hs >> l, :Ws >> l]) for l, a in enumerate(levels)]   # noqa: E731  (top-left w_[l] x h_[l] window)
     seed_pose = orc.se3_from_rt(np.eye(3, dtype=np.float32), np.array([-0.0, -0.0, -0.0], np.float32))   # SE3(I, -TranslationResidual)
     final = vislam.Se3f(*[float(x) for x in init])
     keyframes = []            # dicts: kp, desc, pyr, gx, gy
@@ -144,12 +163,12 @@ def test_main_loop_matches_oracle(vislam, orc, canvas, tmp_path, mode, nframes):
             good, sym = orc.good_matches(p, last["kp"], k, o12, o21)
             assert fr[2] == len(sym) and fr[3] == len(good), (i, fr, len(sym), len(good))
             prev_good = last["kp"][good["queryIdx"]]
-            cand = [orc.patch_points(prev_good, 752, 480, l) for l in range(5)]
+            cand = [orc.patch_points(prev_good, Ws, Hs, l) for l in range(5)]
             keyframes.append(cur)
             if len(keyframes) > 20:                                  # num_max_keyframes = camera_model->min_features (src/VISystemGPU.cpp:121)
                 keyframes.pop(0); checked_free = True
             assert fr[4] == len(keyframes), (i, fr[4], len(keyframes))
-            r = orc.estimate_pose_features(ap, 752, 480, last["pyr"], pyr, last["gx"], last["gy"], cand, seed_pose)
+            r = orc.estimate_pose_features(ap, Ws, Hs, win(last["pyr"]), win(pyr), win(last["gx"]), win(last["gy"]), cand, seed_pose)
             assert aligns[i][1:5] == [r.iterations[3], r.iterations[2], r.iterations[1], r.iterations[0]], (i, aligns[i])
             assert aligns[i][5:9] == [r.n_residuals[3], r.n_residuals[2], r.n_residuals[1], r.n_residuals[0]]
             assert np.array_equal(aposes[i], r.pose.as_array()), (i, aposes[i], r.pose.as_array())

@@ -1,5 +1,6 @@
 // vislam_host.cpp -- adapter bodies; every method cites the reference body it mirrors.
 #include "vislam_host.hpp"
+#include <cfloat>
 #include <cmath>
 #include <cstdlib>
 #include <ctime>
@@ -392,6 +393,7 @@ static vector<double> xml_numbers(const string& doc, const string& tag) {
     while (is >> x) v.push_back(x);
     return v;
 }
+Mat optimal_new_camera_matrix_alpha1(const float K[4], const float dist[4], int in_w, int in_h, int out_w, int out_h);
 void CameraModel::GetCameraModel(string _calibration_path) {                          // src/CameraModel.cpp:16-101
     valid_ = true;
     std::ifstream f(_calibration_path.c_str());
@@ -424,14 +426,72 @@ void CameraModel::GetCameraModel(string _calibration_path) {                    
     if (dist_coeffs_[0] == 0) {                                                       // :78-83
         cout << "Distortion coefficients not found ... not rectifying" << endl;
         valid_ = false;
+        output_intrinsic_camera_ = original_intrinsic_camera_;
     } else {
-        // The reference rectifies here (getOptimalNewCameraMatrix + initUndistortRectifyMap, :84-99) and VISystem crops to a ROI:
-        // calib3d work outside the hot path.  The frames this build processes are taken as they come (the benches use a
-        // zero-distortion calibration), with the original intrinsics.
-        cout << "Distortion coefficients found ... rectification is outside this build: using the original intrinsics" << endl;
-        valid_ = false;
+        // :84-88: K_ = getOptimalNewCameraMatrix(K, dist, Size(in), alpha = 1.0, Size(out), nullptr, false).  The reference never
+        // remaps the frames of the GPU main (VISystemGPU::AddFrameGPU hands the raw image on), but every intrinsic it uses
+        // afterwards -- InitializePyramid, EstimatePoseFeatures, findEssentialMat -- is this matrix, so it is restated here.
+        cout << "Distortion coefficients found ... rectifying" << endl;
+        output_intrinsic_camera_ = optimal_new_camera_matrix_alpha1(input_calibration_, dist_coeffs_, in_width_, in_height_, out_width_, out_height_);
     }
-    output_intrinsic_camera_ = original_intrinsic_camera_;
+}
+
+// cv::getOptimalNewCameraMatrix(alpha = 1, centerPrincipalPoint = false) as calib3d 3.2 computes it (calibration.cpp:
+// cvGetOptimalNewCameraMatrix -> icvGetRectangles -> cvUndistortPoints) -- written from the published algorithm, OpenCV is not
+// available here: PARITY UNPINNED like the rest of the OpenCV-owned arithmetic.
+//   1. a 9 x 9 grid of pixel positions (x * w / 8, y * h / 8), stored as float;
+//   2. each is undistorted into normalised coordinates by 5 fixed-point iterations of the inverse Brown model (double);
+//   3. outer = bounding box of the 81 results (float); with alpha = 1 the new projection maps it onto the output viewport:
+//      fx' = (out_w - 1) / outer.width, cx' = -fx' * outer.x (same for y).
+Mat optimal_new_camera_matrix_alpha1(const float K[4], const float dist[4], int in_w, int in_h, int out_w, int out_h) {
+    const double fx = K[0], fy = K[1], cx = K[2], cy = K[3], k1 = dist[0], k2 = dist[1], p1 = dist[2], p2 = dist[3];
+    float oX0 = FLT_MAX, oX1 = -FLT_MAX, oY0 = FLT_MAX, oY1 = -FLT_MAX;
+    const int N = 9;
+    for (int y = 0; y < N; y++)
+        for (int x = 0; x < N; x++) {
+            const float u = (float)x * in_w / (N - 1), v = (float)y * in_h / (N - 1);
+            double xn = ((double)u - cx) * (1.0 / fx), yn = ((double)v - cy) * (1.0 / fy);
+            const double x0 = xn, y0 = yn;
+            for (int j = 0; j < 5; j++) {
+                const double r2 = xn * xn + yn * yn;
+                const double icdist = 1.0 / (1 + (k2 * r2 + k1) * r2);
+                const double dX = 2 * p1 * xn * yn + p2 * (r2 + 2 * xn * xn);
+                const double dY = p1 * (r2 + 2 * yn * yn) + 2 * p2 * xn * yn;
+                xn = (x0 - dX) * icdist; yn = (y0 - dY) * icdist;
+            }
+            const float px = (float)xn, py = (float)yn;
+            oX0 = std::min(oX0, px); oX1 = std::max(oX1, px); oY0 = std::min(oY0, py); oY1 = std::max(oY1, py);
+        }
+    const float ow = oX1 - oX0, oh = oY1 - oY0;                                       // cv::Rect_<float>(oX0, oY0, oX1 - oX0, oY1 - oY0)
+    const double fx1 = (out_w - 1) / (double)ow, fy1 = (out_h - 1) / (double)oh;
+    const double cx1 = -fx1 * oX0, cy1 = -fy1 * oY0;
+    Mat M = Mat::zeros(3, 3, CV_32FC1);
+    M.at<float>(0, 0) = (float)fx1; M.at<float>(1, 1) = (float)fy1; M.at<float>(0, 2) = (float)cx1; M.at<float>(1, 2) = (float)cy1; M.at<float>(2, 2) = 1;
+    return M;
+}
+
+// initUndistortRectifyMap(K, dist, Mat(), K', Size(out)) maps output pixel (u, v) to the source position
+//   x = (u - cx') / fx', y = (v - cy') / fy';  r2 = x^2 + y^2;  kr = 1 + k1 r2 + k2 r2^2
+//   (fx (x kr + 2 p1 x y + p2 (r2 + 2 x^2)) + cx,  fy (y kr + p1 (r2 + 2 y^2) + 2 p2 x y) + cy)
+// and remap(INTER_LINEAR, BORDER_CONSTANT 0) leaves a pixel black when no tap of its 2 x 2 footprint lies inside the source.
+void CameraModel::RectifiedROI(int roi[4]) const {
+    const double fx = input_calibration_[0], fy = input_calibration_[1], cx = input_calibration_[2], cy = input_calibration_[3];
+    const double k1 = dist_coeffs_[0], k2 = dist_coeffs_[1], p1 = dist_coeffs_[2], p2 = dist_coeffs_[3];
+    const double fxn = output_intrinsic_camera_.at<float>(0, 0), fyn = output_intrinsic_camera_.at<float>(1, 1);
+    const double cxn = output_intrinsic_camera_.at<float>(0, 2), cyn = output_intrinsic_camera_.at<float>(1, 2);
+    auto inside = [&](int u, int v) {
+        const double x = (u - cxn) / fxn, y = (v - cyn) / fyn, r2 = x * x + y * y, kr = 1 + k1 * r2 + k2 * r2 * r2;
+        const double su = fx * (x * kr + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)) + cx;
+        const double sv = fy * (y * kr + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y) + cy;
+        return su > -1.0 && su < in_width_ && sv > -1.0 && sv < in_height_;
+    };
+    const int x_middle = (int)((out_width_ - 1) * 0.5), y_middle = (int)((out_height_ - 1) * 0.5);   // :170-171
+    int x1 = 0, y1 = 0, x2 = out_width_ - 1, y2 = out_height_ - 1;
+    while (x1 < x2 && !inside(x1, y_middle)) x1++;
+    while (x2 > x1 && !inside(x2, y_middle)) x2--;
+    while (y1 < y2 && !inside(x_middle, y1)) y1++;
+    while (y2 > y1 && !inside(x_middle, y2)) y2--;
+    roi[0] = x1 + 5; roi[1] = y1 + 5; roi[2] = x2 - 5; roi[3] = y2 - 5;                // :193-197
 }
 
 // ---------------------------------------------------------------- vi::VISystem / vi::VISystemGPU (src/VISystem.cpp, src/VISystemGPU.cpp)
@@ -477,10 +537,21 @@ void VISystem::EstimatePoseFeatures(Frame* _previous_frame, Frame* _current_fram
     vis_align_params ap; vis_default_align_params(&ap);
     ap.fx = fx_[0]; ap.fy = fy_[0]; ap.cx = cx_[0]; ap.cy = cy_[0];
     const uint8_t* g1[5]; const uint8_t* g2[5]; const int16_t* gx[5]; const int16_t* gy[5]; const float* cd[5]; int32_t n[5];
+    // With a rectifying calibration the system's (w, h) is the ROI of src/VISystem.cpp:162-205 while the frames keep their
+    // size: the reference bounds-checks against w_[lvl], h_[lvl] and indexes the full-size Mats (:1267-1305).  The C ABI takes
+    // dense w_[lvl] x h_[lvl] levels, so the top-left w_[lvl] x h_[lvl] window of every level is what is handed over.
+    Mat crop[4][5];
+    auto window = [&](const Mat& m, int l, Mat& keep) -> const uint8_t* {
+        if (m.empty() || (m.cols == w_[l] && m.rows == h_[l] && m.step == (size_t)m.cols * m.elemSize())) return m.data;
+        if (m.cols < w_[l] || m.rows < h_[l]) return nullptr;
+        keep.create(h_[l], w_[l], m.depth);
+        for (int y = 0; y < h_[l]; y++) std::memcpy(keep.data + (size_t)y * keep.step, m.data + (size_t)y * m.step, keep.step);
+        return keep.data;
+    };
     for (int l = 0; l < 5; l++) {
-        g1[l] = _previous_frame->grayImage[l].data; g2[l] = _current_frame->grayImage[l].data;
-        gx[l] = reinterpret_cast<const int16_t*>(_previous_frame->gradientX[l].data);
-        gy[l] = reinterpret_cast<const int16_t*>(_previous_frame->gradientY[l].data);
+        g1[l] = window(_previous_frame->grayImage[l], l, crop[0][l]); g2[l] = window(_current_frame->grayImage[l], l, crop[1][l]);
+        gx[l] = reinterpret_cast<const int16_t*>(window(_previous_frame->gradientX[l], l, crop[2][l]));
+        gy[l] = reinterpret_cast<const int16_t*>(window(_previous_frame->gradientY[l], l, crop[3][l]));
         cd[l] = reinterpret_cast<const float*>(_previous_frame->candidatePoints[l].data);
         n[l] = _previous_frame->candidatePoints[l].rows;
         if (!g1[l] || !g2[l] || !gx[l] || !gy[l]) n[l] = 0;                            // Update() could not build the half pyramid (size not a multiple of 16)
@@ -550,7 +621,13 @@ void VISystemGPU::InitializeSystemGPU(string _calPath, Point3d _iniPosition, Poi
     map1 = camera_model->GetMap1(); map2 = camera_model->GetMap2();
     fx = K.at<float>(0, 0); fy = K.at<float>(1, 1); cx = K.at<float>(0, 2); cy = K.at<float>(1, 2);
     distortion_valid = camera_model->IsValid();
-    w = w_input; h = h_input;                                                        // :72-85 without the ROI of rectified images
+    if (distortion_valid) {                                                          // :66-75, CalculateROI (src/VISystem.cpp:162-205)
+        int roi[4]; camera_model->RectifiedROI(roi);
+        w = roi[2] - roi[0]; h = roi[3] - roi[1];                                     // :201-204
+        cout << "distortion detected" << endl;
+        cout << "Input width = " << w_input << "\t" << " Output width = " << w << endl;
+        cout << "Input height = " << h_input << "\t" << " Output height = " << h << endl;
+    } else { w = w_input; h = h_input; }
     InitializePyramid(w, h, K);
     initialized = true;
     cout << "Initializing system ... done" << endl << endl;

@@ -189,6 +189,11 @@ public:
     int GetInputWidth() const { return in_width_; }
     int GetInputHeight() const { return in_height_; }
     bool IsValid() const { return valid_; }
+    // what VISystem::CalculateROI (src/VISystem.cpp:162-205) looks for in the rectified first image, from the geometry of the
+    // rectification map alone: first / last column of the middle row and first / last row of the middle column whose source
+    // position falls inside the input image, +-5 px margin.  (x1, y1, x2, y2); see INTEGRATION.md for the remaining gap
+    void RectifiedROI(int roi[4]) const;
+    const float* DistCoeffs() const { return dist_coeffs_; }
     Mat imu2cam0Transformation;                          // 4x4 CV_32F
     float camera_frecuency = 0, imu_frecuency = 0;
     int min_features = 0, num_max_keyframes = 0, start_index = 0, use_gt = 0, use_ros = 0, num_cells = 0, length_patch = 0, detector = 0, matcher = 0;
