@@ -823,6 +823,7 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
     // Camera::Update (src/Camera.cpp:63-72) at the head of the detect chain: the half pyramid of every frame of the batch
     pl->half_valid = false;
     if (stages & VIS_STAGE_UPDATE) {
+        VisRange r_("vis: Camera::Update half pyramid");
         if ((pl->w & 15) || (pl->h & 15)) { ctx->err = "VIS_STAGE_UPDATE: w, h must be multiples of 16"; return VIS_E_INVALID; }
         if (!pl->d_half) HIPCHK(ctx, hipMalloc((void**)&pl->d_half, (size_t)pl->B * vis_grad_frame_elems(pl->w, pl->h)));
         if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[10], sA);
@@ -832,7 +833,7 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
         pl->half_valid = true;
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[0], sA);
-    if (detect) { rc = launch_detect(ctx, pl, d_frames, n, base + 1); if (rc) return rc; }
+    if (detect) { VisRange r_("vis: ORB detect + describe"); rc = launch_detect(ctx, pl, d_frames, n, base + 1); if (rc) return rc; }
     else if (ctx->ev_ok) for (int i = 1; i <= 4; i++) (void)hipEventRecord(ctx->ev[i], sA);
     HIPCHK(ctx, hipEventRecord(ctx->ev_detect_done, sA));
     if (stages & (VIS_STAGE_MATCH | VIS_STAGE_POSE)) HIPCHK(ctx, hipStreamWaitEvent(sM, ctx->ev_detect_done, 0));
@@ -842,6 +843,7 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
     pl->d_pair_t = pl->d_pt[cur];
     ctx->stream = sM;
     if (stages & VIS_STAGE_MATCH) {
+        VisRange r_("vis: knn + match filters");
         rc = launch_expand(ctx, pl, base, n + 1);
         if (!rc) rc = launch_match(ctx, pl, n);
         if (!rc) {
@@ -860,6 +862,7 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
         (void)hipStreamWaitEvent(sP, ctx->ev_filter_done, 0);
         ctx->stream = sP;
         (void)hipEventRecord(ctx->ev_pose_start, sP);
+        VisRange r_("vis: essential RANSAC + recoverPose");
         rc = launch_pose(ctx, pl, n);
         (void)hipEventRecord(ctx->ev_pose_done, sP);
         ctx->pose_pending = true;

@@ -378,9 +378,15 @@ int launch_expand(vis_ctx* ctx, Plan* pl, int rec_first, int rec_count) {
 
 int launch_match(vis_ctx* ctx, Plan* pl, int npairs) {
     if (npairs <= 0) return VIS_OK;
-    static const bool force_popcount = getenv("VIS_KNN_POPCOUNT") != nullptr;     // A/B measurements only
+    // A/B knobs exist only in the diagnostic build (make EXTRA=-DVIS_AB_KNOBS): the shipped library reads no environment variable
+#ifdef VIS_AB_KNOBS
+    static const bool force_popcount = getenv("VIS_KNN_POPCOUNT") != nullptr;
+    static const int nc = getenv("VIS_KNN_NC") ? atoi(getenv("VIS_KNN_NC")) : 2;
+#else
+    const bool force_popcount = false;
+    const int nc = 2;
+#endif
     if (pl->d_descx && pl->kcap <= 16384 && !force_popcount) {
-        static const int nc = getenv("VIS_KNN_NC") ? atoi(getenv("VIS_KNN_NC")) : 2;     // A/B measurements only
         const int per_wg = 128 * (nc == 1 ? 1 : 2);
         const int nchunks = (pl->kcap + per_wg - 1) / per_wg;
         dim3 grid(8 * ((npairs + 7) / 8) * 2 * nchunks);

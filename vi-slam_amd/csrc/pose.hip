@@ -748,7 +748,8 @@ __global__ __launch_bounds__(256) void k_hyp_roots_lane(PoseParams P, int h0, in
 // 256 threads then score every model of the sub-item against the pair's points (wave = model, lanes = points),
 // and thread hyp picks the first model with the largest count.  hbest[pair][h] = (best count << 4) | model, -1 = none.
 #define SC_CH 1024                                                 // points staged in LDS per pass
-__global__ __launch_bounds__(256) void k_hyp_score(PoseParams P, int h0, int h_end, int npairs, const int32_t* __restrict__ rstate,
+// rstate is read (words 0, 6) AND written (word 8, the models-scored counter) here: a plain pointer, no const / __restrict__ promise
+__global__ __launch_bounds__(256) void k_hyp_score(PoseParams P, int h0, int h_end, int npairs, int32_t* rstate,
                                                    const double* __restrict__ n1, const double* __restrict__ n2,
                                                    const double* __restrict__ hyp, size_t S, double* __restrict__ models,
                                                    int32_t* __restrict__ hbest, const int32_t* __restrict__ worklist, int chunks) {
@@ -832,7 +833,7 @@ __global__ __launch_bounds__(256) void k_hyp_score(PoseParams P, int h0, int h_e
         __syncthreads();
         if (tid == 0) {
             int t = 0; for (int k = 0; k < 16; k++) { sBase[k] = t; t += sCnt[k]; } sTotal = t;
-            if (t) atomicAdd(const_cast<int32_t*>(rstate) + (size_t)pair * RS + 8, t);   // point evaluations = models x M
+            if (t) atomicAdd(rstate + (size_t)pair * RS + 8, t);   // point evaluations = models x M
         }
         __syncthreads();
         if (valid) {
@@ -1130,7 +1131,13 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
         // per chunk of hypotheses: (A) minimal solver up to the degree-10 polynomial, lane = hypothesis, 118 KB LDS per wave;
         // (B) its real roots, 16 lanes per hypothesis; (C) models + inlier counts, 256 threads per 16 hypotheses;
         // then the sequential accept/adaptive-bound rule is replayed by k_ransac_scan.
-        static const int first_chunk = getenv("VIS_RANSAC_FIRST") ? std::max(4, std::min(16, atoi(getenv("VIS_RANSAC_FIRST")) & ~3)) : 16;   // A/B knob
+#ifdef VIS_AB_KNOBS       // diagnostic build only (make EXTRA=-DVIS_AB_KNOBS): the shipped library reads no environment variable
+        static const int first_chunk = getenv("VIS_RANSAC_FIRST") ? std::max(4, std::min(16, atoi(getenv("VIS_RANSAC_FIRST")) & ~3)) : 16;
+        static const bool roots16 = getenv("VIS_ROOTS_16LANE") != nullptr;      // the 16-lanes-per-polynomial kernel for every chunk
+#else
+        const int first_chunk = 16;
+        const bool roots16 = false;
+#endif
         const int first = std::min(ctx->p.ransac_adaptive ? first_chunk : 16, std::max(max_iters, 1));
         const int hc = first <= 4 ? 4 : (first <= 8 ? 8 : 16), ppb = 64 / hc;
         const size_t S = (size_t)npairs * max_iters;
@@ -1147,7 +1154,6 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
             const int nsub = (int)std::min<long long>(2048, (long long)npairs * chunks * 4);
             hipLaunchKernelGGL(k_ransac_hyp_list, dim3(nb), dim3(64), HYP_LDS_BYTES, st, P, first, max_iters,
                                npairs, d_n1, d_n2, d_samples, d_rstate, d_hyp, S, (const int32_t*)d_worklist, chunks);
-            static const bool roots16 = getenv("VIS_ROOTS_16LANE") != nullptr;      // A/B knob: the 16-lanes-per-polynomial kernel for every chunk
             if (roots16)
                 hipLaunchKernelGGL(k_hyp_roots, dim3(nsub), dim3(256), 0, st, P, first, max_iters, npairs, d_rstate, d_hyp, S,
                                    (const int32_t*)d_worklist, chunks, 0);

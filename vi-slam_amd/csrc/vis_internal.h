@@ -118,6 +118,15 @@ struct vis_ctx {
     int32_t* d_sample_table = nullptr; int sample_max_m = 0; int sample_iters = 0; unsigned long long sample_seed = 0;
 };
 
+// roctx ranges around the stage families of a batched step (readable rocprofv3 --marker-trace timelines); compiled in when the
+// ROCm install has the roctx header (Makefile: -DVIS_HAVE_ROCTX -lrocprofiler-sdk-roctx), otherwise no-ops
+#ifdef VIS_HAVE_ROCTX
+#include <rocprofiler-sdk-roctx/roctx.h>
+struct VisRange { explicit VisRange(const char* n) { roctxRangePushA(n); } ~VisRange() { roctxRangePop(); } };
+#else
+struct VisRange { explicit VisRange(const char*) {} };
+#endif
+
 #define HIPCHK(ctx, call)                                                          \
     do { hipError_t e_ = (call);                                                   \
          if (e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); \

@@ -110,7 +110,10 @@ void Matcher::computeMatches() {                                                
     if (rc) VisDevice::fail(rc, "computeMatches");
     clock_t knn2 = clock();
     unpack_knn(o12, n1, aux_matches1); unpack_knn(o21, n2, aux_matches2);
-    elapsed_knn1 = elapsed_knn2 = 0.5 * double(knn2 - begin) / CLOCKS_PER_SEC;
+    // elapsed_*: the device time of the call (hipEvents on the context's stream, vis_last_timings) -- what the reference's clock()
+    // around a blocking OpenCV-CUDA call measures; host clock() only if the context has no events
+    vis_timings tm; const bool dev = vis_last_timings(ctx, &tm) == VIS_OK && tm.ms_knn > 0;
+    elapsed_knn1 = elapsed_knn2 = dev ? 0.5e-3 * tm.ms_knn : 0.5 * double(knn2 - begin) / CLOCKS_PER_SEC;
 }
 void Matcher::computeBestMatches(int n_cells) {                                   // :353-367 (sym + sort + grid, fused on device)
     vis_ctx* ctx = VisDevice::get();
@@ -145,7 +148,8 @@ void Matcher::computeBestMatches(int n_cells) {                                 
     for (int i = 0; i < ns; i++) matches.push_back(DMatch(sym[i].queryIdx, sym[i].trainIdx, sym[i].distance));
     for (int i = 0; i < ng; i++) goodMatches.push_back(DMatch(good[i].queryIdx, good[i].trainIdx, good[i].distance));
     nSymMatches = ns; nBestMatches = ng;
-    elapsed_symMatches = elapsed_sortMatches = 0; elapsed_bestMatches = double(best - begin) / CLOCKS_PER_SEC;
+    vis_timings tm; const bool dev = vis_last_timings(ctx, &tm) == VIS_OK && tm.ms_filter > 0;
+    elapsed_symMatches = elapsed_sortMatches = 0; elapsed_bestMatches = dev ? 1e-3 * tm.ms_filter : double(best - begin) / CLOCKS_PER_SEC;
 }
 void Matcher::getMatches(vector<KeyPoint>& a, vector<KeyPoint>& b) {              // :286-292
     for (unsigned i = 0; i < matches.size(); i++) { a.push_back(keypoints_1[matches[i].queryIdx]); b.push_back(keypoints_2[matches[i].trainIdx]); }
@@ -301,6 +305,7 @@ bool CameraGPU::addGPUKeyframe() {                                              
     clock_t cbegin = clock();
     nPointsDetect = detectAndComputeGPUFeatures();
     clock_t cdetect = clock();
+    vis_timings tdet; const bool dev_det = vis_last_timings(VisDevice::get(), &tdet) == VIS_OK && tdet.ms_total > 0;
     if ((nPointsDetect > 1) && (frameList.size() != 0)) {
         computeGPUGoodMatches();
         clock_t cgood = clock();
@@ -311,8 +316,9 @@ bool CameraGPU::addGPUKeyframe() {                                              
         clock_t cpatches = clock();
         saveFrame();
         nBestMatches = (int)matcherGPU.goodMatches.size();
-        elapsed_detect = double(cdetect - cbegin) / CLOCKS_PER_SEC;
-        elapsed_computeGoodMatches = double(cgood - cdetect) / CLOCKS_PER_SEC;
+        elapsed_detect = dev_det ? 1e-3 * tdet.ms_total : double(cdetect - cbegin) / CLOCKS_PER_SEC;   // device time of the detect chain
+        const double dev_match = matcherGPU.elapsed_knn1 + matcherGPU.elapsed_knn2 + matcherGPU.elapsed_bestMatches;
+        elapsed_computeGoodMatches = dev_match > 0 ? dev_match : double(cgood - cdetect) / CLOCKS_PER_SEC;
         elapsed_computeGradient = double(cgradient - cgood) / CLOCKS_PER_SEC;
         elapsed_computePatches = double(cpatches - cgradient) / CLOCKS_PER_SEC;
         elapsed_detect_sum += elapsed_detect; elapsed_computeGoodMatches_sum += elapsed_computeGoodMatches;
