@@ -121,10 +121,12 @@ DEV void mul_ql_u(const double (&q)[10], const double (&l)[4], double (&c)[20], 
         for (int v = 0; v < 4; v++) c[CT::T.c_of[m][v]] += sgn * (q[m] * l[v]);
 }
 
-// LDS layout (one wave per block): element-major, lane-minor -> every access is conflict free
-#define LM(r, c) ldsM[((r) * 20 + (c)) * 64 + lane]
-#define LB(j, i) ldsB[((j) * 9 + (i)) * 64 + lane]
-#define HYP_LDS_BYTES ((200 + 36) * 64 * 8)
+// LDS layout (one wave per block): FOUR lanes per hypothesis, 16 hypotheses per wave; element-major, hypothesis-minor.
+// 236 doubles per hypothesis = 30 KB per wave: five waves per CU (the lane-per-hypothesis layout needed 118 KB: one).
+#define QH 16
+#define LM(r, c) ldsM[((r) * 20 + (c)) * QH + hs]
+#define LB(j, i) ldsB[((j) * 9 + (i)) * QH + hs]
+#define HYP_LDS_BYTES ((200 + 36) * QH * 8)
 // hypothesis record (doubles, element-major over all (pair, iteration) slots): det polynomial c[0..10], the three
 // B(z) row polynomials, the null-space basis, the real roots; then two int32 planes: flag, number of roots
 #define HR_BX 11
@@ -137,7 +139,7 @@ DEV void mul_ql_u(const double (&q)[10], const double (&l)[4], double (&c)[20], 
 #define HYP_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
-DEV void load_El(const double* ldsB, int lane, int r, int c, double (&l)[4]) {
+DEV void load_El(const double* ldsB, int hs, int r, int c, double (&l)[4]) {
 #pragma unroll
     for (int v = 0; v < 4; v++) l[v] = LB(v, 3 * r + c);
 }
@@ -220,41 +222,40 @@ __global__ __launch_bounds__(256) void k_pose_prep(PoseParams P, const float* __
     }
 }
 
-// One wave per block, one lane per hypothesis.  hbest[pair][h] = (best inlier count << 4) | first model with that
-// count, or -1 when the sample produced no model.  models[pair][h][m][9] receives every E (row-major).
-// A wave covers (64 / hc) frame pairs x hc consecutive hypotheses: the first launch uses hc = 16 (4 pairs per
-// wave: the adaptive stop usually ends within the first few samples, so 4x fewer 118-KB-LDS workgroups
-// compete with the detect kernels of the next batch), later chunks use hc = 64.
-// Later chunks (h >= 16) are only needed for the pairs whose adaptive bound is still above 16 after the
-// first scan: k_ransac_scan appends those pairs to a work list and a SMALL fixed grid walks the list
-// (worklist != nullptr), so the common case "nothing left to do" costs a handful of workgroups instead of
-// thousands of 118-KB-LDS workgroups that exit immediately.
-// The hypothesis body is one (large) device function shared by two entry points: the direct grid used for
-// the first chunk and the work-list walker used for the later ones.
-__device__ __forceinline__ void ransac_hyp_body(const PoseParams& P, int h0, int hc, int h_end, int npairs, int bx, int by,
+// One wave per block, FOUR lanes per hypothesis (quad lane q = lane & 3, hypothesis slot hs = lane >> 2), 16 consecutive
+// hypotheses of ONE frame pair per wave.  Every matrix element is produced by exactly the operation sequence of
+// oracle/pose.cpp five_point() -- the quad only decides WHICH lane runs a sequence:
+//   Householder QR of the 9 x 5 epipolar system     replicated in the four lanes (registers, ~600 flops)
+//   null-space basis vector j                         lane q = j
+//   constraint row 0 (det E)                          lane 0;      rows 1 + 3 i + j (j = 0..2)    lane q = i + 1
+//   Gauss-Jordan, partial pivoting                    every lane reads column `col` (pivot search + the 10 multipliers), lane q
+//                                                     updates the columns c = q (mod 4) of all rows
+//   B(z), det B(z) (degree 10), record header         lane 0;      the 36 basis doubles of the record    lanes 1..3
+// hypothesis record layout and everything downstream (k_hyp_roots, k_hyp_score) are unchanged.
+// The first launch covers hypotheses [0, first) of every pair (grid.y = pair); later chunks run only for the pairs the
+// first scan put on the device work list: a fixed grid walks (pair, 16-hypothesis chunk) items.
+__device__ __forceinline__ void ransac_hyp_quad(const PoseParams& P, int pair_raw, int hbase, int h_end, int npairs,
                                              const double* __restrict__ n1, const double* __restrict__ n2,
                                              const int32_t* __restrict__ samples, const int32_t* __restrict__ rstate,
                                              double* __restrict__ hyp, size_t S,
                                              double* ldsM, double* ldsB) {
-    const int lane = threadIdx.x;
-    const int ppb = 64 / hc;                                       // pairs per block
-    const int pair_raw = by * ppb + lane / hc;
+    const int lane = threadIdx.x, hs = lane >> 2, q = lane & 3;
     const int pair = min(pair_raw, npairs - 1);
-    const int h = h0 + bx * hc + (lane % hc);
+    const int h = hbase + hs;
     const int32_t* rs = rstate + (size_t)pair * RS;
-    const int niters = rs[0], M = rs[6];
+    const int niters = rs[0];
     const bool active = pair_raw < npairs && h < niters && h < h_end && h < max(P.max_iters, 1);
     if (!__any(active)) return;                                    // adaptive stop already below this wave
     const double* pa = n1 + (size_t)pair * P.mcap * 2;
     const double* pb = n2 + (size_t)pair * P.mcap * 2;
-    const int hh = active ? h : 0;                                 // inactive lanes redo hypothesis 0 (results dropped)
+    const int hh = active ? h : 0;                                 // inactive quads redo hypothesis 0 (results dropped)
     const int32_t* sm = samples + ((size_t)pair * P.max_iters + hh) * 5;
     // ---- epipolar system A = Q^T (9 x 5)
     double A[9][5];
 #pragma unroll
     for (int i = 0; i < 5; i++) {
         // inactive lanes (their pair has no work, e.g. M < 5 or the adaptive bound is already reached) share the
-        // wave with active pairs: they must not touch the (possibly never written) sample table
+        // wave with active ones: they must not touch the (possibly never written) sample table
         const int id = active ? sm[i] : 0;
         const double x1 = pa[2 * id], y1 = pa[2 * id + 1], x2 = pb[2 * id], y2 = pb[2 * id + 1];
         A[0][i] = x2 * x1; A[1][i] = x2 * y1; A[2][i] = x2;
@@ -295,13 +296,11 @@ __device__ __forceinline__ void ransac_hyp_body(const PoseParams& P, int h0, int
         }
         betas[k] = beta;
     }
-    // ---- null-space basis X,Y,Z,W = columns 5..8 of H0..H4 -> LDS
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
+    // ---- null-space basis X,Y,Z,W = columns 5..8 of H0..H4 -> LDS: lane q builds vector j = q
+    {
         double e[9];
 #pragma unroll
-        for (int i = 0; i < 9; i++) e[i] = 0;
-        e[5 + j] = 1.0;
+        for (int i = 0; i < 9; i++) e[i] = (i == 5 + q) ? 1.0 : 0.0;
 #pragma unroll
         for (int k = 4; k >= 0; k--) {
             double d = 0;
@@ -312,10 +311,11 @@ __device__ __forceinline__ void ransac_hyp_body(const PoseParams& P, int h0, int
             for (int i = k; i < 9; i++) e[i] -= d * vs[k][i];
         }
 #pragma unroll
-        for (int i = 0; i < 9; i++) LB(j, i) = e[i];
+        for (int i = 0; i < 9; i++) LB(q, i) = e[i];
     }
-    // ---- constraint rows -> LDS.  row 0: det(E)
-    {
+    HYP_SYNC();
+    // ---- constraint rows -> LDS.  row 0: det(E), lane 0
+    if (q == 0) {
         double row[20];
 #pragma unroll
         for (int c = 0; c < 20; c++) row[c] = 0;
@@ -323,79 +323,107 @@ __device__ __forceinline__ void ransac_hyp_body(const PoseParams& P, int h0, int
         constexpr double sg[3] = {1.0, -1.0, 1.0};
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            double q[10], q2[10], l1[4], l2[4];
+            double qq[10], q2[10], l1[4], l2[4];
 #pragma unroll
-            for (int i = 0; i < 10; i++) { q[i] = 0; q2[i] = 0; }
-            load_El(ldsB, lane, 1, tb[k], l1); load_El(ldsB, lane, 2, tc[k], l2); mul_ll_u(l1, l2, q);
-            load_El(ldsB, lane, 1, td[k], l1); load_El(ldsB, lane, 2, te[k], l2); mul_ll_u(l1, l2, q2);
+            for (int i = 0; i < 10; i++) { qq[i] = 0; q2[i] = 0; }
+            load_El(ldsB, hs, 1, tb[k], l1); load_El(ldsB, hs, 2, tc[k], l2); mul_ll_u(l1, l2, qq);
+            load_El(ldsB, hs, 1, td[k], l1); load_El(ldsB, hs, 2, te[k], l2); mul_ll_u(l1, l2, q2);
 #pragma unroll
-            for (int i = 0; i < 10; i++) q[i] -= q2[i];
-            load_El(ldsB, lane, 0, ta[k], l1);
-            mul_ql_u(q, l1, row, sg[k]);
+            for (int i = 0; i < 10; i++) qq[i] -= q2[i];
+            load_El(ldsB, hs, 0, ta[k], l1);
+            mul_ql_u(qq, l1, row, sg[k]);
         }
 #pragma unroll
         for (int c = 0; c < 20; c++) LM(0, c) = row[c];
-    }
-    // rows 1..9: (E E^T - 0.5 tr(E E^T) I) E
-    {
+    } else {
+        // rows 1 + 3 i + j: (E E^T - 0.5 tr(E E^T) I) E, lane q owns i = q - 1 (all index arithmetic on i goes through LDS)
+        const int i = q - 1;
         double tr[10];
         {
             double dg[3][10];
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
+            for (int ii = 0; ii < 3; ii++) {
 #pragma unroll
-                for (int m = 0; m < 10; m++) dg[i][m] = 0;
+                for (int m = 0; m < 10; m++) dg[ii][m] = 0;
 #pragma unroll
-                for (int k = 0; k < 3; k++) { double l1[4]; load_El(ldsB, lane, i, k, l1); mul_ll_u(l1, l1, dg[i]); }
+                for (int k = 0; k < 3; k++) { double l1[4]; load_El(ldsB, hs, ii, k, l1); mul_ll_u(l1, l1, dg[ii]); }
             }
 #pragma unroll
             for (int m = 0; m < 10; m++) tr[m] = 0.5 * ((dg[0][m] + dg[1][m]) + dg[2][m]);
         }
+        double EEt[3][10];
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-            double EEt[3][10];
+        for (int j = 0; j < 3; j++) {
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
+            for (int m = 0; m < 10; m++) EEt[j][m] = 0;
 #pragma unroll
-                for (int m = 0; m < 10; m++) EEt[j][m] = 0;
+            for (int k = 0; k < 3; k++) { double l1[4], l2[4]; load_El(ldsB, hs, i, k, l1); load_El(ldsB, hs, j, k, l2); mul_ll_u(l1, l2, EEt[j]); }
+        }
 #pragma unroll
-                for (int k = 0; k < 3; k++) { double l1[4], l2[4]; load_El(ldsB, lane, i, k, l1); load_El(ldsB, lane, j, k, l2); mul_ll_u(l1, l2, EEt[j]); }
-            }
+        for (int j = 0; j < 3; j++)
 #pragma unroll
-            for (int m = 0; m < 10; m++) EEt[i][m] -= tr[m];
+            for (int m = 0; m < 10; m++) EEt[j][m] = (j == i) ? EEt[j][m] - tr[m] : EEt[j][m];
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                double row[20];
+        for (int j = 0; j < 3; j++) {
+            double row[20];
 #pragma unroll
-                for (int c = 0; c < 20; c++) row[c] = 0;
+            for (int c = 0; c < 20; c++) row[c] = 0;
 #pragma unroll
-                for (int k = 0; k < 3; k++) { double l1[4]; load_El(ldsB, lane, k, j, l1); mul_ql_u(EEt[k], l1, row, 1.0); }
+            for (int k = 0; k < 3; k++) { double l1[4]; load_El(ldsB, hs, k, j, l1); mul_ql_u(EEt[k], l1, row, 1.0); }
 #pragma unroll
-                for (int c = 0; c < 20; c++) LM(1 + 3 * i + j, c) = row[c];
-            }
+            for (int c = 0; c < 20; c++) LM(1 + 3 * i + j, c) = row[c];
         }
     }
-    // ---- Gauss-Jordan with partial pivoting on the left 10 x 10 block (rows live in LDS, pivot row in registers)
+    HYP_SYNC();
+    // ---- Gauss-Jordan with partial pivoting on the left 10 x 10 block.  Per step every lane reads column `col` (the pivot
+    // search and the multipliers of all rows, taken BEFORE anything of this step is written), then updates its own columns.
     bool ok = true;
 #pragma unroll
     for (int col = 0; col < 10; col++) {
-        int piv = col; double best = fabs(LM(col, col));
-        for (int r = col + 1; r < 10; r++) { const double v = fabs(LM(r, col)); if (v > best) { best = v; piv = r; } }
+        double v[10];
+#pragma unroll
+        for (int r = 0; r < 10; r++) v[r] = LM(r, col);
+        int piv = col; double best = fabs(v[col]);
+#pragma unroll
+        for (int r = col + 1; r < 10; r++) { const double a = fabs(v[r]); if (a > best) { best = a; piv = r; } }
         if (best < 1e-300) ok = false;
-        double prow[20];
+        const double pv = v[col];                                  // after the row exchange row `piv` holds the old row `col`
+        double vp = v[col];
 #pragma unroll
-        for (int c = col; c < 20; c++) { prow[c] = LM(piv, c); const double t = LM(col, c); LM(piv, c) = t; }
-        const double inv = 1.0 / prow[col];
+        for (int r = col + 1; r < 10; r++) vp = (r == piv) ? v[r] : vp;
+        const double inv = 1.0 / vp;                               // prow[col] = old M[piv][col]
+        HYP_SYNC();
 #pragma unroll
-        for (int c = col; c < 20; c++) { prow[c] *= inv; LM(col, c) = prow[c]; }
-        for (int r = 0; r < 10; r++) {
-            if (r == col) continue;
-            const double f = LM(r, col);
-            if (f == 0.0) continue;
+        for (int cc = 0; cc < 5; cc++) {
+            const int c = 4 * cc + q;
+            if (c >= col) {
+                double pr = LM(piv, c);
+                const double t = LM(col, c);
+                LM(piv, c) = t;
+                pr *= inv;
+                LM(col, c) = pr;
 #pragma unroll
-            for (int c = col; c < 20; c++) LM(r, c) -= f * prow[c];
+                for (int r = 0; r < 10; r++) {
+                    if (r == col) continue;
+                    const double f = (r == piv) ? pv : v[r];
+                    if (f != 0.0) LM(r, c) -= f * pr;
+                }
+            }
+        }
+        HYP_SYNC();
+    }
+    // ---- the record's 36 null-space doubles: lanes 1..3, 12 each (element-major, slot-minor: a quad lane's 16 hypotheses are
+    // 16 consecutive slots)
+    const size_t slot = (size_t)pair * P.max_iters + (active ? h : 0);
+    if (active && q != 0) {
+        double* rec = hyp + slot;
+#pragma unroll
+        for (int e = 0; e < 12; e++) {
+            const int idx = (q - 1) * 12 + e;                      // j * 9 + i
+            rec[(size_t)(HR_LB + idx) * S] = ldsB[idx * QH + hs];
         }
     }
+    if (q == 0) {
     // ---- B(z) from rows (4,5),(6,7),(8,9)
     double Bx[3][4], By[3][4], B1[3][5];
 #pragma unroll
@@ -436,9 +464,8 @@ __device__ __forceinline__ void ransac_hyp_body(const PoseParams& P, int h0, int
         for (int i = 0; i <= 10; i++) c10[i] += o[i];
 #undef PMUL
     }
-    // ---- hypothesis record -> global memory (element-major, slot-minor: lanes = consecutive slots)
+    // ---- hypothesis record -> global memory (element-major, slot-minor)
     if (active) {
-        const size_t slot = (size_t)pair * P.max_iters + h;
         double* rec = hyp + slot;
         double mx = 0;
 #pragma unroll
@@ -457,28 +484,26 @@ __device__ __forceinline__ void ransac_hyp_body(const PoseParams& P, int h0, int
 #pragma unroll
             for (int k = 0; k < 5; k++) rec[(size_t)(HR_B1 + 5 * i + k) * S] = B1[i][k];
         }
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int i = 0; i < 9; i++) rec[(size_t)(HR_LB + 9 * j + i) * S] = LB(j, i);
         reinterpret_cast<int32_t*>(hyp + (size_t)HR_DOUBLES * S)[slot] = flag;
+    }
     }
     HYP_SYNC();                                                   // k_ransac_hyp_list re-enters with the same LDS
 }
 
-__global__ __launch_bounds__(64) void k_ransac_hyp(PoseParams P, int h0, int hc, int h_end, int npairs,
+// first chunk: grid (ceil(first / 16), npairs)
+__global__ __launch_bounds__(64) void k_ransac_hyp(PoseParams P, int h0, int h_end, int npairs,
                                                    const double* __restrict__ n1, const double* __restrict__ n2,
                                                    const int32_t* __restrict__ samples, const int32_t* __restrict__ rstate,
                                                    double* __restrict__ hyp, size_t S) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* ldsM = reinterpret_cast<double*>(smem);
-    ransac_hyp_body(P, h0, hc, h_end, npairs, blockIdx.x, blockIdx.y, n1, n2, samples, rstate, hyp, S, ldsM, ldsM + 200 * 64);
+    ransac_hyp_quad(P, blockIdx.y, h0 + blockIdx.x * QH, h_end, npairs, n1, n2, samples, rstate, hyp, S, ldsM, ldsM + 200 * QH);
 }
 
-// Later chunks (h >= 16) are only needed for the pairs whose adaptive bound is still above 16 after the
-// first scan: k_ransac_scan appends those pairs to a work list and a SMALL fixed grid walks the list, so
-// the common case "nothing left to do" costs a handful of workgroups instead of thousands of 118-KB-LDS
-// workgroups that exit immediately.
+// Later chunks (h >= first) are only needed for the pairs whose adaptive bound is still above `first` after the first scan:
+// k_ransac_scan appends those pairs to a work list and a fixed grid walks (pair, 16-hypothesis chunk) items, so the common
+// case "nothing left to do" costs a handful of workgroups that exit immediately.  chunks = 64-hypothesis chunks per pair
+// (the unit of the roots / score kernels' sub-items): four 16-hypothesis items each.
 __global__ __launch_bounds__(64) void k_ransac_hyp_list(PoseParams P, int h0, int h_end, int npairs,
                                                         const double* __restrict__ n1, const double* __restrict__ n2,
                                                         const int32_t* __restrict__ samples, const int32_t* __restrict__ rstate,
@@ -486,10 +511,11 @@ __global__ __launch_bounds__(64) void k_ransac_hyp_list(PoseParams P, int h0, in
                                                         const int32_t* __restrict__ worklist, int chunks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* ldsM = reinterpret_cast<double*>(smem);
-    const int total = worklist[0] * chunks;
+    const int per_pair = chunks * (64 / QH);
+    const int total = worklist[0] * per_pair;
     for (int wi = blockIdx.x; wi < total; wi += gridDim.x)
-        ransac_hyp_body(P, h0, 64, h_end, npairs, wi % chunks, worklist[1 + wi / chunks], n1, n2, samples, rstate, hyp, S,
-                        ldsM, ldsM + 200 * 64);
+        ransac_hyp_quad(P, worklist[1 + wi / per_pair], h0 + (wi % per_pair) * QH, h_end, npairs, n1, n2, samples, rstate, hyp, S,
+                        ldsM, ldsM + 200 * QH);
 }
 
 // ---- sub-items: 16 consecutive hypotheses of one pair.  First chunk (worklist == nullptr): sub = pair, h in [0, 16).
@@ -1139,10 +1165,9 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
         const bool roots16 = false;
 #endif
         const int first = std::min(ctx->p.ransac_adaptive ? first_chunk : 16, std::max(max_iters, 1));
-        const int hc = first <= 4 ? 4 : (first <= 8 ? 8 : 16), ppb = 64 / hc;
         const size_t S = (size_t)npairs * max_iters;
         HIPCHK(ctx, hipMemsetAsync(d_worklist, 0, sizeof(int32_t), st));
-        hipLaunchKernelGGL(k_ransac_hyp, dim3(1, (npairs + ppb - 1) / ppb), dim3(64), HYP_LDS_BYTES, st, P, 0, hc, first, npairs, d_n1, d_n2,
+        hipLaunchKernelGGL(k_ransac_hyp, dim3((first + QH - 1) / QH, npairs), dim3(64), HYP_LDS_BYTES, st, P, 0, first, npairs, d_n1, d_n2,
                            d_samples, d_rstate, d_hyp, S);
         hipLaunchKernelGGL(k_hyp_roots, dim3(npairs), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_hyp, S, (const int32_t*)nullptr, 0, 0);
         hipLaunchKernelGGL(k_hyp_score, dim3(npairs), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_n1, d_n2, d_hyp, S, d_models,
@@ -1150,7 +1175,7 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
         hipLaunchKernelGGL(k_ransac_scan, dim3(npairs), dim3(64), 0, st, P, first, d_counts, d_rstate, d_worklist);
         if (max_iters > first) {
             const int chunks = (max_iters - first + 63) / 64;
-            const int nb = std::min(256, npairs * chunks);
+            const int nb = (int)std::min<long long>(256 * 10, (long long)npairs * chunks * (64 / QH));    // five 30-KB waves per CU, two rounds
             const int nsub = (int)std::min<long long>(2048, (long long)npairs * chunks * 4);
             hipLaunchKernelGGL(k_ransac_hyp_list, dim3(nb), dim3(64), HYP_LDS_BYTES, st, P, first, max_iters,
                                npairs, d_n1, d_n2, d_samples, d_rstate, d_hyp, S, (const int32_t*)d_worklist, chunks);
