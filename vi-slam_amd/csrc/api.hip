@@ -86,7 +86,10 @@ extern "C" int vis_create(int device, vis_ctx** out) {
         hipEventCreateWithFlags(&ctx->ev_detect_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_match_start, hipEventDefault) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_match_done[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_match_done[1], hipEventDisableTiming) != hipSuccess) { delete ctx; return VIS_E_HIP; }
+        hipEventCreateWithFlags(&ctx->ev_match_done[1], hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithPriority(&ctx->update_stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_update_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_update_done, hipEventDisableTiming) != hipSuccess) { delete ctx; return VIS_E_HIP; }
     ctx->ev_ok = true;
     for (int i = 0; i < 12; i++) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) ctx->ev_ok = false;
     *out = ctx;
@@ -112,6 +115,9 @@ extern "C" void vis_destroy(vis_ctx* ctx) {
     if (ctx->ev_detect_done) (void)hipEventDestroy(ctx->ev_detect_done);
     if (ctx->ev_match_start) (void)hipEventDestroy(ctx->ev_match_start);
     for (int i = 0; i < 2; i++) if (ctx->ev_match_done[i]) (void)hipEventDestroy(ctx->ev_match_done[i]);
+    if (ctx->update_stream) { (void)hipStreamSynchronize(ctx->update_stream); (void)hipStreamDestroy(ctx->update_stream); }
+    if (ctx->ev_update_fork) (void)hipEventDestroy(ctx->ev_update_fork);
+    if (ctx->ev_update_done) (void)hipEventDestroy(ctx->ev_update_done);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -820,21 +826,33 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
             have_prev = true;
         }
     }
-    // Camera::Update (src/Camera.cpp:63-72) at the head of the detect chain: the half pyramid of every frame of the batch
+    // Camera::Update (src/Camera.cpp:63-72): the half pyramid of every frame of the batch.  Nothing of the detect chain reads it
+    // and it is pure streaming work, so it runs on a stream of its own beside the (vector-ALU bound) detect kernels; the detect
+    // stream joins it at the end of its chain, so "the detect stream is done" still means "d_frames may be reused".
+    hipStream_t sU = ctx->update_stream;
     pl->half_valid = false;
+    bool update_queued = false;
     if (stages & VIS_STAGE_UPDATE) {
         VisRange r_("vis: Camera::Update half pyramid");
         if ((pl->w & 15) || (pl->h & 15)) { ctx->err = "VIS_STAGE_UPDATE: w, h must be multiples of 16"; return VIS_E_INVALID; }
         if (!pl->d_half) HIPCHK(ctx, hipMalloc((void**)&pl->d_half, (size_t)pl->B * vis_grad_frame_elems(pl->w, pl->h)));
-        if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[10], sA);
+        // the frames were produced on the detect stream (or before the call): order the side stream behind it
+        HIPCHK(ctx, hipEventRecord(ctx->ev_update_fork, sA));
+        HIPCHK(ctx, hipStreamWaitEvent(sU, ctx->ev_update_fork, 0));
+        if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[10], sU);
+        ctx->stream = sU;
         rc = launch_half_pyramid_batch(ctx, d_frames, pl->w, pl->h, pl->stride, (size_t)pl->stride * pl->h, n, pl->d_half);
+        ctx->stream = sA;
         if (rc) return rc;
-        if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[11], sA);
+        if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[11], sU);
+        HIPCHK(ctx, hipEventRecord(ctx->ev_update_done, sU));
+        update_queued = true;
         pl->half_valid = true;
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[0], sA);
     if (detect) { VisRange r_("vis: ORB detect + describe"); rc = launch_detect(ctx, pl, d_frames, n, base + 1); if (rc) return rc; }
     else if (ctx->ev_ok) for (int i = 1; i <= 4; i++) (void)hipEventRecord(ctx->ev[i], sA);
+    if (update_queued) HIPCHK(ctx, hipStreamWaitEvent(sA, ctx->ev_update_done, 0));
     HIPCHK(ctx, hipEventRecord(ctx->ev_detect_done, sA));
     if (stages & (VIS_STAGE_MATCH | VIS_STAGE_POSE)) HIPCHK(ctx, hipStreamWaitEvent(sM, ctx->ev_detect_done, 0));
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev_match_start, sM);
@@ -894,7 +912,7 @@ extern "C" int vis_batch_sync(vis_ctx* ctx) {
         ctx->tm.ms_update = 0;
         const bool upd = ctx->batch && ctx->batch->half_valid;
         if (upd && hipEventElapsedTime(&a, ctx->ev[10], ctx->ev[11]) == hipSuccess) ctx->tm.ms_update = a;
-        hipEvent_t e0 = upd ? ctx->ev[10] : ctx->ev[0];
+        hipEvent_t e0 = ctx->ev[0];
         if (hipEventElapsedTime(&a, e0, ctx->ev[8]) == hipSuccess) ctx->tm.ms_total = a;
         if (hipEventElapsedTime(&a, e0, ctx->ev[6]) == hipSuccess && a > ctx->tm.ms_total) ctx->tm.ms_total = a;
         if (had_pose && hipEventElapsedTime(&a, e0, ctx->ev_pose_done) == hipSuccess && a > ctx->tm.ms_total) ctx->tm.ms_total = a;

@@ -101,6 +101,8 @@ struct vis_ctx {
     hipEvent_t ev_filter_done = nullptr, ev_pose_done = nullptr, ev_pose_start = nullptr;
     hipStream_t match_stream = nullptr;      // knn + filters of batch i overlap the detect chain of batch i+1
     hipEvent_t ev_detect_done = nullptr, ev_match_start = nullptr, ev_match_done[2] = {nullptr, nullptr};
+    hipStream_t update_stream = nullptr;     // VIS_STAGE_UPDATE (Camera::Update): streaming work beside the VALU-bound detect chain
+    hipEvent_t ev_update_fork = nullptr, ev_update_done = nullptr;
     bool pose_pending = false;
     bool pose_attr_set = false;              // > 64 KiB LDS opt-in of the RANSAC solver kernels done on this context's device
     hipEvent_t ev_results_done = nullptr; bool results_pending = false;   // D2H of the last batch's results (vis_batch_results_async)
