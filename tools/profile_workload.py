@@ -34,7 +34,7 @@ cal_dst = torch.empty_like(cal_src)
 for i in range(STEPS):
     junk.fill_(i)
     torch.cuda.synchronize()
-    ctx.batch_run(d.data_ptr(), B)
+    ctx.batch_run(d.data_ptr(), B, vislam.STAGE_FRAME)
     ctx.batch_sync()
 junk.fill_(7)
 torch.cuda.synchronize()
