@@ -109,22 +109,19 @@ def test_headline_geometry_on_corner_dense_images(vislam, orc, ctx, kind):
     assert len(k) >= 900
 
 
-def test_headline_geometry_saturated_ties_are_reported(vislam, orc, ctx):
-    """isolated 0 / 255 pixels on a flat background: 8119 IDENTICAL FAST scores at the retainBest(2 * quota) cut of level 0, all
-    of which KeyPointsFilter::retainBest (and the oracle) pass on to the Harris stage, which then keeps its quota of 217.  8119
-    survivors are beyond the LDS sort a plan is sized for (2.5 * quota + 256 -> 1024 entries): the device
-    path fails with VIS_E_CAPACITY, it never returns a silently cut set"""
+@pytest.mark.parametrize("density", [0.08, 0.3])
+def test_headline_geometry_saturated_ties(vislam, orc, ctx, density):
+    """isolated 0 / 255 pixels on a flat background: thousands of IDENTICAL FAST scores at the retainBest(2 * quota) cut (8119 on
+    level 0 at 8 % density), all of which KeyPointsFilter::retainBest -- and the oracle -- hand to the Harris stage, which then
+    keeps its quota.  Far beyond the LDS sort a plan is sized for (2.5 * quota + 256 -> 1024 entries): k_select then works
+    through the survivors in windows (select_body.inc) and still returns exactly the oracle's keypoints"""
     rng = np.random.default_rng(17)
     rng.integers(0, 256, (480, 752), dtype=np.uint8)               # (same stream position as the CPU-side analysis in DESIGN.md)
-    img = np.where(rng.random((480, 752)) < 0.08, rng.integers(0, 2, (480, 752)) * 255, 128).astype(np.uint8)
+    img = np.where(rng.random((480, 752)) < density, rng.integers(0, 2, (480, 752)) * 255, 128).astype(np.uint8)
     p = vislam.default_params()
     p.nfeatures, p.nlevels, p.w_size, p.h_size = 1000, 8, 752, 480
-    ok, od = orc.orb_detect_compute(p, img, cap=40000)
-    assert (ok["octave"] == 0).sum() == 217                        # the oracle handles it: the Harris cut brings level 0 back to its quota
-    ctx.set_params(p)
-    with pytest.raises(vislam.VisError) as ei:
-        ctx.orb_detect_compute(img, slot=0, cap=40000)
-    assert ei.value.code == -4
+    k, d = _check(vislam, orc, ctx, p, img, cap=40000)
+    assert (k["octave"] == 0).sum() >= 217
 
 
 def test_context_reuse_and_param_changes(vislam, orc, ctx, canvas):
