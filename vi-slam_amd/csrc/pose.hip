@@ -882,6 +882,37 @@ __global__ __launch_bounds__(256) void k_hyp_score(PoseParams P, int h0, int h_e
                 sX2[i] = pb[2 * (c0 + i)]; sY2[i] = pb[2 * (c0 + i) + 1];
             }
             __syncthreads();
+            if (M <= 256) {
+                // Few correspondences (the reference pipeline: <= root^2 = 49 grid matches): LANE = model, the wave walks over its
+                // quarter of the points, whose coordinates are LDS broadcasts.  A wave-per-model pass would leave a third of the
+                // lanes idle at M = 43 and pay a wave reduction per model; here the only reduction is one LDS add per lane.
+                const int q0 = (mc * wv) >> 2, q1 = (mc * (wv + 1)) >> 2;          // this wave's points
+                for (int t0 = 0; t0 < T; t0 += 64) {
+                    const int t = t0 + lane;
+                    const int tc = min(t, T - 1);
+                    double Em[9];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) Em[k] = sE[tc][k];
+                    int good = 0;
+                    for (int i = q0; i < q1; i++) {
+                        const double x1 = sX1[i], y1 = sY1[i], x2 = sX2[i], y2 = sY2[i];
+                        const double Ex0 = (Em[0] * x1 + Em[1] * y1) + Em[2];
+                        const double Ex1 = (Em[3] * x1 + Em[4] * y1) + Em[5];
+                        const double Ex2 = (Em[6] * x1 + Em[7] * y1) + Em[8];
+                        const double Et0 = (Em[0] * x2 + Em[3] * y2) + Em[6];
+                        const double Et1 = (Em[1] * x2 + Em[4] * y2) + Em[7];
+                        const double x2tEx1 = (x2 * Ex0 + y2 * Ex1) + Ex2;
+                        const double a = Ex0 * Ex0, b = Ex1 * Ex1, c = Et0 * Et0, d = Et1 * Et1;
+                        const double num = x2tEx1 * x2tEx1, den = ((a + b) + c) + d;
+                        int in;
+                        if (den > 0 && num <= kLo * den) in = 1;
+                        else if (num >= kHi * den) in = 0;
+                        else in = (float)(num / den) <= thr2 ? 1 : 0;
+                        good += in;
+                    }
+                    if (t < T && good) atomicAdd(&sGood[t], good);
+                }
+            } else
             for (int t = wv; t < T; t += 4) {
                 double Em[9];
 #pragma unroll
