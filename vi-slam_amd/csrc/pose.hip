@@ -161,6 +161,9 @@ struct CvRng {
     unsigned long long state;
     DEV unsigned next() { state = (unsigned long long)(unsigned)state * 4164903690ULL + (unsigned)(state >> 32); return (unsigned)state; }
     DEV int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
+    // next() % m for a divisor that stays the same over thousands of draws: q = floor(x * ceil(2^64 / m) / 2^64) is the exact
+    // quotient for every 32-bit x (Lemire), so the remainder needs two multiplies instead of a hardware-less 32-bit division
+    DEV unsigned next_mod(unsigned m, unsigned long long magic) { const unsigned x = next(); return x - (unsigned)__umul64hi(magic, (unsigned long long)x) * m; }
 };
 
 struct PoseParams {
@@ -172,14 +175,16 @@ struct PoseParams {
 };
 
 // rstate: [0] niters, [1] maxGood, [2] best hypothesis index (-1 none), [3] best model, [4] next iteration to scan,
-//         [5] special (1 = M==5 shortcut, 2 = M<5), [6] M, [7] iterations run, [8] candidate models scored (all chunks)
+//         [5] special (1 = M==5 shortcut, 2 = M<5), [6] M, [7] iterations run, [8] candidate models scored (all chunks),
+//         [9..12] cheirality votes of the four (R, t) candidates, [14] finished workgroups (k_pose_final)
 #define RS VIS_RSTATE_WORDS
 
 // getSubset (ptsetreg.cpp): 5 distinct indices in [0,M), redraw on duplicates, from the running cv::RNG
 DEV void draw_subset(CvRng& rng, int M, int* idx) {
+    const unsigned long long magic = 0xFFFFFFFFFFFFFFFFull / (unsigned)M + 1ull;         // M >= 6 here
     for (int i = 0; i < 5; i++) {
         for (;;) {
-            const int v = idx[i] = rng.uniform(0, M);
+            const int v = idx[i] = (int)rng.next_mod((unsigned)M, magic);
             int j = 0;
             for (; j < i; j++) if (v == idx[j]) break;
             if (j == i) break;
@@ -204,6 +209,7 @@ __global__ __launch_bounds__(256) void k_pose_prep(PoseParams P, const float* __
     int32_t* sm = samples + (size_t)pair * P.max_iters * 5;
     if (tid == 0) {
         rs[1] = 0; rs[2] = -1; rs[3] = 0; rs[4] = 0; rs[6] = M; rs[7] = 0; rs[8] = 0;
+        for (int k = 9; k < 15; k++) rs[k] = 0;
         if (M < 5) { rs[0] = 0; rs[5] = 2; }
         else if (M == 5) { rs[0] = 1; rs[5] = 1; for (int k = 0; k < 5; k++) sm[k] = k; }
         else { rs[0] = max(P.max_iters, 1); rs[5] = 0; }
@@ -773,7 +779,7 @@ __global__ __launch_bounds__(256) void k_hyp_roots_lane(PoseParams P, int h0, in
 // models + scores of one sub-item (16 hypotheses of one pair): thread (hyp, root) back-substitutes its root, the
 // 256 threads then score every model of the sub-item against the pair's points (wave = model, lanes = points),
 // and thread hyp picks the first model with the largest count.  hbest[pair][h] = (best count << 4) | model, -1 = none.
-#define SC_CH 1024                                                 // points staged in LDS per pass
+#define SC_CH 512                                                  // points staged in LDS per pass
 // rstate is read (words 0, 6) AND written (word 8, the models-scored counter) here: a plain pointer, no const / __restrict__ promise
 __global__ __launch_bounds__(256) void k_hyp_score(PoseParams P, int h0, int h_end, int npairs, int32_t* rstate,
                                                    const double* __restrict__ n1, const double* __restrict__ n2,
@@ -1057,15 +1063,19 @@ __device__ bool cheirality(const double* R, const double* t, double x1, double y
     return ok;
 }
 
-// block per pair: winner's inlier mask + recoverPose.  do_pose = 0 -> only the mask / E (findEssentialMat)
+// winner's inlier mask + recoverPose.  do_pose = 0 -> only the mask / E (findEssentialMat).  grid (pairs, nsplit): the M Sampson
+// tests and the 4 M triangulations (a 4 x 4 Jacobi eigen-decomposition each) of a pair are dealt over nsplit workgroups -- with
+// thousands of correspondences per pair (BASELINE config 3: M ~ 3100, 32 pairs) one workgroup per pair left the chip idle for
+// 1.6 ms.  Votes and the inlier count are integers summed with atomics (order independent); the workgroup that finishes last
+// (ticket in rstate[14]) writes the pair's record.
 __global__ __launch_bounds__(256) void k_pose_final(PoseParams P, const double* __restrict__ n1, const double* __restrict__ n2,
-                                                    const double* __restrict__ models, const int32_t* __restrict__ rstate,
+                                                    const double* __restrict__ models, int32_t* rstate,
                                                     const double* __restrict__ E_in, uint8_t* __restrict__ mask_out,
                                                     PoseOut* __restrict__ out, int do_pose) {
     __shared__ double sE[9], sR[2][9], sT[3];
     __shared__ int sgood[4], sinl;
-    const int pair = blockIdx.x, tid = threadIdx.x;
-    const int32_t* rs = rstate + (size_t)pair * RS;
+    const int pair = blockIdx.x, tid = threadIdx.x, nsplit = gridDim.y, part = blockIdx.y;
+    int32_t* rs = rstate + (size_t)pair * RS;
     const int M = rs[6];
     const double* a = n1 + (size_t)pair * P.mcap * 2;
     const double* b = n2 + (size_t)pair * P.mcap * 2;
@@ -1076,14 +1086,14 @@ __global__ __launch_bounds__(256) void k_pose_final(PoseParams P, const double* 
     __syncthreads();
     const float t = (float)(P.thr * P.thr);
     if (!E_in) {
-        for (int i = tid; i < M; i += 256) {
+        for (int i = part * 256 + tid; i < M; i += 256 * nsplit) {
             int f = have ? sampson_inlier(sE, a[2 * i], a[2 * i + 1], b[2 * i], b[2 * i + 1], t) : 0;
             if (have && rs[5] == 1) f = 1;                         // M == 5: all-ones mask
             if (mask_out) mask_out[(size_t)pair * P.mcap + i] = (uint8_t)f;
             if (f) atomicAdd(&sinl, 1);
         }
     }
-    if (tid == 0 && do_pose && have) {
+    if (tid == 0 && do_pose && have) {                             // every workgroup of the pair derives the same four candidates
         double U[9], Vt[9]; svd3_decompose(sE, U, Vt);
         const double W[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1}, Wt[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1};
         double T[9];
@@ -1093,7 +1103,7 @@ __global__ __launch_bounds__(256) void k_pose_final(PoseParams P, const double* 
     }
     __syncthreads();
     if (do_pose && have) {
-        for (int w = tid; w < 4 * M; w += 256) {
+        for (int w = part * 256 + tid; w < 4 * M; w += 256 * nsplit) {
             const int c = w / M, i = w - c * M;
             const double tt[3] = {c < 2 ? sT[0] : -sT[0], c < 2 ? sT[1] : -sT[1], c < 2 ? sT[2] : -sT[2]};
             if (cheirality(sR[c & 1], tt, a[2 * i], a[2 * i + 1], b[2 * i], b[2 * i + 1])) atomicAdd(&sgood[c], 1);
@@ -1101,23 +1111,32 @@ __global__ __launch_bounds__(256) void k_pose_final(PoseParams P, const double* 
     }
     __syncthreads();
     if (tid == 0) {
-        PoseOut o;
-        for (int i = 0; i < 9; i++) { o.E[i] = sE[i]; o.R[i] = 0; }
-        o.t[0] = o.t[1] = o.t[2] = 0;
-        o.n_inliers = E_in ? 0 : (have ? (rs[5] == 1 ? 5 : rs[1]) : 0);
-        o.iters_run = rs[7]; o.n_points = M; o.n_pose_good = 0; o.n_models = rs[8]; o.reserved_ = 0;
-        if (do_pose && have) {
-            const int* g = sgood;
-            int sel;
-            if (g[0] >= g[1] && g[0] >= g[2] && g[0] >= g[3]) sel = 0;
-            else if (g[1] >= g[0] && g[1] >= g[2] && g[1] >= g[3]) sel = 1;
-            else if (g[2] >= g[0] && g[2] >= g[1] && g[2] >= g[3]) sel = 2;
-            else sel = 3;
-            for (int i = 0; i < 9; i++) o.R[i] = sR[sel & 1][i];
-            for (int i = 0; i < 3; i++) o.t[i] = sel < 2 ? sT[i] : -sT[i];
-            o.n_pose_good = g[sel];
+        int last = 1;
+        if (nsplit > 1) {
+            for (int c = 0; c < 4; c++) if (sgood[c]) atomicAdd(rs + 9 + c, sgood[c]);
+            __threadfence();                                       // the sums are visible before the ticket
+            last = atomicAdd(rs + 14, 1) == nsplit - 1;
+            if (last) { __threadfence(); for (int c = 0; c < 4; c++) sgood[c] = atomicAdd(rs + 9 + c, 0); }
         }
-        out[pair] = o;
+        if (last) {
+            PoseOut o;
+            for (int i = 0; i < 9; i++) { o.E[i] = sE[i]; o.R[i] = 0; }
+            o.t[0] = o.t[1] = o.t[2] = 0;
+            o.n_inliers = E_in ? 0 : (have ? (rs[5] == 1 ? 5 : rs[1]) : 0);
+            o.iters_run = rs[7]; o.n_points = M; o.n_pose_good = 0; o.n_models = rs[8]; o.reserved_ = 0;
+            if (do_pose && have) {
+                const int* g = sgood;
+                int sel;
+                if (g[0] >= g[1] && g[0] >= g[2] && g[0] >= g[3]) sel = 0;
+                else if (g[1] >= g[0] && g[1] >= g[2] && g[1] >= g[3]) sel = 1;
+                else if (g[2] >= g[0] && g[2] >= g[1] && g[2] >= g[3]) sel = 2;
+                else sel = 3;
+                for (int i = 0; i < 9; i++) o.R[i] = sR[sel & 1][i];
+                for (int i = 0; i < 3; i++) o.t[i] = sel < 2 ? sT[i] : -sT[i];
+                o.n_pose_good = g[sel];
+            }
+            out[pair] = o;
+        }
     }
 }
 
@@ -1225,7 +1244,8 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
             hipLaunchKernelGGL(k_ransac_scan, dim3(npairs), dim3(64), 0, st, P, max_iters, d_counts, d_rstate, (int32_t*)nullptr);
         }
     }
-    hipLaunchKernelGGL(k_pose_final, dim3(npairs), dim3(256), 0, st, P, d_n1, d_n2, d_models, d_rstate, d_E_in, d_mask, d_pose, do_pose);
+    const int nsplit = std::max(1, std::min(32, (4 * mcap + 4095) / 4096));       // ~16 triangulations per thread
+    hipLaunchKernelGGL(k_pose_final, dim3(npairs, nsplit), dim3(256), 0, st, P, d_n1, d_n2, d_models, d_rstate, d_E_in, d_mask, d_pose, do_pose);
     HIPCHK(ctx, hipGetLastError());
     return VIS_OK;
 }

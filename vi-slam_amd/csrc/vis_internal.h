@@ -174,6 +174,6 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
 int  vis_build_sample_table(vis_ctx* ctx, int max_m);
 int f2f_run(vis_ctx* ctx, const vis_keypoint* d_pts1, const vis_keypoint* d_pts2, int m, const float* d_rot,
             const int32_t* d_idx, int iters, double* d_nv, float* d_counts);
-#define VIS_RSTATE_WORDS 12
+#define VIS_RSTATE_WORDS 16
 
 #endif
