@@ -199,6 +199,17 @@ void fast_detect(const uint8_t* img, int w, int h, int stride, int threshold,
 }
 
 // ---- KeyPointsFilter::retainBest (A.1 item 5): keep every kp with response >= n-th best ---
+// What OpenCV 3.2 (features2d/keypoint.cpp) executes, for whoever can diff against a real build:
+//     if (n_points >= 0 && keypoints.size() > (size_t)n_points) {
+//         if (n_points == 0) { keypoints.clear(); return; }
+//         std::nth_element(keypoints.begin(), keypoints.begin() + n_points, keypoints.end(), KeypointResponseGreater());
+//         float ambiguous_response = keypoints[n_points - 1].response;          // an element of the UNSORTED top n
+//         new_end = std::partition(keypoints.begin() + n_points, keypoints.end(), KeypointResponseGreaterThanThreshold(ambiguous_response));   // >=
+//         keypoints.resize(new_end - keypoints.begin());
+//     }
+// keypoints[n-1] after nth_element is some member of the top n, not necessarily the smallest: with ties at the cut the kept set
+// (and its order) is libstdc++-defined.  SPEC of this restatement: cut = the true n-th best response, every tie at the cut is
+// kept (what OpenCV does whenever keypoints[n-1] carries the cut value, e.g. when the whole top n is tied), canonical order.
 static void retain_best(std::vector<RawKp>& k, int n) {
     if (n < 0 || (int)k.size() <= n) return;
     if (n == 0) { k.clear(); return; }
