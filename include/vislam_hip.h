@@ -333,6 +333,13 @@ typedef struct vis_pose_result {
  * vis_batch_sync() (or after waiting for an event recorded behind this call); a later vis_batch_results_async is
  * ordered behind this one on the device but does not make this one visible to the host by itself. */
 int  vis_batch_results_async(vis_ctx* ctx, vis_pose_result* h_pose, vis_dmatch* h_good, int32_t* h_ngood, int n_cap);
+/* Batched streams run FAST at a per-level threshold tau >= fast_threshold predicted from the previous batch: retainBest(2 * quota)
+ * only keeps corners whose score reaches a cut far above fast_threshold, and a corner below the cut can neither be kept nor
+ * suppress a kept one, so any tau <= cut gives the identical keypoints.  The prediction is verified per (frame, level) on the
+ * device and whatever it got wrong is redone at fast_threshold inside the same vis_batch_run: results never depend on it.
+ * tau_next (nlevels ints, may be NULL) = the thresholds the NEXT batch will start from; *n_redone = (frame, level) pairs the last
+ * batch had to redo.  Synchronises.  vis_batch_reset() forgets the prediction. */
+int  vis_batch_fast_thresholds(vis_ctx* ctx, int32_t* tau_next, int32_t* n_redone);
 /* device-side error/overflow flags of the last batch (0 = clean) */
 int  vis_batch_status(vis_ctx* ctx, int* flags);
 

@@ -120,6 +120,52 @@ def test_batch_update_stage_writes_the_half_pyramids(vislam, orc, canvas):
     c.close()
 
 
+def test_speculative_fast_threshold_is_exact(vislam, orc, canvas):
+    """batched streams run FAST at a per-level threshold predicted from the previous batch's retainBest cuts (detect.hip fast_tile);
+    k_select verifies it per (frame, level) and a device work list redoes what the prediction got wrong.  Batches chosen so that
+    the prediction is (1) absent, (2) far too high (noise -> stream: the fix-up path redoes everything), (3) right (stream ->
+    stream), (4) too high again (stream -> low contrast), (5) too low / harmless (low contrast -> noise): every frame of every batch
+    must equal the oracle's FAST-at-20 result bit for bit"""
+    import torch
+    p = _params(vislam)
+    c = vislam.Context(0, p)
+    rng = np.random.default_rng(5)
+    n = 4
+    stream = lambda t0: np.stack([vislam.synth_frame(canvas, t0 + t, 752, 480) for t in range(n)])      # noqa: E731
+    noise = rng.integers(0, 256, (n, 480, 752), dtype=np.uint8)
+    low = (stream(40).astype(np.int32) // 3 + 80).astype(np.uint8)                                           # a third of the contrast
+    batches = [stream(0), noise, stream(8), stream(12), low, noise, stream(16)]
+    c.batch_plan(752, 480, 752, n)
+    redone, taus = [], []
+    for bi, frames in enumerate(batches):
+        dev = torch.from_numpy(np.ascontiguousarray(frames)).cuda()
+        c.batch_run(dev.data_ptr(), n, vislam.STAGE_DETECT)
+        c.batch_sync()
+        assert c.batch_status() == 0, bi
+        tau, nr = c.batch_fast_thresholds()
+        redone.append(nr); taus.append(tau.copy())
+        for t in range(n):
+            k, d = c.batch_keypoints(t)
+            ok, od = orc.orb_detect_compute(p, frames[t])
+            _assert_same(k, d, ok, od)
+    # what the prediction machinery did: nothing to redo without a prediction (batch 0) or with a good one (stream -> stream),
+    # every (frame, level) redone when the previous batch promised far more (noise -> stream, stream -> low contrast)
+    assert redone[0] == 0 and redone[3] == 0, redone
+    assert redone[1] > 0 and redone[2] > 0 and redone[4] == n * 8, redone
+    assert (taus[2] > 40).all() and (taus[4] == 20).any(), taus          # after a stream batch / after a low-contrast batch
+    # a reset forgets the prediction (new stream): still exact
+    c.batch_reset()
+    assert (c.batch_fast_thresholds()[0] == 20).all()
+    dev = torch.from_numpy(low).cuda()
+    c.batch_run(dev.data_ptr(), n, vislam.STAGE_DETECT)
+    c.batch_sync()
+    for t in range(n):
+        k, d = c.batch_keypoints(t)
+        ok, od = orc.orb_detect_compute(p, low[t])
+        _assert_same(k, d, ok, od)
+    c.close()
+
+
 def test_batch_matches_single(vislam, orc, canvas):
     """batched device path == single-frame path == oracle, including the carried frame across batches"""
     import torch

@@ -223,7 +223,7 @@ void plan_destroy(Plan* pl) {
         F(pl->d_pyr[l]);
         F(pl->d_cand[l]); F(pl->d_seg_kp[l]);
     }
-    F(pl->d_fast_tiles); F(pl->d_tile_cnt); F(pl->d_seg_cnt); F(pl->d_flags); F(pl->d_angle_tab); F(pl->d_half);
+    F(pl->d_fast_tiles); F(pl->d_tile_cnt); F(pl->d_seg_cnt); F(pl->d_flags); F(pl->d_angle_tab); F(pl->d_half); F(pl->d_tau); F(pl->d_seg_cut); F(pl->d_fix);
     F(pl->d_kps); F(pl->d_desc); F(pl->d_nkp); F(pl->d_descx);
     for (int i = 0; i < 2; i++) { F(pl->d_pq[i]); F(pl->d_pt[i]); F(pl->d_pqn[i]); }
     F(pl->d_knn12); F(pl->d_knn21);
@@ -265,6 +265,13 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
     DALLOC(pl->d_tile_cnt, (size_t)B * pl->total_tiles); DALLOC(pl->d_seg_cnt, (size_t)B * L + VIS_MAX_LEVELS);   // + padding: k_describe reads VIS_MAX_LEVELS counts per frame
     if (pl->total_tiles > 65535) { plan_destroy(pl); return VIS_E_INVALID; }        // k_fast: gridDim.y
     { int rc2 = build_fast_tiles(ctx, pl); if (rc2) { plan_destroy(pl); return rc2; } }
+    if (nsets == 2) {                                              // batched stream plans predict the FAST threshold from batch to batch
+        pl->speculate = true;
+        DALLOC(pl->d_tau, L); DALLOC(pl->d_seg_cut, (size_t)B * L); DALLOC(pl->d_fix, (size_t)B * L + 1);
+        std::vector<int32_t> t0((size_t)L, ctx->p.fast_threshold);
+        HIPCHK(ctx, hipMemcpy(pl->d_tau, t0.data(), (size_t)L * 4, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemset(pl->d_fix, 0, ((size_t)B * L + 1) * 4));
+    }
     DALLOC(pl->d_flags, 4);
     HIPCHK(ctx, hipMemset(pl->d_flags, 0, 16));
     DALLOC(pl->d_kps, (size_t)nrec * kcap); DALLOC(pl->d_desc, (size_t)nrec * kcap * 32); DALLOC(pl->d_nkp, nrec);
@@ -795,6 +802,10 @@ extern "C" int vis_batch_reset(vis_ctx* ctx) {
     if (!ctx || !ctx->batch) return VIS_E_STATE;
     sync_all(ctx);
     ctx->batch->have_prev = false; ctx->batch->last_n = 0; ctx->batch->carry_from = 0; ctx->batch->pair0_valid = false;
+    if (ctx->batch->speculate) {                                   // a new stream: no prediction
+        std::vector<int32_t> t0((size_t)ctx->batch->L, ctx->p.fast_threshold);
+        HIPCHK(ctx, hipMemcpy(ctx->batch->d_tau, t0.data(), t0.size() * 4, hipMemcpyHostToDevice));
+    }
     return VIS_OK;
 }
 
@@ -944,6 +955,16 @@ extern "C" int vis_batch_results_async(vis_ctx* ctx, vis_pose_result* h_pose, vi
     if (h_ngood) HIPCHK(ctx, hipMemcpyAsync(h_ngood, pl->d_ngood, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipEventRecord(ctx->ev_results_done, s));
     ctx->results_pending = true;
+    return VIS_OK;
+}
+
+extern "C" int vis_batch_fast_thresholds(vis_ctx* ctx, int32_t* tau_next, int32_t* n_redone) {
+    if (!ctx || !ctx->batch) return VIS_E_STATE;
+    Plan* pl = ctx->batch;
+    sync_all(ctx);
+    if (!pl->speculate) { if (n_redone) *n_redone = 0; if (tau_next) for (int l = 0; l < pl->L; l++) tau_next[l] = ctx->p.fast_threshold; return VIS_OK; }
+    if (tau_next) HIPCHK(ctx, hipMemcpy(tau_next, pl->d_tau, (size_t)pl->L * 4, hipMemcpyDeviceToHost));
+    if (n_redone) HIPCHK(ctx, hipMemcpy(n_redone, pl->d_fix, 4, hipMemcpyDeviceToHost));
     return VIS_OK;
 }
 

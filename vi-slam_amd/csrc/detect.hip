@@ -290,7 +290,7 @@ __device__ __forceinline__ pk16 pretest_axis(pk16 c, pk16 n, pk16 so, pk16 e, pk
 
 // one record per FAST tile of the pyramid (all levels), built once per plan: everything a workgroup needs arrives with one
 // pair of scalar loads instead of a level search + two integer divisions in SALU code
-struct FastTile { const uint8_t* img; uint32_t* cand; uint32_t frame_bytes; int w, h, stride, ox, oy, ntiles, tile; };
+struct FastTile { const uint8_t* img; uint32_t* cand; uint32_t frame_bytes; int w, h, stride, ox, oy; uint32_t ntiles_tile; int level; };   // ntiles_tile = ntiles << 16 | tile
 static_assert(sizeof(FastTile) == 48, "FastTile is read as s_load_dwordx8 + x4");
 #define TILE_CAND_CAP (FT_W * FT_H / 4)     // 3x3 NMS bound per FT_W x FT_H tile: a tile's slot can never overflow
 
@@ -305,23 +305,26 @@ static_assert(sizeof(FastTile) == 48, "FastTile is read as s_load_dwordx8 + x4")
 #else
 #define FAST_STAMP(i) do { } while (0)
 #endif
-__global__ __launch_bounds__(256) void k_fast(const FastTile* __restrict__ tiles, const uint8_t* __restrict__ frames0, int total_tiles,
-                                              int threshold, int edge, int32_t* __restrict__ tile_cnt, int nframes,
-                                              unsigned long long* __restrict__ stamps) {
+// Speculative threshold (batched streams).  KeyPointsFilter::retainBest(2 * quota) keeps, per level, the corners whose score
+// reaches a cut that is far above the FAST threshold t (S-752: 61..82 against t = 20) and moves little from frame to frame.  A
+// corner below the cut is neither kept nor able to suppress a kept one in the 3x3 NMS (strict >), so FAST may run with ANY
+// threshold tau <= cut and give the identical keypoints -- while scoring a quarter of the candidates.  tau[level] is predicted from
+// the previous batch's cuts (k_tau_update: min over the frames - margin); k_select VERIFIES it per (frame, level): fewer than
+// 2 * quota candidates at tau > t means the prediction was too high there -> that (frame, level) goes on a device work list and is
+// redone at t by k_fast_fix / k_select_fix.  Exact for every input; only the speed depends on how coherent the stream is.
+__device__ __forceinline__ void fast_tile(const FastTile& V, const uint8_t* __restrict__ frames0, int total_tiles, int f, int gtile,
+                                          int threshold, int edge, int32_t* __restrict__ tile_cnt, unsigned long long* __restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) uint32_t px[PX_H * PX_W / 4];
     __shared__ __attribute__((aligned(16))) uint8_t sc[(SC_H * SC_S + 15) / 16 * 16];
     __shared__ uint16_t queue[SC_H * SC_W + 64];        // + one scratch word per lane (branch-free append)
     __shared__ int lcount, qn;
     const int tid = threadIdx.x;
-    const int f = blockIdx.z * 8 + blockIdx.x, gtile = blockIdx.y;
-    if (f >= nframes) return;
-    const FastTile V = tiles[gtile];
     const int ox = V.ox, oy = V.oy, w = V.w, h = V.h, stride = V.stride;
     // tiles that cannot emit (entirely inside the culled border) do nothing
     if (ox + FT_W <= edge || ox >= w - edge || oy + FT_H <= edge || oy >= h - edge) return;
     const uint8_t* base = (V.img ? V.img : frames0) + (size_t)f * V.frame_bytes;       // level 0 is the caller's batch
     // every tile owns a fixed slot of TILE_CAND_CAP candidates: no returning atomics, no cross-tile ordering
-    uint32_t* slot = V.cand + ((size_t)f * V.ntiles + V.tile) * TILE_CAND_CAP;
+    uint32_t* slot = V.cand + ((size_t)f * (V.ntiles_tile >> 16) + (V.ntiles_tile & 0xFFFFu)) * TILE_CAND_CAP;
     if (tid == 0) { lcount = 0; qn = 0; }
 #ifdef VIS_FAST_PROFILE
     unsigned long long tprev = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -504,6 +507,35 @@ __global__ __launch_bounds__(256) void k_fast(const FastTile* __restrict__ tiles
     if (tid == 0) tile_cnt[(size_t)f * total_tiles + gtile] = lcount;
 }
 
+__global__ __launch_bounds__(256) void k_fast(const FastTile* __restrict__ tiles, const uint8_t* __restrict__ frames0, int total_tiles,
+                                              int threshold, int edge, int32_t* __restrict__ tile_cnt, int nframes,
+                                              unsigned long long* __restrict__ stamps, const int32_t* __restrict__ tau) {
+    const int f = blockIdx.z * 8 + blockIdx.x, gtile = blockIdx.y;
+    if (f >= nframes) return;
+    const FastTile V = tiles[gtile];
+    fast_tile(V, frames0, total_tiles, f, gtile, tau ? tau[V.level] : threshold, edge, tile_cnt, stamps);
+}
+
+// work list: fix[0] = number of (frame, level) entries, fix[1 + i] = frame * L + level.  A small fixed grid walks
+// (entry, tile of that level) items; with an empty list (the normal case) every workgroup leaves at once.
+struct FixLevels { int tile_base[VIS_MAX_LEVELS], ntiles[VIS_MAX_LEVELS], L, max_tiles; };
+__global__ __launch_bounds__(256) void k_fast_fix(const FastTile* __restrict__ tiles, const uint8_t* __restrict__ frames0, int total_tiles,
+                                                  int threshold, int edge, int32_t* __restrict__ tile_cnt, FixLevels X,
+                                                  const int32_t* __restrict__ fix) {
+    const int items = fix[0] * X.max_tiles;
+    for (int wk = blockIdx.x; wk < items; wk += gridDim.x) {
+        const int e = fix[1 + wk / X.max_tiles], j = wk % X.max_tiles;
+        const int f = e / X.L, l = e - f * X.L;
+        if (j < X.ntiles[l]) {                                        // workgroup-uniform
+            const int gtile = X.tile_base[l] + j;
+            const FastTile V = tiles[gtile];
+            if (threadIdx.x == 0) tile_cnt[(size_t)f * total_tiles + gtile] = 0;      // tiles that cannot emit return without a count
+            fast_tile(V, frames0, total_tiles, f, gtile, threshold, edge, tile_cnt, nullptr);
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_select
 struct LevelArgs {
@@ -563,22 +595,52 @@ extern "C" int vis_debug_select_stamps(unsigned long long out[VIS_MAX_LEVELS * 8
     return hipMemcpyToSymbol(HIP_SYMBOL(g_sel_stamps), z, sizeof(z)) == hipSuccess ? VIS_OK : VIS_E_HIP;
 }
 #endif
+// tau / t_base / seg_cut / fix: the speculative threshold (fast_tile); tau == nullptr: plain FAST at t_base
+#define SEL_ARGS DetLevels D, const int32_t* __restrict__ tile_cnt, int total_tiles, int32_t* __restrict__ seg_cnt, \
+                 int32_t* __restrict__ flags, int max_surv, int nframes, const int32_t* __restrict__ tau, int t_base, \
+                 int32_t* __restrict__ seg_cut, int32_t* fix
 #define SEL_NT 256
-__global__ __launch_bounds__(256) void k_select(DetLevels D, const int32_t* __restrict__ tile_cnt, int total_tiles,
-                                                int32_t* __restrict__ seg_cnt,
-                                                int32_t* __restrict__ flags, int max_surv, int nframes) {
+__global__ __launch_bounds__(256) void k_select(SEL_ARGS) {
 #include "select_body.inc"
 }
 #undef SEL_NT
 // 1024 threads per (frame, level) when a level sorts thousands of survivors (N = 4000 / 8000): the LDS bitonic sort and the
 // gather loops are the critical path of a launch that has only frames x levels workgroups
 #define SEL_NT 1024
-__global__ __launch_bounds__(1024) void k_select_1024(DetLevels D, const int32_t* __restrict__ tile_cnt, int total_tiles,
-                                                int32_t* __restrict__ seg_cnt,
-                                                int32_t* __restrict__ flags, int max_surv, int nframes) {
+__global__ __launch_bounds__(1024) void k_select_1024(SEL_ARGS) {
 #include "select_body.inc"
 }
 #undef SEL_NT
+// the (frame, level) pairs whose predicted threshold was too high, after k_fast_fix redid their tiles at t
+#define SEL_FIX
+#define SEL_NT 256
+__global__ __launch_bounds__(256) void k_select_fix(SEL_ARGS) {
+#include "select_body.inc"
+}
+#undef SEL_NT
+#define SEL_NT 1024
+__global__ __launch_bounds__(1024) void k_select_fix_1024(SEL_ARGS) {
+#include "select_body.inc"
+}
+#undef SEL_NT
+#undef SEL_FIX
+
+// next batch's prediction: per level the smallest cut of this batch's frames minus a margin, never below t
+#define TAU_MARGIN 4
+__global__ __launch_bounds__(256) void k_tau_update(const int32_t* __restrict__ seg_cut, int L, int nframes, int t_base, int32_t* __restrict__ tau) {
+    __shared__ int smin[VIS_MAX_LEVELS];
+    const int tid = threadIdx.x;
+    if (tid < VIS_MAX_LEVELS) smin[tid] = 255;
+    __syncthreads();
+    for (int l = 0; l < L; l++) {
+        int m = 255;
+        for (int f = tid; f < nframes; f += 256) m = min(m, seg_cut[(size_t)f * L + l]);
+        for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
+        if ((tid & 63) == 0) atomicMin(&smin[l], m);
+    }
+    __syncthreads();
+    if (tid < L) tau[tid] = max(t_base, smin[tid] - TAU_MARGIN);
+}
 
 // ------------------------------------------------------------------------------------------------
 // k_describe: one wave per keypoint
@@ -950,7 +1012,8 @@ int build_fast_tiles(vis_ctx* ctx, Plan* pl) {
         for (int i = 0; i < V.tiles_x * V.tiles_y; i++) {
             FastTile& r = t[(size_t)V.tile_base + i];
             r.img = l == 0 ? nullptr : pl->d_pyr[l]; r.cand = pl->d_cand[l]; r.frame_bytes = (uint32_t)V.frame_bytes;
-            r.w = V.w; r.h = V.h; r.stride = V.stride; r.ntiles = V.tiles_x * V.tiles_y; r.tile = i;
+            r.w = V.w; r.h = V.h; r.stride = V.stride; r.ntiles_tile = ((uint32_t)(V.tiles_x * V.tiles_y) << 16) | (uint32_t)i; r.level = l;
+            if (V.tiles_x * V.tiles_y > 65535) return VIS_E_INVALID;
             // tile grid origin = (edge rounded down to 16, edge): see vis_compute_levels
             r.ox = (e & ~15) + (i % V.tiles_x) * FT_W; r.oy = e + (i / V.tiles_x) * FT_H;
         }
@@ -988,25 +1051,42 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
                                pl->d_pyr[l], V.w, V.h, V.stride, V.frame_bytes, scale_x, scale_y, bxc, per_frame, n);
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[1], st);
+    const int t_base = ctx->p.fast_threshold;
+    const int32_t* tau = pl->speculate ? pl->d_tau : nullptr;            // batched streams only (see fast_tile)
+    if (pl->speculate) HIPCHK(ctx, hipMemsetAsync(pl->d_fix, 0, sizeof(int32_t), st));
     {
         hipLaunchKernelGGL(k_fast, dim3(8, pl->total_tiles, (n + 7) / 8), dim3(256), 0, st, (const FastTile*)pl->d_fast_tiles, d_frames,
-                           pl->total_tiles, ctx->p.fast_threshold, ctx->p.edge_threshold, pl->d_tile_cnt, n, vis_fast_stamps());
+                           pl->total_tiles, t_base, ctx->p.edge_threshold, pl->d_tile_cnt, n, vis_fast_stamps(), tau);
         nfast = 1;
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[2], st);
     int max_surv = 0; for (int l = 0; l < L; l++) max_surv = std::max(max_surv, pl->lv[l].surv_cap);
     int max_nt = 0; for (int l = 0; l < L; l++) max_nt = std::max(max_nt, pl->lv[l].tiles_x * pl->lv[l].tiles_y);
     const size_t sel_lds = (size_t)max_surv * 8 + 16 + 1024 + ((size_t)max_nt + 2) * 4 + 1024;   // keys | flags | hist | tile prefix | suffix sums
-    if (max_surv > 1024) {   // large quotas: 1024 threads per (frame, level)
-        if (sel_lds > 65536)   // > 64 KiB of dynamic LDS needs the opt-in attribute (160 KiB per CU on gfx950)
-            HIPCHK(ctx, hipFuncSetAttribute((const void*)k_select_1024, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
-        hipLaunchKernelGGL(k_select_1024, dim3(xcd_grid(n, L)), dim3(1024), sel_lds, st, D, pl->d_tile_cnt, pl->total_tiles,
-                           pl->d_seg_cnt, pl->d_flags, max_surv, n);
-    } else {
-        if (sel_lds > 65536)
-            HIPCHK(ctx, hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
-        hipLaunchKernelGGL(k_select, dim3(xcd_grid(n, L)), dim3(256), sel_lds, st, D, pl->d_tile_cnt, pl->total_tiles,
-                           pl->d_seg_cnt, pl->d_flags, max_surv, n);
+    const bool big = max_surv > 1024;    // large quotas: 1024 threads per (frame, level)
+    if (sel_lds > 65536) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (160 KiB per CU on gfx950)
+        HIPCHK(ctx, hipFuncSetAttribute(big ? (const void*)k_select_1024 : (const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
+        if (pl->speculate)
+            HIPCHK(ctx, hipFuncSetAttribute(big ? (const void*)k_select_fix_1024 : (const void*)k_select_fix, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
+    }
+    int32_t* seg_cut = pl->speculate ? pl->d_seg_cut : nullptr;
+    int32_t* fix = pl->speculate ? pl->d_fix : nullptr;
+    if (big) hipLaunchKernelGGL(k_select_1024, dim3(xcd_grid(n, L)), dim3(1024), sel_lds, st, D, pl->d_tile_cnt, pl->total_tiles,
+                                pl->d_seg_cnt, pl->d_flags, max_surv, n, tau, t_base, seg_cut, fix);
+    else hipLaunchKernelGGL(k_select, dim3(xcd_grid(n, L)), dim3(256), sel_lds, st, D, pl->d_tile_cnt, pl->total_tiles,
+                            pl->d_seg_cnt, pl->d_flags, max_surv, n, tau, t_base, seg_cut, fix);
+    if (pl->speculate) {
+        // redo what the prediction got wrong (normally nothing: both grids find an empty list and leave), then predict the next batch
+        FixLevels X; X.L = L; X.max_tiles = max_nt;
+        for (int l = 0; l < VIS_MAX_LEVELS; l++) { X.tile_base[l] = l < L ? pl->lv[l].tile_base : 0; X.ntiles[l] = l < L ? pl->lv[l].tiles_x * pl->lv[l].tiles_y : 0; }
+        hipLaunchKernelGGL(k_fast_fix, dim3(2048), dim3(256), 0, st, (const FastTile*)pl->d_fast_tiles, d_frames, pl->total_tiles, t_base,
+                           ctx->p.edge_threshold, pl->d_tile_cnt, X, (const int32_t*)pl->d_fix);
+        const int fix_grid = std::min(n * L, 65535);
+        if (big) hipLaunchKernelGGL(k_select_fix_1024, dim3(fix_grid), dim3(1024), sel_lds, st, D, pl->d_tile_cnt, pl->total_tiles,
+                                    pl->d_seg_cnt, pl->d_flags, max_surv, n, tau, t_base, seg_cut, fix);
+        else hipLaunchKernelGGL(k_select_fix, dim3(fix_grid), dim3(256), sel_lds, st, D, pl->d_tile_cnt, pl->total_tiles,
+                                pl->d_seg_cnt, pl->d_flags, max_surv, n, tau, t_base, seg_cut, fix);
+        hipLaunchKernelGGL(k_tau_update, dim3(1), dim3(256), 0, st, (const int32_t*)pl->d_seg_cut, L, n, t_base, pl->d_tau);
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[3], st);
     // workgroups per frame: enough to fill the chip for small batches, a wave walks over many keypoints for large ones

@@ -51,6 +51,12 @@ struct Plan {
     float4*  d_seg_kp[VIS_MAX_LEVELS] = {};  // B x keep_cap (x, y, response, unused)
     int32_t* d_flags = nullptr;              // device error flags (1 word)
     uint32_t* d_angle_tab = nullptr;         // IC-angle byte weight/mask table for k_describe
+    // speculative FAST threshold of batched streams (detect.hip fast_tile): per-level prediction, per-(frame, level) cuts of the
+    // last batch, and the work list of the pairs whose prediction was too high
+    bool speculate = false;
+    int32_t* d_tau = nullptr;                // L
+    int32_t* d_seg_cut = nullptr;            // B x L
+    int32_t* d_fix = nullptr;                // 1 + B x L
     uint8_t* d_half = nullptr;               // VIS_STAGE_UPDATE: B x vis_grad_frame_elems(w, h) half pyramids (allocated on first use)
     bool half_valid = false;
     // records

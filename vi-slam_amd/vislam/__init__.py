@@ -114,7 +114,7 @@ ABI_SYMBOLS = [
     "vis_image_list", "vis_image_time", "vis_pgm_info", "vis_image_read",
     "vis_feeder_create", "vis_feeder_destroy", "vis_feeder_host_buffer", "vis_feeder_submit", "vis_feeder_release",
     "vis_default_align_params", "vis_estimate_pose_features", "vis_align_batch", "vis_batch_align",
-    "vis_synth_frame_parallax", "vis_synth_frames_device", "vis_batch_results_async", "vis_batch_half_pyramid",
+    "vis_synth_frame_parallax", "vis_synth_frames_device", "vis_batch_results_async", "vis_batch_half_pyramid", "vis_batch_fast_thresholds",
     "vis_se3_exp", "vis_se3_mul", "vis_se3_from_rt", "vis_se3_matrix",
 ]
 
@@ -182,6 +182,7 @@ def _load():
     lib.vis_synth_frames_device.argtypes = [vp, vp, ci, C.c_uint64, ci, ci, ci, ci, ci, ci, vp]
     lib.vis_batch_results_async.argtypes = [vp, vp, vp, vp, ci]
     lib.vis_batch_half_pyramid.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.vis_batch_fast_thresholds.argtypes = [vp, vp, C.POINTER(C.c_int32)]
     lib.vis_se3_exp.argtypes = [vp, C.POINTER(Se3f)]; lib.vis_se3_exp.restype = None
     lib.vis_se3_mul.argtypes = [C.POINTER(Se3f), C.POINTER(Se3f), C.POINTER(Se3f)]; lib.vis_se3_mul.restype = None
     lib.vis_se3_from_rt.argtypes = [vp, vp, C.POINTER(Se3f)]; lib.vis_se3_from_rt.restype = None
@@ -570,6 +571,13 @@ class Context:
         self.batch_results_async(n, pose.ctypes.data, good.ctypes.data, ng.ctypes.data)
         self.batch_sync()
         return pose, good, ng
+
+    def batch_fast_thresholds(self):
+        """(per-level FAST thresholds the next batch starts from, (frame, level) pairs the last batch had to redo)"""
+        tau = np.zeros(self.params.nlevels, np.int32)
+        nr = C.c_int32(0)
+        self._chk(lib.vis_batch_fast_thresholds(self._h, _ptr(tau), C.byref(nr)), "vis_batch_fast_thresholds")
+        return tau, nr.value
 
     def batch_status(self):
         f = C.c_int(0)
