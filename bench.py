@@ -262,6 +262,7 @@ def main():
     dt = vdist.max_over_ranks(dt, dist, dev)
 
     fam, launches_fast = family_times(ctx, step, 8)
+    tau_next, redone = ctx.batch_fast_thresholds()       # the speculative FAST thresholds (exact by construction; see include/vislam_hip.h)
     headline_pose = None
     if rank == 0 and (a.stages & vislam.STAGE_POSE):
         step(0); ctx.batch_sync()
@@ -489,7 +490,10 @@ def main():
                                    "crop under pure image translation: every grid match is an exact inlier, the adaptive stop ends RANSAC after "
                                    "<= 4 hypotheses (see pose_load) and the recovered pose is degenerate; legs.s752_fixed1000 / legs.s752_parallax load "
                                    "the pose kernels.  Results stay on the device inside the timed region (legs.s752_results_d2h adds the download); "
-                                   "Camera::Update's half pyramid (4 levels per frame) is part of the step, as it is of the CPU baseline",
+                                   "Camera::Update's half pyramid (4 levels per frame) is part of the step, as it is of the CPU baseline.  "
+                                   "FAST runs at a per-level threshold predicted from the previous batch's retainBest cuts (a corner below the cut "
+                                   "is neither kept nor able to suppress a kept one), verified per (frame, level) on the device, mispredictions redone "
+                                   "at fast_threshold inside the step: keypoints identical to FAST at 20 for every input (fast_threshold_prediction)",
                        "frames_per_step_per_gpu": B, "parallelism": f"stream-per-gpu x{world}" if world > 1 else "single-gpu"},
             # `bound` names the roofline `frac` is priced against (north_star asks for the HBM roofline of detect/describe);
             # `limited_by` is what the counters say actually limits this kernel (see valu_roofline / detect_kernels)
@@ -497,6 +501,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": per_launch_s * 1e3},
             "valu_roofline": valu,
+            "fast_threshold_prediction": {"tau_next_per_level": [int(x) for x in tau_next], "fast_threshold": int(p.fast_threshold),
+                                          "frame_level_pairs_redone_in_the_last_step": int(redone),
+                                          "what": "thresholds the next batch's k_fast starts from (min over the last batch's frames of the "
+                                                  "retainBest(2*quota) cut per level, minus 4); 0 pairs redone = every prediction of the last step held"},
             "detect_kernels": detect_kernels,
             "pose_load": headline_pose,
             "aux_kernels": aux,

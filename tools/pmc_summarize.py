@@ -11,14 +11,23 @@ from collections import defaultdict
 out_dir, B = sys.argv[1], int(sys.argv[2])
 commit = sys.argv[3] if len(sys.argv) > 3 else None      # the build the counters were taken on (stamp it)
 peak_log = sys.argv[4] if len(sys.argv) > 4 else None    # stdout of lib/valu_peak run in the same lease (its last line is JSON)
+# the workload runs WARM untimed steps before its measured ones (tools/profile_workload.py: the FAST threshold prediction starts
+# with the second batch of a stream): the first warm / (warm + steps) of every kernel's dispatches are dropped
+warm = int(os.environ.get("VIS_PROFILE_WARM", "2"))
+steps = int(os.environ.get("VIS_PROFILE_STEPS", "3"))
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]      # "void k_resize<true>(..." -> "k_resize"
-        acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[name][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
 summary = {}
 for k, cs in acc.items():
-    summary[k] = {c: {"calls": len(v), "mean": sum(v) / len(v)} for c, v in cs.items()}
+    summary[k] = {}
+    for c, v in cs.items():
+        vals = [x for _, x in sorted(v)]
+        if k.startswith("k_") and len(vals) % (warm + steps) == 0 and len(vals) >= warm + steps:
+            vals = vals[len(vals) // (warm + steps) * warm:]
+        summary[k][c] = {"calls": len(vals), "mean": sum(vals) / len(vals)}
 # calibration: the 256 MiB device-to-device copy = the largest copyBuffer dispatch of each pass
 known = 256 << 20
 cal = {}
