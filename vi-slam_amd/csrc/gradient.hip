@@ -239,11 +239,87 @@ size_t vis_grad_frame_elems(int w, int h) {
     return (t + 63) & ~(size_t)63;                                   // frames start on 64-element boundaries
 }
 
+// ---- Camera::Update, all four half levels in ONE pass: thread = one 16 x 16 block of the frame (16 aligned 16-byte row loads),
+// level 1 = 8 x 8, level 2 = 4 x 4, level 3 = 2 x 2, level 4 = 1 pixel of it, every level the exact 2 x 2 box mean
+// (a + b + c + d + 2) >> 2 of the level above.  The frame is read once instead of 1.33 times and nothing is re-read from memory.
+// Needs w, h multiples of 16 and a 16-byte aligned frame / stride (the batched path guarantees w, h; alignment is checked by the
+// launcher, which otherwise falls back to the per-level kernel).
+static __device__ __forceinline__ uint32_t box_rows(uint32_t a, uint32_t b) {          // two source dwords (rows y, y+1) -> 2 outputs in 16-bit fields
+    const uint32_t M = 0x00FF00FFu;
+    return ((((a & M) + ((a >> 8) & M)) + ((b & M) + ((b >> 8) & M)) + 0x00020002u) >> 2) & M;
+}
+__global__ __launch_bounds__(256) void k_half_all(const uint8_t* __restrict__ src, int w, int h, int sstride, size_t sframe,
+                                                  uint8_t* __restrict__ dst, size_t dframe, int nframes) {
+    const int bxn = w >> 4, byn = h >> 4;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int f = blockIdx.y;
+    if (f >= nframes || idx >= bxn * byn) return;
+    const int by = idx / bxn, bx = idx - by * bxn;
+    const uint8_t* s0 = src + (size_t)f * sframe + (size_t)(16 * by) * sstride + 16 * bx;
+    uint8_t* d = dst + (size_t)f * dframe;
+    // level 1: rows 2r, 2r+1 -> 8 pixels = four dwords of 2 x 16-bit fields each
+    uint32_t L1[8][4];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint4 a = *reinterpret_cast<const uint4*>(s0 + (size_t)(2 * r) * sstride);
+        const uint4 b = *reinterpret_cast<const uint4*>(s0 + (size_t)(2 * r + 1) * sstride);
+        L1[r][0] = box_rows(a.x, b.x); L1[r][1] = box_rows(a.y, b.y); L1[r][2] = box_rows(a.z, b.z); L1[r][3] = box_rows(a.w, b.w);
+    }
+    const size_t o1 = (size_t)w * h, o2 = o1 + (size_t)(w >> 1) * (h >> 1), o3 = o2 + (size_t)(w >> 2) * (h >> 2), o4 = o3 + (size_t)(w >> 3) * (h >> 3);
+    {   // store level 1: 8 rows x 8 bytes (fields -> bytes: v_perm picks bytes 0 and 2 of two field dwords)
+        const int w1 = w >> 1;
+        uint8_t* p = d + o1 + (size_t)(8 * by) * w1 + 8 * bx;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t lo = __builtin_amdgcn_perm(L1[r][1], L1[r][0], 0x06040200u), hi = __builtin_amdgcn_perm(L1[r][3], L1[r][2], 0x06040200u);
+            *reinterpret_cast<uint2*>(p + (size_t)r * w1) = make_uint2(lo, hi);
+        }
+    }
+    // level 2 from level 1: horizontal neighbours are the two fields of one dword
+    uint32_t L2[4][2];                                                                 // 4 rows x 4 pixels, 2 fields per dword
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const uint32_t a0 = L1[2 * r][2 * c], a1 = L1[2 * r][2 * c + 1], b0 = L1[2 * r + 1][2 * c], b1 = L1[2 * r + 1][2 * c + 1];
+            const uint32_t s0_ = (a0 & 0xFFFFu) + (a0 >> 16) + (b0 & 0xFFFFu) + (b0 >> 16) + 2u;
+            const uint32_t s1_ = (a1 & 0xFFFFu) + (a1 >> 16) + (b1 & 0xFFFFu) + (b1 >> 16) + 2u;
+            L2[r][c] = (s0_ >> 2) | ((s1_ >> 2) << 16);
+        }
+    {
+        const int w2 = w >> 2;
+        uint8_t* p = d + o2 + (size_t)(4 * by) * w2 + 4 * bx;
+#pragma unroll
+        for (int r = 0; r < 4; r++) *reinterpret_cast<uint32_t*>(p + (size_t)r * w2) = __builtin_amdgcn_perm(L2[r][1], L2[r][0], 0x06040200u);
+    }
+    uint32_t L3[2];                                                                    // 2 rows x 2 pixels
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const uint32_t a0 = L2[2 * r][0], a1 = L2[2 * r][1], b0 = L2[2 * r + 1][0], b1 = L2[2 * r + 1][1];
+        const uint32_t s0_ = (a0 & 0xFFFFu) + (a0 >> 16) + (b0 & 0xFFFFu) + (b0 >> 16) + 2u;
+        const uint32_t s1_ = (a1 & 0xFFFFu) + (a1 >> 16) + (b1 & 0xFFFFu) + (b1 >> 16) + 2u;
+        L3[r] = (s0_ >> 2) | ((s1_ >> 2) << 16);
+    }
+    {
+        const int w3 = w >> 3;
+        uint8_t* p = d + o3 + (size_t)(2 * by) * w3 + 2 * bx;
+#pragma unroll
+        for (int r = 0; r < 2; r++) *reinterpret_cast<uint16_t*>(p + (size_t)r * w3) = (uint16_t)((L3[r] & 0xFFu) | ((L3[r] >> 8) & 0xFF00u));
+    }
+    d[o4 + (size_t)by * (w >> 4) + bx] = (uint8_t)(((L3[0] & 0xFFFFu) + (L3[0] >> 16) + (L3[1] & 0xFFFFu) + (L3[1] >> 16) + 2u) >> 2);
+}
+
 // d_pyr: n x frame_elems u8; levels 1..4 are written at their dense offsets (the level-0 part is not touched:
 // level 0 is the caller's frame)
 int launch_half_pyramid_batch(vis_ctx* ctx, const uint8_t* d_frames, int w, int h, int stride, size_t frame_bytes, int n,
                               uint8_t* d_pyr) {
     const size_t fe = vis_grad_frame_elems(w, h);
+    if (!(w & 15) && !(h & 15) && !(stride & 15) && !(frame_bytes & 15) && !((uintptr_t)d_frames & 15) && !((uintptr_t)d_pyr & 15) && !(fe & 15)) {
+        const int blocks = (w >> 4) * (h >> 4);
+        hipLaunchKernelGGL(k_half_all, dim3((blocks + 255) / 256, n), dim3(256), 0, ctx->stream, d_frames, w, h, stride, frame_bytes, d_pyr, fe, n);
+        HIPCHK(ctx, hipGetLastError());
+        return VIS_OK;
+    }
     size_t off = 0;
     for (int l = 1; l < 5; l++) {
         const int sw = w >> (l - 1), sh = h >> (l - 1), dw = sw >> 1, dh = sh >> 1;
