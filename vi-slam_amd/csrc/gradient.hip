@@ -1,6 +1,6 @@
 // gradient.hip -- the step after matching inside CameraGPU::addGPUKeyframe (/root/reference/src/CameraGPU.cpp:154-157)
 // on gfx950, batched over frames:
-//   Camera::Update's half pyramid            /root/reference/src/Camera.cpp:63-72     k_half4
+//   Camera::Update's half pyramid            /root/reference/src/Camera.cpp:63-72     k_half_all (k_half4 per level: unaligned buffers)
 //   Camera::computeGradient                  /root/reference/src/Camera.cpp:167-184   k_gradient
 //   Camera::ObtainPatchesPointsPreviousFrame /root/reference/src/Camera.cpp:358-410   k_patch_points
 //   Camera::ObtainDebugPointsPreviousFrame   /root/reference/src/Camera.cpp:413-445   k_debug_points
