@@ -220,7 +220,7 @@ void plan_destroy(Plan* pl) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(pl->d_stage);
     for (int l = 0; l < VIS_MAX_LEVELS; l++) {
-        F(pl->d_pyr[l]);
+        F(pl->d_pyr[l]); F(pl->d_rs_tab[l]);
         F(pl->d_cand[l]); F(pl->d_seg_kp[l]);
     }
     F(pl->d_fast_tiles); F(pl->d_tile_cnt); F(pl->d_seg_cnt); F(pl->d_flags); F(pl->d_angle_tab); F(pl->d_half); F(pl->d_tau); F(pl->d_seg_cut); F(pl->d_fix);

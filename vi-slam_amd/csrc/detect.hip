@@ -63,10 +63,95 @@ __device__ __forceinline__ void resize_coef(int d, double scale, int slen, int& 
 }
 
 #ifndef RS_ROWS
-#define RS_ROWS 8            // destination rows per thread: the column coefficients are computed once per thread
+#define RS_ROWS 10           // destination rows per thread: the column coefficients are computed once per thread
 #endif
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
 typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+
+// Loads + arithmetic of the RS_ROWS destination rows of a thread for a COMPILE-TIME row-sharing pattern SHARE (bit r: destination
+// row r's first source row is the second source row of row r - 1).  Consecutive destination rows share a source row whenever the
+// source index advances by one -- four times out of five at the pyramid's scale 1.2 -- and with the pattern known to the compiler
+// the shared row is neither loaded nor horizontally interpolated twice (12 instead of 20 loads).  A run-time pattern does not pay:
+// predicated or scalar-branched loads measured 0.66 ms for the pyramid of 1024 frames against 0.62 without any sharing and 0.51
+// with a compile-time pattern -- so k_resize tests the wave's pattern against the ten that occur at scale 1.2 and falls back to
+// SHARE = 0 (everything loaded) for any other wave.  Same values in every case.
+template <uint32_t SHARE>
+__device__ __forceinline__ void resize_rows(const uint8_t* __restrict__ fbase, uint32_t wb, uint32_t asel, const uint32_t (&YX)[RS_ROWS], const uint32_t (&YY)[RS_ROWS],
+                                            const uint4* __restrict__ yrow, const uint32_t (&sel)[4],
+                                            const uint32_t (&coef)[4], uint8_t* __restrict__ dbase, int dstride, int dy0, int dh, uint32_t keep) {
+    uint64_t W0[RS_ROWS], W1[RS_ROWS];
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; r++) {
+        // (frame base in SGPRs + one 32-bit lane offset: no 64-bit address pairs)
+        // Byte-unaligned 8-byte loads run at about half the rate of dword-aligned ones in the texture addresser (measured: 0.57 ms
+        // against 0.47 for the whole pyramid), so a row is fetched as the THREE aligned dwords that contain its 8-byte window and the
+        // window is cut out with two v_perm_b32 (asel = bytes s .. s + 3, s = 0 .. 4: k_resize_tab keeps the 12 bytes inside the row).
+        const u32x3_a4 d1 = *reinterpret_cast<const u32x3_a4*>(fbase + (wb + YY[r]));
+        W1[r] = (uint64_t)__builtin_amdgcn_perm(d1.y, d1.x, asel) | ((uint64_t)__builtin_amdgcn_perm(d1.z, d1.y, asel) << 32);
+        if (!((SHARE >> r) & 1u)) {
+            const u32x3_a4 d0 = *reinterpret_cast<const u32x3_a4*>(fbase + (wb + YX[r]));
+            W0[r] = (uint64_t)__builtin_amdgcn_perm(d0.y, d0.x, asel) | ((uint64_t)__builtin_amdgcn_perm(d0.z, d0.y, asel) << 32);
+        }
+    }
+#pragma unroll
+    for (int r = 1; r < RS_ROWS; r++) if ((SHARE >> r) & 1u) W0[r] = W1[r - 1];
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; r++) {
+        uint32_t v[4];
+        const uint32_t B0 = yrow[r].z, B1 = yrow[r].w;      // the Q11 row weights (<< 16) stay in LDS until their row is due
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t p0 = __builtin_amdgcn_perm((uint32_t)(W0[r] >> 32), (uint32_t)W0[r], sel[k]);
+            const uint32_t p1 = __builtin_amdgcn_perm((uint32_t)(W1[r] >> 32), (uint32_t)W1[r], sel[k]);
+            const uint32_t r0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, p0), __builtin_bit_cast(us2_t, coef[k]), 0u, false);
+            const uint32_t r1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, p1), __builtin_bit_cast(us2_t, coef[k]), 0u, false);
+            // (B * (r >> 4)) >> 16 as ONE v_mul_hi_u32 with the weight pre-shifted by 16 (B <= 2048, r >> 4 <= 32640)
+            v[k] = (__umulhi(B0, r0 >> 4) + __umulhi(B1, r1 >> 4) + 2u) >> 2;               // <= 255
+        }
+        const uint32_t out = ((v[3] << 8 | v[2]) << 16) | (v[1] << 8 | v[0]);
+        if (dy0 + r < dh) *reinterpret_cast<uint32_t*>(dbase + (uint32_t)__umul24(dy0 + r, dstride)) = out & keep;
+    }
+}
+
+// The coefficient tables of one pyramid step, built once per plan by the same IEEE operations cv::resize builds its own with:
+// 12 words per 4-pixel column group (4 byte selectors, 4 packed Q11 pairs, window start, store mask, 2 unused) followed by 4 words
+// per destination row (two source row offsets, two Q11 weights << 16).
+__global__ void k_resize_tab(uint32_t* __restrict__ tab, int bx_count, int dw, int dh, int sw, int sh, int sstride, double scale_x, double scale_y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < bx_count) {
+        const int dx4 = i * 4;
+        int sxs[4], a0s[4], a1s[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) resize_coef(min(dx4 + k, dw - 1), scale_x, sw, sxs[k], a0s[k], a1s[k]);
+        // window start clamped so that the 8-byte fetch stays inside the row; at the right edge the second
+        // byte of a pair may fall outside the window: its coefficient is 0 there, so any byte will do
+        const int wb = min(sxs[0], sstride - 8);
+        const int wa = min(wb & ~3, sstride - 12);           // the aligned 12 bytes fetched around the window (rows are >= 12 bytes, stride % 4 == 0)
+        uint32_t* e = tab + 12 * i;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int o = sxs[k] - wb;
+            e[k] = 0x0c000c00u | (uint32_t)o | ((uint32_t)min(o + 1, 7) << 16);
+            e[4 + k] = (uint32_t)a0s[k] | ((uint32_t)a1s[k] << 16);
+        }
+        e[8] = (uint32_t)wa;
+        // bytes of the 4-pixel store that lie inside the row (the rest is written as 0, as it always was)
+        e[9] = dx4 + 3 < dw ? 0xFFFFFFFFu : (0xFFFFFFFFu >> (8 * (dx4 + 4 - dw)));
+        e[10] = 0x03020100u + 0x01010101u * (uint32_t)(wb - wa);      // v_perm selector of window byte 0 .. 3 within a dword pair
+        e[11] = 0u;
+    }
+    if (i < dh) {
+        // vertical: row indices are clamped, the coefficients are not (resizeGeneric_Invoker)
+        float fy = (float)((i + 0.5) * scale_y - 0.5);
+        const int sy = (int)floorf(fy);
+        fy -= (float)sy;
+        const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
+        uint32_t* e = tab + 12 * bx_count + 4 * i;
+        e[0] = (uint32_t)__umul24(sy0, sstride); e[1] = (uint32_t)__umul24(sy1, sstride);
+        e[2] = (uint32_t)__float2int_rn((1.f - fy) * 2048.f) << 16; e[3] = (uint32_t)__float2int_rn(fy * 2048.f) << 16;
+    }
+}
 
 // NARROW (scale <= 2, every ORB pyramid step): the 4 outputs of a thread touch <= 8 consecutive source bytes, so
 // one 8-byte load per source row, one v_perm_b32 per output to pull (p[sx], p[sx+1]) out as a u16 pair and one
@@ -76,7 +161,7 @@ template <bool NARROW>
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, int sw, int sh, int sstride, size_t sframe,
                                                 uint8_t* __restrict__ dst, int dw, int dh, int dstride, size_t dframe,
                                                 double scale_x, double scale_y,
-                                                int bx_count, int per_frame, int nframes) {
+                                                int bx_count, int per_frame, int nframes, const uint32_t* __restrict__ tab) {
     int f, inner;
     if (!xcd_frame_map(blockIdx.x, per_frame, nframes, f, inner)) return;
     // flat (row group, 4-pixel column group) index: rows are narrower than 256 px on most levels, a 2-D block
@@ -87,10 +172,10 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
     if (cg < 0) { rg--; cg += bx_count; } else if (cg >= bx_count) { rg++; cg -= bx_count; }
     const int dx4 = cg * 4, dy0 = rg * RS_ROWS;
     if (NARROW) {
-        // The row coefficients (two source row offsets, two Q11 weights) are the same for every thread of a row: the
-        // workgroup computes each destination row it touches ONCE (thread t -> row row_first + t) and shares them through
-        // LDS, instead of 8 double-precision source coordinates per thread (the kernel is VALU-issue bound and the
-        // coefficient arithmetic was 40 % of its instructions).
+        // Neither the row coefficients (two source row offsets, two Q11 weights: the same for every thread of a row) nor the column
+        // coefficients (the same for every thread of a column group) are computed here: k_resize_tab tabulated them once per plan
+        // (the kernel is VALU-issue bound and the double-precision coordinate arithmetic was a quarter of its instructions).  A
+        // thread's dependency chain is table entry -> source bytes; the rows of the workgroup go through LDS.
         __shared__ uint4 yc[256];
         const int tid = threadIdx.y * 64 + threadIdx.x;
         int rg_first = (int)(((float)(inner * 256) + 0.5f) * (1.0f / (float)bx_count));
@@ -98,69 +183,33 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
         int rg_last = (int)(((float)(inner * 256 + 255) + 0.5f) * (1.0f / (float)bx_count));
         { const int c1 = inner * 256 + 255 - rg_last * bx_count; if (c1 < 0) rg_last--; else if (c1 >= bx_count) rg_last++; }
         const int row_first = rg_first * RS_ROWS, nrows = (rg_last - rg_first + 1) * RS_ROWS;
-        const bool shared_rows = nrows <= 256;                       // always, unless a level is narrower than 32 pixels
-        if (shared_rows && tid < nrows) {
-            const int dy = min(row_first + tid, dh - 1);
-            // vertical: row indices are clamped, the coefficients are not (resizeGeneric_Invoker)
-            float fy = (float)((dy + 0.5) * scale_y - 0.5);
-            const int sy = (int)floorf(fy);
-            fy -= (float)sy;
-            const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
-            yc[tid] = make_uint4((uint32_t)__umul24(sy0, sstride), (uint32_t)__umul24(sy1, sstride),
-                                 (uint32_t)__float2int_rn((1.f - fy) * 2048.f) << 16, (uint32_t)__float2int_rn(fy * 2048.f) << 16);
-        }
+        const uint4* tab4 = reinterpret_cast<const uint4*>(tab);
+        // nrows <= 256: the host sends narrower levels (< 12 groups per row) to the wide variant
+        if (tid < nrows) yc[tid] = tab4[3 * bx_count + min(row_first + tid, dh - 1)];
+        uint4 s4, c4, m4;
+        if (dy0 < dh) { s4 = tab4[3 * cg]; c4 = tab4[3 * cg + 1]; m4 = tab4[3 * cg + 2]; }
         __syncthreads();
         if (dy0 >= dh) return;
-        int sxs[4], a0s[4], a1s[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) resize_coef(min(dx4 + k, dw - 1), scale_x, sw, sxs[k], a0s[k], a1s[k]);
+        const uint32_t sel[4] = {s4.x, s4.y, s4.z, s4.w}, coef[4] = {c4.x, c4.y, c4.z, c4.w};
+        const uint32_t wb = m4.x, keep = m4.y, asel = m4.z;
         uint8_t* dbase = dst + (size_t)f * dframe + dx4;
-        // bytes of the 4-pixel store that lie inside the row (the rest is written as 0, as it always was)
-        const uint32_t keep = dx4 + 3 < dw ? 0xFFFFFFFFu : (0xFFFFFFFFu >> (8 * (dx4 + 4 - dw)));
-        // window start clamped so that the 8-byte fetch stays inside the row; at the right edge the second
-        // byte of a pair may fall outside the window: its coefficient is 0 there, so any byte will do
-        const int wb = min(sxs[0], sstride - 8);
-        uint32_t sel[4], coef[4];
+        const uint8_t* fbase = src + (size_t)f * sframe;
+        const uint4* yrow = yc + (dy0 - row_first);
+        uint32_t YX[RS_ROWS], YY[RS_ROWS];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int o = sxs[k] - wb;
-            sel[k] = 0x0c000c00u | (uint32_t)o | ((uint32_t)min(o + 1, 7) << 16);
-            coef[k] = (uint32_t)a0s[k] | ((uint32_t)a1s[k] << 16);
-        }
-        const uint8_t* sbase = src + (size_t)f * sframe + wb;
-        uint64_t W0[RS_ROWS], W1[RS_ROWS]; uint32_t B0[RS_ROWS], B1[RS_ROWS];
+        for (int r = 0; r < RS_ROWS; r++) { YX[r] = yrow[r].x; YY[r] = yrow[r].y; }
+        // the row-sharing pattern of the WAVE (one scalar bit per row: every lane's first source row is the row above's second)
+        uint32_t share = 0;
 #pragma unroll
-        for (int r = 0; r < RS_ROWS; r++) {
-            uint4 y;
-            if (shared_rows) y = yc[dy0 - row_first + r];
-            else {
-                const int dy = min(dy0 + r, dh - 1);
-                float fy = (float)((dy + 0.5) * scale_y - 0.5);
-                const int sy = (int)floorf(fy);
-                fy -= (float)sy;
-                const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
-                y = make_uint4((uint32_t)__umul24(sy0, sstride), (uint32_t)__umul24(sy1, sstride),
-                               (uint32_t)__float2int_rn((1.f - fy) * 2048.f) << 16, (uint32_t)__float2int_rn(fy * 2048.f) << 16);
-            }
-            B0[r] = y.z; B1[r] = y.w;
-            W0[r] = *reinterpret_cast<const u64_unaligned*>(sbase + y.x);
-            W1[r] = *reinterpret_cast<const u64_unaligned*>(sbase + y.y);
-        }
-#pragma unroll
-        for (int r = 0; r < RS_ROWS; r++) {
-            uint32_t v[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t p0 = __builtin_amdgcn_perm((uint32_t)(W0[r] >> 32), (uint32_t)W0[r], sel[k]);
-                const uint32_t p1 = __builtin_amdgcn_perm((uint32_t)(W1[r] >> 32), (uint32_t)W1[r], sel[k]);
-                const uint32_t r0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, p0), __builtin_bit_cast(us2_t, coef[k]), 0u, false);
-                const uint32_t r1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, p1), __builtin_bit_cast(us2_t, coef[k]), 0u, false);
-                // (B * (r >> 4)) >> 16 as ONE v_mul_hi_u32 with the weight pre-shifted by 16 (B <= 2048, r >> 4 <= 32640)
-                v[k] = (__umulhi(B0[r], r0 >> 4) + __umulhi(B1[r], r1 >> 4) + 2u) >> 2;         // <= 255
-            }
-            const uint32_t out = ((v[3] << 8 | v[2]) << 16) | (v[1] << 8 | v[0]);
-            if (dy0 + r < dh) *reinterpret_cast<uint32_t*>(dbase + (uint32_t)__umul24(dy0 + r, dstride)) = out & keep;
-        }
+        for (int r = 1; r < RS_ROWS; r++) share |= (__builtin_amdgcn_ballot_w64(YX[r] != YY[r - 1]) == 0 ? 1u : 0u) << r;
+        // At scale 1.2 the source row advances by two once every five rows (ten rows: at p and p + 5).  Any pattern that is a SUBSET
+        // of the wave's is exact (an unshared row is simply loaded); the second list covers waves that straddle two row groups whose
+        // phase differs by one, so that only waves at a clamped border or of another scale load all twenty rows.
+#define RS_CASE(M) if ((M & ~share) == 0u) { resize_rows<M>(fbase, wb, asel, YX, YY, yrow, sel, coef, dbase, dstride, dy0, dh, keep); return; }
+        RS_CASE(0x3DEu) RS_CASE(0x3BCu) RS_CASE(0x37Au) RS_CASE(0x2F6u) RS_CASE(0x1EEu)
+        RS_CASE(0x39Cu) RS_CASE(0x338u) RS_CASE(0x272u) RS_CASE(0x0E6u) RS_CASE(0x1CEu)
+#undef RS_CASE
+        resize_rows<0u>(fbase, wb, asel, YX, YY, yrow, sel, coef, dbase, dstride, dy0, dh, keep);
         return;
     }
     if (dy0 >= dh) return;
@@ -1043,12 +1092,18 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
         const int bxc = (V.w + 3) / 4, per_frame = (bxc * ((V.h + RS_ROWS - 1) / RS_ROWS) + 255) / 256;   // bxc = 4-px groups per row
         // scale exactly as cv::resize derives it: inv_scale = (double)dsize/ssize; scale = 1./inv_scale
         const double scale_x = 1. / ((double)V.w / U.w), scale_y = 1. / ((double)V.h / U.h);
-        if (scale_x <= 2.0)
+        if (scale_x <= 2.0 && bxc >= 12) {       // (256 threads then span at most 23 row groups = 230 rows of coefficients)
+            if (!pl->d_rs_tab[l]) {              // first use of the plan: tabulate the step's coefficients
+                const size_t words = (size_t)12 * bxc + (size_t)4 * V.h;
+                HIPCHK(ctx, hipMalloc((void**)&pl->d_rs_tab[l], words * 4));
+                hipLaunchKernelGGL(k_resize_tab, dim3((std::max(bxc, V.h) + 255) / 256), dim3(256), 0, st, pl->d_rs_tab[l], bxc, V.w, V.h, U.w, U.h, U.stride, scale_x, scale_y);
+                HIPCHK(ctx, hipStreamSynchronize(st));       // (once: later launches may come from another stream)
+            }
             hipLaunchKernelGGL(k_resize<true>, dim3(xcd_grid(n, per_frame)), dim3(64, 4), 0, st, D.lv[l - 1].img, U.w, U.h, U.stride, U.frame_bytes,
-                               pl->d_pyr[l], V.w, V.h, V.stride, V.frame_bytes, scale_x, scale_y, bxc, per_frame, n);
-        else
+                               pl->d_pyr[l], V.w, V.h, V.stride, V.frame_bytes, scale_x, scale_y, bxc, per_frame, n, (const uint32_t*)pl->d_rs_tab[l]);
+        } else
             hipLaunchKernelGGL(k_resize<false>, dim3(xcd_grid(n, per_frame)), dim3(64, 4), 0, st, D.lv[l - 1].img, U.w, U.h, U.stride, U.frame_bytes,
-                               pl->d_pyr[l], V.w, V.h, V.stride, V.frame_bytes, scale_x, scale_y, bxc, per_frame, n);
+                               pl->d_pyr[l], V.w, V.h, V.stride, V.frame_bytes, scale_x, scale_y, bxc, per_frame, n, (const uint32_t*)nullptr);
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[1], st);
     const int t_base = ctx->p.fast_threshold;

@@ -43,6 +43,7 @@ struct Plan {
     // ---- device buffers
     uint8_t* d_stage = nullptr;              // single-frame upload staging (stride x h)
     uint8_t* d_pyr[VIS_MAX_LEVELS] = {};     // level l >= 1: B x h_l x stride_l
+    uint32_t* d_rs_tab[VIS_MAX_LEVELS] = {}; // level l >= 1: coefficient tables of the resize step l-1 -> l (detect.hip k_resize_tab; built on first use)
     uint32_t* d_cand[VIS_MAX_LEVELS] = {};   // B x tiles_l x 512 packed (score<<24 | y<<12 | x)
     int32_t* d_tile_cnt = nullptr;           // B x total_tiles candidates per tile
     int total_tiles = 0;
