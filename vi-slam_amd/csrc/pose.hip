@@ -228,6 +228,55 @@ __global__ __launch_bounds__(256) void k_pose_prep(PoseParams P, const float* __
     }
 }
 
+// the value lane SRC of every quad holds, in all four lanes of the quad (two DPP moves per double)
+template <int SRC>
+DEV double quad_bcast(double x) {
+    constexpr int ctrl = SRC * 0x55;                               // quad_perm [SRC, SRC, SRC, SRC]
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, ctrl, 0xF, 0xF, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), ctrl, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
+}
+
+// One Gauss-Jordan step (column COL) of the quad's 10 x 20 system: M[r][cc] = element (r, 4 cc + q) in lane q.  The pivot column
+// comes from its owner lane by quad broadcast; pivot search, reciprocal and multipliers are replicated in the four lanes; a lane
+// updates its own columns c >= COL.  Per element exactly the operations of oracle/pose.cpp five_point(): rows COL and piv are
+// exchanged, the pivot row is scaled by 1 / pivot, every other row with a non-zero multiplier subtracts multiplier * pivot row.
+template <int COL>
+DEV void gj_step(double (&M)[10][5], int q, bool& ok) {
+    double v[10];
+#pragma unroll
+    for (int r = 0; r < 10; r++) v[r] = quad_bcast<(COL & 3)>(M[r][COL >> 2]);
+    int piv = COL; double best = fabs(v[COL]);
+#pragma unroll
+    for (int r = COL + 1; r < 10; r++) { const double a = fabs(v[r]); if (a > best) { best = a; piv = r; } }
+    if (best < 1e-300) ok = false;
+    const double pv = v[COL];                                      // after the row exchange row `piv` holds the old row COL
+    double vp = v[COL];
+#pragma unroll
+    for (int r = COL + 1; r < 10; r++) vp = (r == piv) ? v[r] : vp;
+    const double inv = 1.0 / vp;
+#pragma unroll
+    for (int cc = 0; cc < 5; cc++) {
+        if (4 * cc + 3 < COL) continue;                            // columns left of the pivot are finished
+        if (4 * cc + q >= COL) {
+            const double t = M[COL][cc];
+            double pr = t;
+#pragma unroll
+            for (int r = COL + 1; r < 10; r++)
+                if (r == piv) { pr = M[r][cc]; M[r][cc] = t; }
+            pr *= inv;
+            M[COL][cc] = pr;
+#pragma unroll
+            for (int r = 0; r < 10; r++) {
+                if (r == COL) continue;
+                const double f = (r == piv) ? pv : v[r];
+                if (f != 0.0) M[r][cc] -= f * pr;
+            }
+        }
+    }
+}
+
 // One wave per block, FOUR lanes per hypothesis (quad lane q = lane & 3, hypothesis slot hs = lane >> 2), 16 consecutive
 // hypotheses of ONE frame pair per wave.  Every matrix element is produced by exactly the operation sequence of
 // oracle/pose.cpp five_point() -- the quad only decides WHICH lane runs a sequence:
@@ -381,43 +430,25 @@ __device__ __forceinline__ void ransac_hyp_quad(const PoseParams& P, int pair_ra
         }
     }
     HYP_SYNC();
-    // ---- Gauss-Jordan with partial pivoting on the left 10 x 10 block.  Per step every lane reads column `col` (the pivot
-    // search and the multipliers of all rows, taken BEFORE anything of this step is written), then updates its own columns.
+    // ---- Gauss-Jordan with partial pivoting on the left 10 x 10 block, IN REGISTERS: lane q takes its columns c = q (mod 4) of
+    // all ten rows out of LDS once (50 doubles), gj_step<col> runs the ten steps on them, and only the right-hand block of rows
+    // 4..9 -- what B(z) is built from -- goes back.  (With the matrix in LDS every element update was a dependent LDS round trip
+    // of a kernel that runs at one wave per SIMD: 1.2 of its 2.0 ms per 1.02 M hypotheses.)
+    double Mq[10][5];
+#pragma unroll
+    for (int r = 0; r < 10; r++)
+#pragma unroll
+        for (int cc = 0; cc < 5; cc++) Mq[r][cc] = LM(r, 4 * cc + q);
     bool ok = true;
+    gj_step<0>(Mq, q, ok); gj_step<1>(Mq, q, ok); gj_step<2>(Mq, q, ok); gj_step<3>(Mq, q, ok); gj_step<4>(Mq, q, ok);
+    gj_step<5>(Mq, q, ok); gj_step<6>(Mq, q, ok); gj_step<7>(Mq, q, ok); gj_step<8>(Mq, q, ok); gj_step<9>(Mq, q, ok);
+    HYP_SYNC();                                                    // every lane has taken its columns
 #pragma unroll
-    for (int col = 0; col < 10; col++) {
-        double v[10];
+    for (int r = 4; r < 10; r++)
 #pragma unroll
-        for (int r = 0; r < 10; r++) v[r] = LM(r, col);
-        int piv = col; double best = fabs(v[col]);
-#pragma unroll
-        for (int r = col + 1; r < 10; r++) { const double a = fabs(v[r]); if (a > best) { best = a; piv = r; } }
-        if (best < 1e-300) ok = false;
-        const double pv = v[col];                                  // after the row exchange row `piv` holds the old row `col`
-        double vp = v[col];
-#pragma unroll
-        for (int r = col + 1; r < 10; r++) vp = (r == piv) ? v[r] : vp;
-        const double inv = 1.0 / vp;                               // prow[col] = old M[piv][col]
-        HYP_SYNC();
-#pragma unroll
-        for (int cc = 0; cc < 5; cc++) {
-            const int c = 4 * cc + q;
-            if (c >= col) {
-                double pr = LM(piv, c);
-                const double t = LM(col, c);
-                LM(piv, c) = t;
-                pr *= inv;
-                LM(col, c) = pr;
-#pragma unroll
-                for (int r = 0; r < 10; r++) {
-                    if (r == col) continue;
-                    const double f = (r == piv) ? pv : v[r];
-                    if (f != 0.0) LM(r, c) -= f * pr;
-                }
-            }
-        }
-        HYP_SYNC();
-    }
+        for (int cc = 2; cc < 5; cc++)
+            if (4 * cc + q >= 10) LM(r, 4 * cc + q) = Mq[r][cc];
+    HYP_SYNC();
     // ---- the record's 36 null-space doubles: lanes 1..3, 12 each (element-major, slot-minor: a quad lane's 16 hypotheses are
     // 16 consecutive slots)
     const size_t slot = (size_t)pair * P.max_iters + (active ? h : 0);
@@ -535,6 +566,29 @@ DEV bool sub_item(const int32_t* worklist, int chunks, int h0, int npairs, int s
     return true;
 }
 
+// per lane: bit of `mask` set ? a : b.  Written out as two VOP3-encoded v_cndmask_b32 with the mask in an SGPR pair: the compiler
+// picks the VOP2 encoding (selector in vcc) for a run of selects on one condition, and three or more of those back to back issue
+// at 23 cycles each on gfx950 instead of 4 (profiles/r02_valu_cnd_mi355x.txt) -- in the bisection loop that was more than the
+// Horner chain itself.
+DEV double sel_f64(unsigned long long mask, double a, double b) {
+    const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+    unsigned lo, hi;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"((unsigned)ub), "v"((unsigned)ua), "s"(mask));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"((unsigned)(ub >> 32)), "v"((unsigned)(ua >> 32)), "s"(mask));
+    return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
+}
+
+// One bisection step on (lo, hi) given the mid point m and fm = f(m).  The sequential algorithm leaves its loop when the mid
+// point no longer lies strictly inside (m == lo or m == hi: the interval has collapsed to neighbouring doubles); here the step is
+// simply taken, because it is then a no-op: lo only ever moves to points where (f < 0) == neg and hi to points where it differs
+// (true of the start values by the sign-change test), f(m) is the same Horner chain that classified that end point, so m == lo
+// re-assigns lo and m == hi re-assigns hi.  That removes two f64 compares and the guard logic from every step; whether ALL active
+// lanes of the wave have collapsed is looked at every eighth step only (extra steps change nothing).  Lanes without an interval
+// run on garbage that nobody reads.
+#define BISECT_STEP(act_)                                                               \
+        if ((it & 7) == 7 && !__any((act_) && (m > lo) && (m < hi))) break;             \
+        { const unsigned long long left_ = __builtin_amdgcn_ballot_w64(fm < 0) ^ negmask; lo = sel_f64(left_, m, lo); hi = sel_f64(left_, hi, m); }
+
 // one bisection level of the derivative-interlacing root finder (oracle/pose.cpp real_roots), ONE candidate
 // interval per lane: lane j of a 16-lane group owns the interval (prev[j-1], prev[j]) of the degree-D derivative.
 // The arithmetic per interval is exactly the sequential algorithm's; only the mapping to lanes differs.
@@ -556,6 +610,7 @@ DEV void roots_level(const double (&c)[11], double B, int j, int gshift, double*
 #pragma unroll
     for (int i = D - 1; i >= 0; i--) { flo = flo * lo + q[i]; fhi = fhi * hi + q[i]; }
     const bool neg = flo < 0;
+    const unsigned long long negmask = ~__builtin_amdgcn_ballot_w64(neg);      // left = (fm < 0) == neg
     const bool act = mine && ((flo < 0) != (fhi < 0));
     constexpr int NIT = (D == 10) ? BISECT_FINAL : BISECT_INNER;
     for (int it = 0; it < NIT; it++) {
@@ -563,11 +618,7 @@ DEV void roots_level(const double (&c)[11], double B, int j, int gshift, double*
         double fm = q[D];
 #pragma unroll
         for (int i = D - 1; i >= 0; i--) fm = fm * m + q[i];
-        const bool go = act && (m > lo) && (m < hi);               // "break" of the reference loop == no-op from here on
-        const bool left = (fm < 0) == neg;
-        if (go && left) lo = m;
-        if (go && !left) hi = m;
-        if (D == 10 && !__any(go)) break;
+        BISECT_STEP(act)
     }
     const double r = 0.5 * (lo + hi);
     const uint32_t mask = (uint32_t)(__builtin_amdgcn_ballot_w64(act) >> gshift) & 0xFFFFu;
@@ -596,6 +647,7 @@ DEV void roots_level_rt(const double* cl, int deg, int d, double B, int j, int g
 #pragma unroll
     for (int i = 9; i >= 0; i--) { flo = flo * lo + q[i]; fhi = fhi * hi + q[i]; }
     const bool neg = flo < 0;
+    const unsigned long long negmask = ~__builtin_amdgcn_ballot_w64(neg);
     const bool act = mine && ((flo < 0) != (fhi < 0));
     const int nit = d == deg ? BISECT_FINAL : BISECT_INNER;
     for (int it = 0; it < nit; it++) {
@@ -603,11 +655,7 @@ DEV void roots_level_rt(const double* cl, int deg, int d, double B, int j, int g
         double fm = q[10];
 #pragma unroll
         for (int i = 9; i >= 0; i--) fm = fm * m + q[i];
-        const bool go = act && (m > lo) && (m < hi);
-        const bool left = (fm < 0) == neg;
-        if (go && left) lo = m;
-        if (go && !left) hi = m;
-        if (!__any(go)) break;
+        BISECT_STEP(act)
     }
     const double r = 0.5 * (lo + hi);
     const uint32_t mask = (uint32_t)(__builtin_amdgcn_ballot_w64(act) >> gshift) & 0xFFFFu;
@@ -708,34 +756,43 @@ DEV void roots_level_lane(const double (&c)[11], double B, double (*prev)[64], i
         q[i] = c[i + K] * f;
     }
     constexpr int NIT = (D == 10) ? BISECT_FINAL : BISECT_INNER;
+    // signs at the interval end points -B, root 0 .. root nprev-1 of the previous level, +B (each value is the Horner chain the
+    // sequential algorithm evaluates at that end point; it evaluates the inner ones twice, as hi of one interval and lo of the next)
+    uint32_t sneg = 0;
+#pragma unroll
+    for (int j = 0; j <= D; j++) {
+        const double x = j == 0 ? -B : ((D > 1 && j <= D - 1 && j <= nprev) ? prev[j - 1][lane] : B);
+        double fx = q[D];
+#pragma unroll
+        for (int i = D - 1; i >= 0; i--) fx = fx * x + q[i];
+        sneg |= (fx < 0 ? 1u : 0u) << j;
+    }
+    // interval j = (end point j, end point j + 1), j = 0 .. nprev, holds a root iff the signs differ.  A lane walks over ITS
+    // sign-change intervals only (ascending), so the wave needs max-over-lanes(number of roots) rounds instead of D.
+    const int last = min(nprev, D - 1);                            // index of the interval that ends at +B
+    uint32_t todo = (sneg ^ (sneg >> 1)) & ((2u << last) - 1u);
     int ncur = 0;
-    double lo_next = -B;
+    int j = todo ? __builtin_ctz(todo) : 0;
+    double lo = (j == 0) ? -B : prev[j - 1][lane];
+    double hi = (j >= last) ? B : prev[j][lane];
+    while (__any(todo != 0)) {
+        const bool act = todo != 0;
+        const unsigned long long negmask = ~__builtin_amdgcn_ballot_w64((sneg >> j) & 1u);       // left = (fm < 0) == neg
+        for (int it = 0; it < NIT; it++) {
+            const double m = 0.5 * (lo + hi);
+            double fm = q[D];
 #pragma unroll
-    for (int j = 0; j < D; j++) {                                  // the degree D-1 level left at most D-1 roots: D intervals
-        const bool mine = j <= nprev;
-        double lo = lo_next;
-        const double pj = (D > 1 && j < D - 1) ? prev[j][lane] : B;   // root j of the previous level (unused when j >= nprev)
-        double hi = (j >= nprev) ? B : pj;
-        lo_next = pj;
-        double flo = q[D], fhi = q[D];
-#pragma unroll
-        for (int i = D - 1; i >= 0; i--) { flo = flo * lo + q[i]; fhi = fhi * hi + q[i]; }
-        const bool neg = flo < 0;
-        const bool act = mine && ((flo < 0) != (fhi < 0));
-        if (__any(act)) {
-            for (int it = 0; it < NIT; it++) {
-                const double m = 0.5 * (lo + hi);
-                double fm = q[D];
-#pragma unroll
-                for (int i = D - 1; i >= 0; i--) fm = fm * m + q[i];
-                const bool go = act && (m > lo) && (m < hi);       // "break" of the reference loop == no-op from here on
-                const bool left = (fm < 0) == neg;
-                if (go && left) lo = m;
-                if (go && !left) hi = m;
-                if (!__any(go)) break;
-            }
+            for (int i = D - 1; i >= 0; i--) fm = fm * m + q[i];
+            BISECT_STEP(act)
         }
-        if (act) { prev[ncur][lane] = 0.5 * (lo + hi); ncur++; }
+        const double r = 0.5 * (lo + hi);
+        // the next interval's end points are read BEFORE this root is stored: root k lands at index k <= j, the next interval
+        // j' > j reads indices j' - 1 and j' >= k, and everything after it reads indices > k
+        todo &= todo - 1u;
+        j = todo ? __builtin_ctz(todo) : 0;
+        lo = (j == 0) ? -B : prev[j - 1][lane];
+        hi = (j >= last) ? B : prev[min(j, 9)][lane];
+        if (act) { prev[ncur][lane] = r; ncur++; }                 // (a lane only ever touches its own column of prev)
     }
     nprev = ncur;
 }
@@ -779,7 +836,7 @@ __global__ __launch_bounds__(256) void k_hyp_roots_lane(PoseParams P, int h0, in
 // models + scores of one sub-item (16 hypotheses of one pair): thread (hyp, root) back-substitutes its root, the
 // 256 threads then score every model of the sub-item against the pair's points (wave = model, lanes = points),
 // and thread hyp picks the first model with the largest count.  hbest[pair][h] = (best count << 4) | model, -1 = none.
-#define SC_CH 512                                                  // points staged in LDS per pass
+#define SC_CH 256                                                  // points staged in LDS per pass (512: 29 KB of LDS per workgroup and 1.30 instead of 0.98 ms per 1.02 M hypotheses)
 // rstate is read (words 0, 6) AND written (word 8, the models-scored counter) here: a plain pointer, no const / __restrict__ promise
 __global__ __launch_bounds__(256) void k_hyp_score(PoseParams P, int h0, int h_end, int npairs, int32_t* rstate,
                                                    const double* __restrict__ n1, const double* __restrict__ n2,
@@ -889,12 +946,21 @@ __global__ __launch_bounds__(256) void k_hyp_score(PoseParams P, int h0, int h_e
             }
             __syncthreads();
             if (M <= 256) {
-                // Few correspondences (the reference pipeline: <= root^2 = 49 grid matches): LANE = model, the wave walks over its
-                // quarter of the points, whose coordinates are LDS broadcasts.  A wave-per-model pass would leave a third of the
-                // lanes idle at M = 43 and pay a wave reduction per model; here the only reduction is one LDS add per lane.
-                const int q0 = (mc * wv) >> 2, q1 = (mc * (wv + 1)) >> 2;          // this wave's points
-                for (int t0 = 0; t0 < T; t0 += 64) {
-                    const int t = t0 + lane;
+                // Few correspondences (the reference pipeline: <= root^2 = 49 grid matches): LANE = (model, slice of the points).  A
+                // wave-per-model pass would leave a third of the lanes idle at M = 43 and pay a wave reduction per model; here the
+                // only reduction is one LDS add per lane.  The points are cut into K slices, K chosen per sub-item so that the
+                // T x K (model, slice) items fill the 256 lanes in the fewest passes: at the typical T = 67 models of 16 hypotheses
+                // K = 3 takes one pass of 15 points where a fixed K = 4 (64 models per pass) took two passes of 11.
+                int K = 1, cost = 0x7FFFFFFF;
+                for (int k = 1; k <= 8; k++) {
+                    const int per = 256 / k, c = ((T + per - 1) / per) * ((mc + k - 1) / k);
+                    if (c < cost) { cost = c; K = k; }
+                }
+                const int per = 256 / K;
+                const int ks = tid / per, tl = tid - ks * per;                        // slice, model within the pass
+                const int q0 = (mc * ks) / K, q1 = ks < K ? (mc * (ks + 1)) / K : q0;   // lanes beyond per * K idle
+                for (int t0 = 0; t0 < T; t0 += per) {
+                    const int t = t0 + tl;
                     const int tc = min(t, T - 1);
                     double Em[9];
 #pragma unroll
