@@ -122,11 +122,14 @@ DEV void mul_ql_u(const double (&q)[10], const double (&l)[4], double (&c)[20], 
 }
 
 // LDS layout (one wave per block): FOUR lanes per hypothesis, 16 hypotheses per wave; element-major, hypothesis-minor.
-// 236 doubles per hypothesis = 30 KB per wave: five waves per CU (the lane-per-hypothesis layout needed 118 KB: one).
+// 116 doubles per hypothesis = 14.5 KB per wave (a four-row stage + the null-space basis; the 10 x 20 system itself lives in the
+// quad's registers): ten waves per CU as far as LDS goes (the lane-per-hypothesis layout needed 118 KB: one).
 #define QH 16
-#define LM(r, c) ldsM[((r) * 20 + (c)) * QH + hs]
+#define LS(s_, c) ldsM[((s_) * 20 + (c)) * QH + hs]                 // stage slot s_ (four rows of 20) of the row -> column exchange
+#define LR(r, c) ldsM[(((r) - 4) * 10 + ((c) - 10)) * QH + hs]    // the same memory afterwards: right-hand block of rows 4..9
 #define LB(j, i) ldsB[((j) * 9 + (i)) * QH + hs]
-#define HYP_LDS_BYTES ((200 + 36) * QH * 8)
+#define HYP_STAGE 80
+#define HYP_LDS_BYTES ((HYP_STAGE + 36) * QH * 8)
 // hypothesis record (doubles, element-major over all (pair, iteration) slots): det polynomial c[0..10], the three
 // B(z) row polynomials, the null-space basis, the real roots; then two int32 planes: flag, number of roots
 #define HR_BX 11
@@ -369,29 +372,14 @@ __device__ __forceinline__ void ransac_hyp_quad(const PoseParams& P, int pair_ra
         for (int i = 0; i < 9; i++) LB(q, i) = e[i];
     }
     HYP_SYNC();
-    // ---- constraint rows -> LDS.  row 0: det(E), lane 0
-    if (q == 0) {
-        double row[20];
-#pragma unroll
-        for (int c = 0; c < 20; c++) row[c] = 0;
-        constexpr int ta[3] = {0, 1, 2}, tb[3] = {1, 0, 0}, tc[3] = {2, 2, 1}, td[3] = {2, 2, 1}, te[3] = {1, 0, 0};
-        constexpr double sg[3] = {1.0, -1.0, 1.0};
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            double qq[10], q2[10], l1[4], l2[4];
-#pragma unroll
-            for (int i = 0; i < 10; i++) { qq[i] = 0; q2[i] = 0; }
-            load_El(ldsB, hs, 1, tb[k], l1); load_El(ldsB, hs, 2, tc[k], l2); mul_ll_u(l1, l2, qq);
-            load_El(ldsB, hs, 1, td[k], l1); load_El(ldsB, hs, 2, te[k], l2); mul_ll_u(l1, l2, q2);
-#pragma unroll
-            for (int i = 0; i < 10; i++) qq[i] -= q2[i];
-            load_El(ldsB, hs, 0, ta[k], l1);
-            mul_ql_u(qq, l1, row, sg[k]);
-        }
-#pragma unroll
-        for (int c = 0; c < 20; c++) LM(0, c) = row[c];
-    } else {
-        // rows 1 + 3 i + j: (E E^T - 0.5 tr(E E^T) I) E, lane q owns i = q - 1 (all index arithmetic on i goes through LDS)
+    // ---- constraint rows.  Row 0 (det E) is built by lane 0, rows 1 + 3 i + j of (E E^T - 0.5 tr(E E^T) I) E by lane q = i + 1;
+    // the Gauss-Jordan below wants COLUMNS c = q (mod 4) of all ten rows in lane q.  The exchange goes through a four-row LDS
+    // stage in three rounds (round j: rows 1 + j, 4 + j, 7 + j, and row 0 in the first), so a wave holds 14.5 KB of LDS instead of
+    // the 30 KB of the whole 10 x 20 system: ten waves per CU fit instead of five.
+    double Mq[10][5];
+    double EEt[3][10];
+    if (q != 0) {
+        // lane q owns i = q - 1 (all index arithmetic on i goes through LDS)
         const int i = q - 1;
         double tr[10];
         {
@@ -406,7 +394,6 @@ __device__ __forceinline__ void ransac_hyp_quad(const PoseParams& P, int pair_ra
 #pragma unroll
             for (int m = 0; m < 10; m++) tr[m] = 0.5 * ((dg[0][m] + dg[1][m]) + dg[2][m]);
         }
-        double EEt[3][10];
 #pragma unroll
         for (int j = 0; j < 3; j++) {
 #pragma unroll
@@ -418,36 +405,59 @@ __device__ __forceinline__ void ransac_hyp_quad(const PoseParams& P, int pair_ra
         for (int j = 0; j < 3; j++)
 #pragma unroll
             for (int m = 0; m < 10; m++) EEt[j][m] = (j == i) ? EEt[j][m] - tr[m] : EEt[j][m];
+    }
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
+    for (int j = 0; j < 3; j++) {
+        if (q == 0) {
+            if (j == 0) {
+                double row[20];
+#pragma unroll
+                for (int c = 0; c < 20; c++) row[c] = 0;
+                constexpr int ta[3] = {0, 1, 2}, tb[3] = {1, 0, 0}, tc[3] = {2, 2, 1}, td[3] = {2, 2, 1}, te[3] = {1, 0, 0};
+                constexpr double sg[3] = {1.0, -1.0, 1.0};
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    double qq[10], q2[10], l1[4], l2[4];
+#pragma unroll
+                    for (int i = 0; i < 10; i++) { qq[i] = 0; q2[i] = 0; }
+                    load_El(ldsB, hs, 1, tb[k], l1); load_El(ldsB, hs, 2, tc[k], l2); mul_ll_u(l1, l2, qq);
+                    load_El(ldsB, hs, 1, td[k], l1); load_El(ldsB, hs, 2, te[k], l2); mul_ll_u(l1, l2, q2);
+#pragma unroll
+                    for (int i = 0; i < 10; i++) qq[i] -= q2[i];
+                    load_El(ldsB, hs, 0, ta[k], l1);
+                    mul_ql_u(qq, l1, row, sg[k]);
+                }
+#pragma unroll
+                for (int c = 0; c < 20; c++) LS(0, c) = row[c];
+            }
+        } else {
             double row[20];
 #pragma unroll
             for (int c = 0; c < 20; c++) row[c] = 0;
 #pragma unroll
             for (int k = 0; k < 3; k++) { double l1[4]; load_El(ldsB, hs, k, j, l1); mul_ql_u(EEt[k], l1, row, 1.0); }
 #pragma unroll
-            for (int c = 0; c < 20; c++) LM(1 + 3 * i + j, c) = row[c];
+            for (int c = 0; c < 20; c++) LS(q, c) = row[c];
         }
+        HYP_SYNC();
+#pragma unroll
+        for (int cc = 0; cc < 5; cc++) {
+            if (j == 0) Mq[0][cc] = LS(0, 4 * cc + q);
+            Mq[1 + j][cc] = LS(1, 4 * cc + q); Mq[4 + j][cc] = LS(2, 4 * cc + q); Mq[7 + j][cc] = LS(3, 4 * cc + q);
+        }
+        HYP_SYNC();
     }
-    HYP_SYNC();
-    // ---- Gauss-Jordan with partial pivoting on the left 10 x 10 block, IN REGISTERS: lane q takes its columns c = q (mod 4) of
-    // all ten rows out of LDS once (50 doubles), gj_step<col> runs the ten steps on them, and only the right-hand block of rows
-    // 4..9 -- what B(z) is built from -- goes back.  (With the matrix in LDS every element update was a dependent LDS round trip
-    // of a kernel that runs at one wave per SIMD: 1.2 of its 2.0 ms per 1.02 M hypotheses.)
-    double Mq[10][5];
-#pragma unroll
-    for (int r = 0; r < 10; r++)
-#pragma unroll
-        for (int cc = 0; cc < 5; cc++) Mq[r][cc] = LM(r, 4 * cc + q);
+    // ---- Gauss-Jordan with partial pivoting on the left 10 x 10 block, IN REGISTERS (gj_step<col>); only the right-hand block of
+    // rows 4..9 -- what B(z) is built from -- goes back to LDS.  (With the matrix in LDS every element update was a dependent LDS
+    // round trip of a kernel that ran at one wave per SIMD: 1.2 of its 2.0 ms per 1.02 M hypotheses.)
     bool ok = true;
     gj_step<0>(Mq, q, ok); gj_step<1>(Mq, q, ok); gj_step<2>(Mq, q, ok); gj_step<3>(Mq, q, ok); gj_step<4>(Mq, q, ok);
     gj_step<5>(Mq, q, ok); gj_step<6>(Mq, q, ok); gj_step<7>(Mq, q, ok); gj_step<8>(Mq, q, ok); gj_step<9>(Mq, q, ok);
-    HYP_SYNC();                                                    // every lane has taken its columns
 #pragma unroll
     for (int r = 4; r < 10; r++)
 #pragma unroll
         for (int cc = 2; cc < 5; cc++)
-            if (4 * cc + q >= 10) LM(r, 4 * cc + q) = Mq[r][cc];
+            if (4 * cc + q >= 10) LR(r, 4 * cc + q) = Mq[r][cc];
     HYP_SYNC();
     // ---- the record's 36 null-space doubles: lanes 1..3, 12 each (element-major, slot-minor: a quad lane's 16 hypotheses are
     // 16 consecutive slots)
@@ -467,7 +477,7 @@ __device__ __forceinline__ void ransac_hyp_quad(const PoseParams& P, int pair_ra
     for (int i = 0; i < 3; i++) {
         double a[10], b[10];
 #pragma unroll
-        for (int c = 0; c < 10; c++) { a[c] = LM(4 + 2 * i, 10 + c); b[c] = LM(5 + 2 * i, 10 + c); }
+        for (int c = 0; c < 10; c++) { a[c] = LR(4 + 2 * i, 10 + c); b[c] = LR(5 + 2 * i, 10 + c); }
         Bx[i][0] = a[2]; Bx[i][1] = a[1] - b[2]; Bx[i][2] = a[0] - b[1]; Bx[i][3] = -b[0];
         By[i][0] = a[5]; By[i][1] = a[4] - b[5]; By[i][2] = a[3] - b[4]; By[i][3] = -b[3];
         B1[i][0] = a[9]; B1[i][1] = a[8] - b[9]; B1[i][2] = a[7] - b[8]; B1[i][3] = a[6] - b[7]; B1[i][4] = -b[6];
@@ -534,14 +544,14 @@ __global__ __launch_bounds__(64) void k_ransac_hyp(PoseParams P, int h0, int h_e
                                                    double* __restrict__ hyp, size_t S) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* ldsM = reinterpret_cast<double*>(smem);
-    ransac_hyp_quad(P, blockIdx.y, h0 + blockIdx.x * QH, h_end, npairs, n1, n2, samples, rstate, hyp, S, ldsM, ldsM + 200 * QH);
+    ransac_hyp_quad(P, blockIdx.y, h0 + blockIdx.x * QH, h_end, npairs, n1, n2, samples, rstate, hyp, S, ldsM, ldsM + HYP_STAGE * QH);
 }
 
 // Later chunks (h >= first) are only needed for the pairs whose adaptive bound is still above `first` after the first scan:
 // k_ransac_scan appends those pairs to a work list and a fixed grid walks (pair, 16-hypothesis chunk) items, so the common
 // case "nothing left to do" costs a handful of workgroups that exit immediately.  chunks = 64-hypothesis chunks per pair
 // (the unit of the roots / score kernels' sub-items): four 16-hypothesis items each.
-__global__ __launch_bounds__(64) void k_ransac_hyp_list(PoseParams P, int h0, int h_end, int npairs,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_ransac_hyp_list(PoseParams P, int h0, int h_end, int npairs,
                                                         const double* __restrict__ n1, const double* __restrict__ n2,
                                                         const int32_t* __restrict__ samples, const int32_t* __restrict__ rstate,
                                                         double* __restrict__ hyp, size_t S,
@@ -550,9 +560,11 @@ __global__ __launch_bounds__(64) void k_ransac_hyp_list(PoseParams P, int h0, in
     double* ldsM = reinterpret_cast<double*>(smem);
     const int per_pair = chunks * (64 / QH);
     const int total = worklist[0] * per_pair;
-    for (int wi = blockIdx.x; wi < total; wi += gridDim.x)
-        ransac_hyp_quad(P, worklist[1 + wi / per_pair], h0 + (wi % per_pair) * QH, h_end, npairs, n1, n2, samples, rstate, hyp, S,
-                        ldsM, ldsM + 200 * QH);
+    for (int wi = blockIdx.x; wi < total; wi += gridDim.x) {
+        const int pair = __builtin_amdgcn_readfirstlane(worklist[1 + wi / per_pair]);      // wave-uniform: keep them in SGPRs
+        const int hb = __builtin_amdgcn_readfirstlane(h0 + (wi % per_pair) * QH);
+        ransac_hyp_quad(P, pair, hb, h_end, npairs, n1, n2, samples, rstate, hyp, S, ldsM, ldsM + HYP_STAGE * QH);
+    }
 }
 
 // ---- sub-items: 16 consecutive hypotheses of one pair.  First chunk (worklist == nullptr): sub = pair, h in [0, 16).
@@ -628,50 +640,34 @@ DEV void roots_level(const double (&c)[11], double B, int j, int gshift, double*
     HYP_SYNC();
 }
 
-// the same level for a polynomial whose degree is only known at run time (the degree-10 coefficient vanished):
-// q is padded with zeros up to degree 10 -- Horner started on leading zeros reproduces the degree-d Horner chain
-// bit for bit (0*m + q[d] == q[d]) -- and its coefficients come from the group's LDS copy of c.
-DEV void roots_level_rt(const double* cl, int deg, int d, double B, int j, int gshift, double* prev, int& nprev) {
-    const int k = deg - d;
-    double q[11];
+// Polynomials whose degree-10 coefficient vanished (record flag 2; S-752's planar, purely translating scenes produce one in every
+// tenth 64-hypothesis item) take the SAME fixed-degree levels: oracle/pose.cpp real_roots() drops the leading coefficients below
+// 1e-15 and works on degree deg = 10 - s.  With those coefficients set to exactly 0 the template's level D = d + s IS the reduced
+// polynomial's level d -- the same derivative order 10 - D = deg - d, the same coefficients, a Horner chain that starts on zeros
+// (0 * m + q[d] == q[d] bit for bit), 200 bisection steps on the last level and 40 on the others -- and the levels D <= s see a
+// constant or the zero polynomial: no sign change, no roots, which is the state level d = 1 starts from.  Only the root bound B
+// differs (coefficients relative to c[deg]).  Returns B; c is modified in place.
+DEV double poly_prepare(double (&c)[11], int flag) {
+    int deg = 10;
+    if (flag == 2) {
 #pragma unroll
-    for (int i = 0; i <= 10; i++) {
-        double f = 1.0;
-        for (int jj = 0; jj < k; jj++) f *= (double)(i + k - jj);
-        q[i] = i <= d ? cl[min(i + k, 10)] * f : 0.0;
+        for (int i = 10; i >= 1; i--) if (deg == i && fabs(c[i]) < 1e-15) deg = i - 1;
     }
-    const bool mine = j < d && j <= nprev;
-    double lo = (j == 0) ? -B : prev[j > 0 ? (j <= 10 ? j - 1 : 9) : 0];
-    double hi = (j == nprev) ? B : prev[j < 10 ? j : 9];
-    double flo = q[10], fhi = q[10];
+    double cd = c[10];
 #pragma unroll
-    for (int i = 9; i >= 0; i--) { flo = flo * lo + q[i]; fhi = fhi * hi + q[i]; }
-    const bool neg = flo < 0;
-    const unsigned long long negmask = ~__builtin_amdgcn_ballot_w64(neg);
-    const bool act = mine && ((flo < 0) != (fhi < 0));
-    const int nit = d == deg ? BISECT_FINAL : BISECT_INNER;
-    for (int it = 0; it < nit; it++) {
-        const double m = 0.5 * (lo + hi);
-        double fm = q[10];
+    for (int i = 9; i >= 0; i--) cd = (deg == i) ? c[i] : cd;
 #pragma unroll
-        for (int i = 9; i >= 0; i--) fm = fm * m + q[i];
-        BISECT_STEP(act)
-    }
-    const double r = 0.5 * (lo + hi);
-    const uint32_t mask = (uint32_t)(__builtin_amdgcn_ballot_w64(act) >> gshift) & 0xFFFFu;
-    HYP_SYNC();
-    if (act) prev[__popc(mask & ((1u << j) - 1u))] = r;
-    nprev = __popc(mask);
-    HYP_SYNC();
+    for (int i = 1; i <= 10; i++) c[i] = (i > deg) ? 0.0 : c[i];
+    double B = 0;
+#pragma unroll
+    for (int i = 0; i < 10; i++) { const double t = fabs(c[i] / cd); B = (i < deg) ? fmax(B, t) : B; }
+    return B + 1.0;
 }
 
 // real roots of every hypothesis polynomial: 16 lanes per hypothesis, 16 hypotheses (one sub-item) per block
-// only_reduced != 0: handle only the (rare) polynomials whose degree-10 coefficient vanished; k_hyp_roots_lane did the others
 __global__ __launch_bounds__(256) void k_hyp_roots(PoseParams P, int h0, int h_end, int npairs, const int32_t* __restrict__ rstate,
-                                                   double* __restrict__ hyp, size_t S, const int32_t* __restrict__ worklist, int chunks,
-                                                   int only_reduced) {
+                                                   double* __restrict__ hyp, size_t S, const int32_t* __restrict__ worklist, int chunks) {
     __shared__ double sh_prev[16][10];
-    __shared__ double sh_c[16][11];
     const int g = threadIdx.x >> 4, j = threadIdx.x & 15, gshift = (threadIdx.x & 63) & ~15;
     for (int sub = blockIdx.x; ; sub += gridDim.x) {
         int pair, hbase;
@@ -682,57 +678,23 @@ __global__ __launch_bounds__(256) void k_hyp_roots(PoseParams P, int h0, int h_e
         int32_t* flags = reinterpret_cast<int32_t*>(hyp + (size_t)HR_DOUBLES * S);
         int32_t* nrs = flags + S;
         const int flag = active ? flags[slot] : 0;
-        if (only_reduced && !__any(flag == 2)) { if (!worklist) return; continue; }     // nothing of reduced degree in this wave: no loads
         double c[11];
 #pragma unroll
         for (int i = 0; i <= 10; i++) c[i] = flag ? hyp[slot + (size_t)i * S] : (i == 10 ? 1.0 : 0.0);
         double* prev = sh_prev[g];
         int np = 0;
-        if (!only_reduced && __any(flag == 1)) {
-            double B = 0;
-#pragma unroll
-            for (int i = 0; i < 10; i++) B = fmax(B, fabs(c[i] / c[10]));
-            B += 1.0;
-            if (flag != 1) B = 1.0;                                // lanes of other groups: keep the arithmetic finite, results unused
+        if (__any(flag != 0)) {
+            const double B = poly_prepare(c, flag);                // groups without a model: c = x^10, B = 1, results unused
             roots_level<1>(c, B, j, gshift, prev, np); roots_level<2>(c, B, j, gshift, prev, np);
             roots_level<3>(c, B, j, gshift, prev, np); roots_level<4>(c, B, j, gshift, prev, np);
             roots_level<5>(c, B, j, gshift, prev, np); roots_level<6>(c, B, j, gshift, prev, np);
             roots_level<7>(c, B, j, gshift, prev, np); roots_level<8>(c, B, j, gshift, prev, np);
             roots_level<9>(c, B, j, gshift, prev, np); roots_level<10>(c, B, j, gshift, prev, np);
         }
-        if (only_reduced) { }
-        else if (flag == 1) {
+        if (flag) {
             if (j < np) hyp[slot + (size_t)(HR_ROOTS + j) * S] = prev[j];
             if (j == 0) nrs[slot] = np;
-        } else if (active && flag == 0 && j == 0) nrs[slot] = 0;
-        if (__any(flag == 2)) {                                    // rare: the degree-10 coefficient vanished somewhere in this wave
-            double* cl = sh_c[g];
-            if (j == 0) {
-#pragma unroll
-                for (int i = 0; i <= 10; i++) cl[i] = c[i];
-            }
-            HYP_SYNC();
-            int deg = 10;
-            while (deg > 0 && fabs(cl[deg]) < 1e-15) deg--;
-            if (flag != 2) deg = 0;
-            double B = 0;
-            for (int i = 0; i < deg; i++) B = fmax(B, fabs(cl[i] / cl[deg]));
-            B += 1.0;
-            int degmax = deg;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) degmax = max(degmax, __shfl_xor(degmax, o));
-            int nq = 0;
-            for (int d = 1; d <= degmax; d++) {
-                // groups of lower degree idle through the extra levels (d > deg: no interval is theirs)
-                int np2 = nq;
-                roots_level_rt(cl, deg, d <= deg ? d : 0, B, d <= deg ? j : 16, gshift, prev, np2);
-                if (d <= deg) nq = np2;
-            }
-            if (flag == 2) {
-                if (j < nq) hyp[slot + (size_t)(HR_ROOTS + j) * S] = prev[j];
-                if (j == 0) nrs[slot] = nq;
-            }
-        }
+        } else if (active && j == 0) nrs[slot] = 0;
         HYP_SYNC();
         if (!worklist) return;
     }
@@ -813,23 +775,20 @@ __global__ __launch_bounds__(256) void k_hyp_roots_lane(PoseParams P, int h0, in
         const int flag = active ? flags[slot] : 0;
         double c[11];
 #pragma unroll
-        for (int i = 0; i <= 10; i++) c[i] = flag == 1 ? hyp[slot + (size_t)i * S] : (i == 10 ? 1.0 : 0.0);
+        for (int i = 0; i <= 10; i++) c[i] = flag ? hyp[slot + (size_t)i * S] : (i == 10 ? 1.0 : 0.0);
         int np = 0;
-        if (__any(flag == 1)) {
-            double B = 0;
-#pragma unroll
-            for (int i = 0; i < 10; i++) B = fmax(B, fabs(c[i] / c[10]));
-            B += 1.0;
+        if (__any(flag != 0)) {
+            const double B = poly_prepare(c, flag);
             roots_level_lane<1>(c, B, prev, lane, np); roots_level_lane<2>(c, B, prev, lane, np);
             roots_level_lane<3>(c, B, prev, lane, np); roots_level_lane<4>(c, B, prev, lane, np);
             roots_level_lane<5>(c, B, prev, lane, np); roots_level_lane<6>(c, B, prev, lane, np);
             roots_level_lane<7>(c, B, prev, lane, np); roots_level_lane<8>(c, B, prev, lane, np);
             roots_level_lane<9>(c, B, prev, lane, np); roots_level_lane<10>(c, B, prev, lane, np);
         }
-        if (flag == 1) {
+        if (flag) {
             for (int j = 0; j < np; j++) hyp[slot + (size_t)(HR_ROOTS + j) * S] = prev[j][lane];
             nrs[slot] = np;
-        } else if (active && flag == 0) nrs[slot] = 0;
+        } else if (active) nrs[slot] = 0;
     }
 }
 
@@ -1285,26 +1244,22 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
         HIPCHK(ctx, hipMemsetAsync(d_worklist, 0, sizeof(int32_t), st));
         hipLaunchKernelGGL(k_ransac_hyp, dim3((first + QH - 1) / QH, npairs), dim3(64), HYP_LDS_BYTES, st, P, 0, first, npairs, d_n1, d_n2,
                            d_samples, d_rstate, d_hyp, S);
-        hipLaunchKernelGGL(k_hyp_roots, dim3(npairs), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_hyp, S, (const int32_t*)nullptr, 0, 0);
+        hipLaunchKernelGGL(k_hyp_roots, dim3(npairs), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_hyp, S, (const int32_t*)nullptr, 0);
         hipLaunchKernelGGL(k_hyp_score, dim3(npairs), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_n1, d_n2, d_hyp, S, d_models,
                            d_counts, (const int32_t*)nullptr, 0);
         hipLaunchKernelGGL(k_ransac_scan, dim3(npairs), dim3(64), 0, st, P, first, d_counts, d_rstate, d_worklist);
         if (max_iters > first) {
             const int chunks = (max_iters - first + 63) / 64;
-            const int nb = (int)std::min<long long>(256 * 10, (long long)npairs * chunks * (64 / QH));    // five 30-KB waves per CU, two rounds
+            const int nb = (int)std::min<long long>(256 * 16, (long long)npairs * chunks * (64 / QH));    // eight waves per CU (two per SIMD: 256 VGPRs), two rounds
             const int nsub = (int)std::min<long long>(2048, (long long)npairs * chunks * 4);
             hipLaunchKernelGGL(k_ransac_hyp_list, dim3(nb), dim3(64), HYP_LDS_BYTES, st, P, first, max_iters,
                                npairs, d_n1, d_n2, d_samples, d_rstate, d_hyp, S, (const int32_t*)d_worklist, chunks);
             if (roots16)
                 hipLaunchKernelGGL(k_hyp_roots, dim3(nsub), dim3(256), 0, st, P, first, max_iters, npairs, d_rstate, d_hyp, S,
-                                   (const int32_t*)d_worklist, chunks, 0);
-            else {
-                // one hypothesis per lane; the rare polynomials of reduced degree go through the 16-lane kernel afterwards
+                                   (const int32_t*)d_worklist, chunks);
+            else           // one hypothesis per lane
                 hipLaunchKernelGGL(k_hyp_roots_lane, dim3(std::min(2048, (npairs * chunks + 3) / 4)), dim3(256), 0, st, P, first, max_iters, d_rstate,
                                    d_hyp, S, (const int32_t*)d_worklist, chunks);
-                hipLaunchKernelGGL(k_hyp_roots, dim3(nsub), dim3(256), 0, st, P, first, max_iters, npairs, d_rstate, d_hyp, S,
-                                   (const int32_t*)d_worklist, chunks, 1);
-            }
             hipLaunchKernelGGL(k_hyp_score, dim3(nsub), dim3(256), 0, st, P, first, max_iters, npairs, d_rstate, d_n1, d_n2, d_hyp, S,
                                d_models, d_counts, (const int32_t*)d_worklist, chunks);
             hipLaunchKernelGGL(k_ransac_scan, dim3(npairs), dim3(64), 0, st, P, max_iters, d_counts, d_rstate, (int32_t*)nullptr);
