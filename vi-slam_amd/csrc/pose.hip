@@ -792,6 +792,80 @@ __global__ __launch_bounds__(256) void k_hyp_roots_lane(PoseParams P, int h0, in
     }
 }
 
+// Candidate essential matrices of every hypothesis: ONE HYPOTHESIS PER LANE, the lane walks over its real roots in ascending order
+// and back-substitutes each (oracle/pose.cpp five_point(), the part after the roots).  A flat grid without LDS or barriers: the record
+// fields of 64 consecutive hypotheses are 512 contiguous bytes per load.  (As the prologue of k_hyp_score -- thread = (hypothesis,
+// root), 16 hypotheses per workgroup, the whole chain in front of three barriers -- this part took 0.7 of that kernel's 0.97 ms.)
+// Valid models go to models[slot][m] in root order; the record's root-count word is overwritten by the number of valid models.
+__global__ __launch_bounds__(256) void k_hyp_models(PoseParams P, int h0, int h_end, int npairs, const int32_t* __restrict__ rstate,
+                                                    double* __restrict__ hyp, size_t S, double* __restrict__ models,
+                                                    const int32_t* __restrict__ worklist, int chunks) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int32_t* nrs = reinterpret_cast<int32_t*>(hyp + (size_t)HR_DOUBLES * S) + S;
+    const int total = worklist ? worklist[0] * chunks : (npairs + 3) / 4;      // items: 64 hypotheses of one pair / 16 of each of four pairs
+    for (int item = blockIdx.x * 4 + wv; item < total; item += gridDim.x * 4) {
+        int pair, h;
+        if (worklist) { pair = worklist[1 + item / chunks]; h = h0 + (item % chunks) * 64 + lane; }
+        else { pair = item * 4 + (lane >> 4); h = h0 + (lane & 15); }
+        const bool active = pair < npairs && h < rstate[(size_t)min(pair, npairs - 1) * RS] && h < h_end && h < max(P.max_iters, 1);
+        if (!active) continue;
+        const size_t slot = (size_t)pair * P.max_iters + h;
+        const int nr = nrs[slot];
+        int m = 0;
+        if (nr > 0) {
+            const double* rec = hyp + slot;
+            double cf[39], lb[36];
+#pragma unroll
+            for (int i = 0; i < 39; i++) cf[i] = rec[(size_t)(HR_BX + i) * S];          // Bx[3][4], By[3][4], B1[3][5]
+#pragma unroll
+            for (int i = 0; i < 36; i++) lb[i] = rec[(size_t)(HR_LB + i) * S];
+            double* mo = models + slot * 90;
+            for (int ri = 0; ri < nr; ri++) {
+                const double z = rec[(size_t)(HR_ROOTS + ri) * S];
+                double Bz[3][3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    double v = cf[4 * i + 3];
+#pragma unroll
+                    for (int k = 2; k >= 0; k--) v = v * z + cf[4 * i + k];
+                    Bz[i][0] = v;
+                    v = cf[12 + 4 * i + 3];
+#pragma unroll
+                    for (int k = 2; k >= 0; k--) v = v * z + cf[12 + 4 * i + k];
+                    Bz[i][1] = v;
+                    v = cf[24 + 5 * i + 4];
+#pragma unroll
+                    for (int k = 3; k >= 0; k--) v = v * z + cf[24 + 5 * i + k];
+                    Bz[i][2] = v;
+                }
+                double c01[3], c02[3], c12[3];
+                cross3(Bz[0], Bz[1], c01); cross3(Bz[0], Bz[2], c02); cross3(Bz[1], Bz[2], c12);
+                const double n01 = dot3(c01, c01), n02 = dot3(c02, c02), n12 = dot3(c12, c12);
+                double nv0 = c01[0], nv1 = c01[1], nv2 = c01[2], nn = n01;
+                if (n02 > nn) { nv0 = c02[0]; nv1 = c02[1]; nv2 = c02[2]; nn = n02; }
+                if (n12 > nn) { nv0 = c12[0]; nv1 = c12[1]; nv2 = c12[2]; nn = n12; }
+                if (!(nn > 0)) continue;
+                const double inv = 1.0 / sqrt(nn);
+                const double w = nv2 * inv;
+                if (fabs(w) < 1e-10) continue;
+                const double x = (nv0 * inv) / w, y = (nv1 * inv) / w;
+                double E[9], fn = 0;
+#pragma unroll
+                for (int i = 0; i < 9; i++) {
+                    E[i] = ((x * lb[i] + y * lb[9 + i]) + z * lb[18 + i]) + lb[27 + i];
+                    fn += E[i] * E[i];
+                }
+                fn = sqrt(fn);
+                if (!(fn > 0)) continue;
+#pragma unroll
+                for (int i = 0; i < 9; i++) mo[9 * m + i] = E[i] / fn;
+                m++;
+            }
+        }
+        nrs[slot] = m;                                             // from here on: the number of candidate models
+    }
+}
+
 // models + scores of one sub-item (16 hypotheses of one pair): thread (hyp, root) back-substitutes its root, the
 // 256 threads then score every model of the sub-item against the pair's points (wave = model, lanes = points),
 // and thread hyp picks the first model with the largest count.  hbest[pair][h] = (best count << 4) | model, -1 = none.
@@ -799,11 +873,11 @@ __global__ __launch_bounds__(256) void k_hyp_roots_lane(PoseParams P, int h0, in
 // rstate is read (words 0, 6) AND written (word 8, the models-scored counter) here: a plain pointer, no const / __restrict__ promise
 __global__ __launch_bounds__(256) void k_hyp_score(PoseParams P, int h0, int h_end, int npairs, int32_t* rstate,
                                                    const double* __restrict__ n1, const double* __restrict__ n2,
-                                                   const double* __restrict__ hyp, size_t S, double* __restrict__ models,
+                                                   const double* __restrict__ hyp, size_t S, const double* __restrict__ models,
                                                    int32_t* __restrict__ hbest, const int32_t* __restrict__ worklist, int chunks) {
     __shared__ double sE[160][9];
     __shared__ double sX1[SC_CH], sY1[SC_CH], sX2[SC_CH], sY2[SC_CH];
-    __shared__ int32_t sValid[16][10], sBase[16], sCnt[16], sTag[160], sGood[160], sTotal;
+    __shared__ int32_t sBase[16], sCnt[16], sTag[160], sGood[160], sTotal;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float thr2 = (float)(P.thr * P.thr);
     // division-free classification of (float)(num/den) <= thr2: mid = the double half way between thr2 and the next
@@ -815,68 +889,11 @@ __global__ __launch_bounds__(256) void k_hyp_score(PoseParams P, int h0, int h_e
         int pair, hbase;
         if (!sub_item(worklist, chunks, h0, npairs, sub, pair, hbase)) return;
         const int niters = rstate[(size_t)pair * RS], M = rstate[(size_t)pair * RS + 6];
-        const int32_t* nrs = reinterpret_cast<const int32_t*>(hyp + (size_t)HR_DOUBLES * S) + S;
-        // ---- (hyp, root) threads: back-substitution
-        const int hy = tid / 10, ri = tid - hy * 10;
-        bool valid = false;
-        double E[9];
-        if (tid < 160) {
-            const int h = hbase + hy;
+        const int32_t* nmod = reinterpret_cast<const int32_t*>(hyp + (size_t)HR_DOUBLES * S) + S;    // models per hypothesis (k_hyp_models)
+        if (tid < 16) {
+            const int h = hbase + tid;
             const bool active = h < niters && h < h_end && h < max(P.max_iters, 1);
-            const size_t slot = (size_t)pair * P.max_iters + h;
-            if (active && ri < nrs[slot]) {
-                const double* rec = hyp + slot;
-                const double z = rec[(size_t)(HR_ROOTS + ri) * S];
-                double Bz[3][3];
-#pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    double v = rec[(size_t)(HR_BX + 4 * i + 3) * S];
-#pragma unroll
-                    for (int k = 2; k >= 0; k--) v = v * z + rec[(size_t)(HR_BX + 4 * i + k) * S];
-                    Bz[i][0] = v;
-                    v = rec[(size_t)(HR_BY + 4 * i + 3) * S];
-#pragma unroll
-                    for (int k = 2; k >= 0; k--) v = v * z + rec[(size_t)(HR_BY + 4 * i + k) * S];
-                    Bz[i][1] = v;
-                    v = rec[(size_t)(HR_B1 + 5 * i + 4) * S];
-#pragma unroll
-                    for (int k = 3; k >= 0; k--) v = v * z + rec[(size_t)(HR_B1 + 5 * i + k) * S];
-                    Bz[i][2] = v;
-                }
-                double c01[3], c02[3], c12[3];
-                cross3(Bz[0], Bz[1], c01); cross3(Bz[0], Bz[2], c02); cross3(Bz[1], Bz[2], c12);
-                const double n01 = dot3(c01, c01), n02 = dot3(c02, c02), n12 = dot3(c12, c12);
-                double nv0 = c01[0], nv1 = c01[1], nv2 = c01[2], nn = n01;
-                if (n02 > nn) { nv0 = c02[0]; nv1 = c02[1]; nv2 = c02[2]; nn = n02; }
-                if (n12 > nn) { nv0 = c12[0]; nv1 = c12[1]; nv2 = c12[2]; nn = n12; }
-                if (nn > 0) {
-                    const double inv = 1.0 / sqrt(nn);
-                    const double w = nv2 * inv;
-                    if (!(fabs(w) < 1e-10)) {
-                        const double x = (nv0 * inv) / w, y = (nv1 * inv) / w;
-                        double fn = 0;
-#pragma unroll
-                        for (int i = 0; i < 9; i++) {
-                            E[i] = ((x * rec[(size_t)(HR_LB + i) * S] + y * rec[(size_t)(HR_LB + 9 + i) * S]) + z * rec[(size_t)(HR_LB + 18 + i) * S]) +
-                                   rec[(size_t)(HR_LB + 27 + i) * S];
-                            fn += E[i] * E[i];
-                        }
-                        fn = sqrt(fn);
-                        if (fn > 0) {
-#pragma unroll
-                            for (int i = 0; i < 9; i++) E[i] = E[i] / fn;
-                            valid = true;
-                        }
-                    }
-                }
-            }
-            sValid[hy][ri] = valid ? 1 : 0;
-        }
-        __syncthreads();
-        if (tid < 16) {                                            // models per hypothesis and their base in the sub-item's list
-            int c = 0;
-            for (int r = 0; r < 10; r++) c += sValid[tid][r];
-            sCnt[tid] = c;
+            sCnt[tid] = active ? nmod[(size_t)pair * P.max_iters + h] : 0;
         }
         __syncthreads();
         if (tid == 0) {
@@ -884,14 +901,15 @@ __global__ __launch_bounds__(256) void k_hyp_score(PoseParams P, int h0, int h_e
             if (t) atomicAdd(rstate + (size_t)pair * RS + 8, t);   // point evaluations = models x M
         }
         __syncthreads();
-        if (valid) {
-            int m = 0;
-            for (int r = 0; r < ri; r++) m += sValid[hy][r];       // model index = rank among the hypothesis' valid roots
-            const int t = sBase[hy] + m;
-            double* mo = models + ((size_t)pair * P.max_iters + hbase + hy) * 90 + 9 * m;
+        {
+            const int hy = tid / 10, m = tid - hy * 10;            // thread = (hypothesis, model): the sub-item's model list in LDS
+            if (tid < 160 && m < sCnt[hy]) {
+                const int t = sBase[hy] + m;
+                const double* mo = models + ((size_t)pair * P.max_iters + hbase + hy) * 90 + 9 * m;
 #pragma unroll
-            for (int k = 0; k < 9; k++) { mo[k] = E[k]; sE[t][k] = E[k]; }
-            sTag[t] = (hy << 4) | m; sGood[t] = 0;
+                for (int k = 0; k < 9; k++) sE[t][k] = mo[k];
+                sTag[t] = (hy << 4) | m; sGood[t] = 0;
+            }
         }
         const int T = sTotal;
         const double* pa = n1 + (size_t)pair * P.mcap * 2;
@@ -1245,6 +1263,7 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
         hipLaunchKernelGGL(k_ransac_hyp, dim3((first + QH - 1) / QH, npairs), dim3(64), HYP_LDS_BYTES, st, P, 0, first, npairs, d_n1, d_n2,
                            d_samples, d_rstate, d_hyp, S);
         hipLaunchKernelGGL(k_hyp_roots, dim3(npairs), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_hyp, S, (const int32_t*)nullptr, 0);
+        hipLaunchKernelGGL(k_hyp_models, dim3((npairs + 15) / 16), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_hyp, S, d_models, (const int32_t*)nullptr, 0);
         hipLaunchKernelGGL(k_hyp_score, dim3(npairs), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_n1, d_n2, d_hyp, S, d_models,
                            d_counts, (const int32_t*)nullptr, 0);
         hipLaunchKernelGGL(k_ransac_scan, dim3(npairs), dim3(64), 0, st, P, first, d_counts, d_rstate, d_worklist);
@@ -1260,6 +1279,8 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
             else           // one hypothesis per lane
                 hipLaunchKernelGGL(k_hyp_roots_lane, dim3(std::min(2048, (npairs * chunks + 3) / 4)), dim3(256), 0, st, P, first, max_iters, d_rstate,
                                    d_hyp, S, (const int32_t*)d_worklist, chunks);
+            hipLaunchKernelGGL(k_hyp_models, dim3(std::min(4096, (npairs * chunks + 3) / 4)), dim3(256), 0, st, P, first, max_iters, npairs, d_rstate,
+                               d_hyp, S, d_models, (const int32_t*)d_worklist, chunks);
             hipLaunchKernelGGL(k_hyp_score, dim3(nsub), dim3(256), 0, st, P, first, max_iters, npairs, d_rstate, d_n1, d_n2, d_hyp, S,
                                d_models, d_counts, (const int32_t*)d_worklist, chunks);
             hipLaunchKernelGGL(k_ransac_scan, dim3(npairs), dim3(64), 0, st, P, max_iters, d_counts, d_rstate, (int32_t*)nullptr);
