@@ -1028,18 +1028,31 @@ __global__ __launch_bounds__(64) void k_ransac_scan(PoseParams P, int hi, const 
     int niters = rs[0], maxGood = rs[1], iter = rs[4], bi = rs[2], bm = rs[3];
     const int M = rs[6];
     const int32_t* hb = hbest + (size_t)pair * P.max_iters;
+    // 256 iterations per round (four results per lane, loaded together).  Only an ACCEPTED iteration changes the state (its count
+    // exceeds everything before it; the adaptive bound can only shrink then), so inside a 64-iteration block the walk jumps from
+    // one accepted iteration to the next by ballot instead of visiting all 64: same survivor, same bound, same iteration count.
     while (iter < niters && iter < hi) {
-        const int base = iter;
-        const int idx = base + lane;
-        const int v = (idx < hi && idx < P.max_iters) ? hb[idx] : -1;
-        for (int k = 0; k < 64 && iter < niters && iter < hi; k++, iter++) {
-            const int e = __shfl(v, k);
-            if (e < 0) continue;
-            const int good = e >> 4;
-            if (good > max(maxGood, 4)) {
-                bi = iter; bm = e & 15; maxGood = good;
-                if (P.adaptive) niters = update_num_iters(P.prob, (double)(M - good) / M, 5, niters);
+        const int base0 = iter;
+        int v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const int idx = base0 + 64 * j + lane; v[j] = (idx < hi && idx < P.max_iters) ? hb[idx] : -1; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int base = base0 + 64 * j;
+            if (!(base < niters && base < hi)) break;
+            int lim = min(niters, hi) - base;                      // iterations of this block still inside the bound (>= 1)
+            const int good_l = v[j] < 0 ? -1 : (v[j] >> 4);
+            int start = 0, last = -1;
+            for (;;) {
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(lane >= start && lane < lim && good_l > max(maxGood, 4));
+                if (!mask) break;
+                const int k = __builtin_ctzll(mask);
+                const int e = __builtin_amdgcn_readlane(v[j], k);
+                bi = base + k; bm = e & 15; maxGood = e >> 4;
+                if (P.adaptive) { niters = update_num_iters(P.prob, (double)(M - maxGood) / M, 5, niters); lim = min(niters, hi) - base; }
+                last = k; start = k + 1;
             }
+            iter = base + max(min(64, lim), last + 1);             // the sequential loop leaves one past the last iteration it ran
         }
     }
     if (lane == 0) {
