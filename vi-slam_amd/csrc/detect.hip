@@ -63,7 +63,7 @@ __device__ __forceinline__ void resize_coef(int d, double scale, int slen, int& 
 }
 
 #ifndef RS_ROWS
-#define RS_ROWS 10           // destination rows per thread: the column coefficients are computed once per thread
+#define RS_ROWS 5            // destination rows per thread (10: 110 VGPRs = 4 waves per SIMD and 0.49 ms for the pyramid of 1024 frames; 5: 63 VGPRs = 8 waves, 0.455 ms)
 #endif
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
@@ -72,10 +72,10 @@ typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 // Loads + arithmetic of the RS_ROWS destination rows of a thread for a COMPILE-TIME row-sharing pattern SHARE (bit r: destination
 // row r's first source row is the second source row of row r - 1).  Consecutive destination rows share a source row whenever the
 // source index advances by one -- four times out of five at the pyramid's scale 1.2 -- and with the pattern known to the compiler
-// the shared row is neither loaded nor horizontally interpolated twice (12 instead of 20 loads).  A run-time pattern does not pay:
-// predicated or scalar-branched loads measured 0.66 ms for the pyramid of 1024 frames against 0.62 without any sharing and 0.51
-// with a compile-time pattern -- so k_resize tests the wave's pattern against the ten that occur at scale 1.2 and falls back to
-// SHARE = 0 (everything loaded) for any other wave.  Same values in every case.
+// the shared row is neither loaded nor horizontally interpolated twice (6 instead of 10 loads for five rows).  A run-time pattern
+// does not pay: predicated or scalar-branched loads measured 0.66 ms for the pyramid of 1024 frames against 0.62 without any sharing
+// and 0.51 with a compile-time pattern -- so k_resize tests the wave's pattern against the ones that occur at scale 1.2 and falls
+// back to SHARE = 0 (everything loaded) for any other wave.  Same values in every case.
 template <uint32_t SHARE>
 __device__ __forceinline__ void resize_rows(const uint8_t* __restrict__ fbase, uint32_t wb, uint32_t asel, const uint32_t (&YX)[RS_ROWS], const uint32_t (&YY)[RS_ROWS],
                                             const uint4* __restrict__ yrow, const uint32_t (&sel)[4],
@@ -202,12 +202,16 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
         uint32_t share = 0;
 #pragma unroll
         for (int r = 1; r < RS_ROWS; r++) share |= (__builtin_amdgcn_ballot_w64(YX[r] != YY[r - 1]) == 0 ? 1u : 0u) << r;
-        // At scale 1.2 the source row advances by two once every five rows (ten rows: at p and p + 5).  Any pattern that is a SUBSET
-        // of the wave's is exact (an unshared row is simply loaded); the second list covers waves that straddle two row groups whose
-        // phase differs by one, so that only waves at a clamped border or of another scale load all twenty rows.
+        // At scale 1.2 the source row advances by two once every five rows (at row p of a group of five; ten rows: at p and p + 5).
+        // Any pattern that is a SUBSET of the wave's is exact (an unshared row is simply loaded); the second list covers waves that
+        // straddle two row groups whose phase differs by one, so that only waves at a clamped border or of another scale load every row.
 #define RS_CASE(M) if ((M & ~share) == 0u) { resize_rows<M>(fbase, wb, asel, YX, YY, yrow, sel, coef, dbase, dstride, dy0, dh, keep); return; }
+#if RS_ROWS == 10
         RS_CASE(0x3DEu) RS_CASE(0x3BCu) RS_CASE(0x37Au) RS_CASE(0x2F6u) RS_CASE(0x1EEu)
         RS_CASE(0x39Cu) RS_CASE(0x338u) RS_CASE(0x272u) RS_CASE(0x0E6u) RS_CASE(0x1CEu)
+#elif RS_ROWS == 5
+        RS_CASE(0x1Eu) RS_CASE(0x1Cu) RS_CASE(0x1Au) RS_CASE(0x16u) RS_CASE(0x0Eu) RS_CASE(0x18u) RS_CASE(0x12u) RS_CASE(0x06u)
+#endif
 #undef RS_CASE
         resize_rows<0u>(fbase, wb, asel, YX, YY, yrow, sel, coef, dbase, dstride, dy0, dh, keep);
         return;
