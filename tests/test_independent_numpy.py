@@ -7,6 +7,8 @@ algorithms*: a second implementation written from the definition, not from the o
   (b) five-point: numpy.roots of the degree-10 polynomial                                     vs the bisection roots
   (c) cv::resize INTER_LINEAR: float64 bilinear interpolation at the same sample positions    vs orc_resize_linear (+-1 LSB)
   (d) k_fast's SWAR pretest (vi-slam_amd/csrc/detect.hip) replayed in numpy uint32 arithmetic: it never rejects a FAST corner
+  (e) the root finder in the form the pose kernels run it (fixed levels on a zero-padded polynomial, compacted interval walk,
+      guard-free bisection steps) replayed in Python floats                                   vs the sequential algorithm, bit for bit
 """
 import numpy as np
 import pytest
@@ -199,3 +201,145 @@ def test_swar_byte_tests_exhaustive():
                         ci, ri = c1.astype(np.int64), r1.astype(np.int64)
                         assert not ((ri < ci - t) & (dbit == 0)).any(), (t, lane, oc, orr)
                         assert not ((ri > ci + t) & (nb == 1)).any(), (t, lane, oc, orr)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (e) the root finder as the HIP kernels run it (vi-slam_amd/csrc/pose.hip: poly_prepare, roots_level_lane, BISECT_STEP) against the
+#     sequential algorithm of oracle/pose.cpp real_roots(), both replayed in Python floats (IEEE double, no FMA): bit-identical roots.
+#     What the kernels do differently: (1) a polynomial whose leading coefficients vanished runs through the FIXED ten levels with
+#     those coefficients set to exactly 0, (2) the end-point signs of a level are evaluated once and a lane visits only its
+#     sign-change intervals, (3) a bisection step is taken without the "mid point strictly inside" guard (a collapsed interval makes
+#     the step a no-op) and the collapse is only looked at every eighth step.
+def _horner(q, x):
+    r = q[-1]
+    for c in q[-2::-1]:
+        r = r * x + c
+    return r
+
+
+def _roots_sequential(cin):
+    """oracle/pose.cpp real_roots(), line by line"""
+    deg = 10
+    mx = max(abs(v) for v in cin)
+    if mx == 0:
+        return []
+    c = [v / mx for v in cin]
+    while deg > 0 and abs(c[deg]) < 1e-15:
+        deg -= 1
+    if deg == 0:
+        return []
+    B = max(abs(c[i] / c[deg]) for i in range(deg)) + 1.0
+    prev = []
+    for d in range(1, deg + 1):
+        k = deg - d
+        q = []
+        for i in range(d + 1):
+            f = 1.0
+            for j in range(k):
+                f *= float(i + k - j)
+            q.append(c[i + k] * f)
+        cur = []
+        for j in range(len(prev) + 1):
+            lo = -B if j == 0 else prev[j - 1]
+            hi = B if j == len(prev) else prev[j]
+            flo, fhi = _horner(q, lo), _horner(q, hi)
+            if (flo < 0) == (fhi < 0):
+                continue
+            for _ in range(200 if d == deg else 40):
+                m = 0.5 * (lo + hi)
+                if m <= lo or m >= hi:
+                    break
+                if (_horner(q, m) < 0) == (flo < 0):
+                    lo = m
+                else:
+                    hi = m
+            cur.append(0.5 * (lo + hi))
+        prev = cur
+    return prev
+
+
+def _roots_kernel_form(cin):
+    """the kernels' formulation: ten fixed levels on the zero-padded polynomial, sign pass, compacted walk, guard-free steps"""
+    mx = max(abs(v) for v in cin)
+    if mx == 0:
+        return []
+    c = [v / mx for v in cin]                                 # (the solver stores the normalised polynomial in the record)
+    deg = 10
+    for i in range(10, 0, -1):                                # poly_prepare
+        if deg == i and abs(c[i]) < 1e-15:
+            deg = i - 1
+    cd = c[deg]
+    c = [c[i] if i <= deg else 0.0 for i in range(11)]
+    B = 0.0
+    for i in range(10):
+        if i < deg:
+            B = max(B, abs(c[i] / cd))
+    B += 1.0
+    prev = []
+    for D in range(1, 11):
+        K = 10 - D
+        q = []
+        for i in range(D + 1):
+            f = 1.0
+            for jj in range(K):
+                f *= float(i + K - jj)
+            q.append(c[i + K] * f)
+        nprev = len(prev)
+        ends = [-B] + prev + [B]                              # end points 0 .. nprev + 1
+        neg = [_horner(q, x) < 0 for x in ends]
+        todo = [j for j in range(nprev + 1) if neg[j] != neg[j + 1]]
+        cur = []
+        for j in todo:
+            lo, hi = ends[j], ends[j + 1]
+            for it in range(200 if D == 10 else 40):
+                m = 0.5 * (lo + hi)
+                fm = _horner(q, m)
+                if (it & 7) == 7 and not (m > lo and m < hi):
+                    break
+                if (fm < 0) == neg[j]:
+                    lo = m
+                else:
+                    hi = m
+            cur.append(0.5 * (lo + hi))
+        prev = cur
+    return prev
+
+
+def test_root_finder_kernel_formulation_is_the_sequential_algorithm(orc):
+    rng = np.random.default_rng(77)
+    polys = []
+    for k in range(24):                                       # polynomials of the five-point solver itself (pins the Python replay to the C oracle)
+        X = np.column_stack([rng.uniform(-1, 1, 5), rng.uniform(-1, 1, 5), rng.uniform(2, 6, 5)])
+        w = rng.normal(0, 0.3, 3)
+        th = np.linalg.norm(w)
+        Kx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]) / max(th, 1e-12)
+        R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+        X2 = X @ R.T + rng.normal(0, 0.5, 3)
+        _, poly, roots = orc.five_point_poly(X[:, :2] / X[:, 2:], X2[:, :2] / X2[:, 2:])
+        if np.abs(poly).max() == 0:
+            continue
+        seq = _roots_sequential(list(poly))
+        assert seq == list(roots), k                          # the replay IS the oracle's algorithm
+        polys.append(list(poly))
+    for k in range(24):                                       # synthetic: known real roots (clustered / spread), reduced degrees, tiny leading terms
+        nreal = int(rng.integers(0, 11))
+        r = np.sort(rng.uniform(-3, 3, nreal) * (10.0 ** rng.integers(-2, 2)))
+        p = np.poly1d([1.0])
+        for x in r:
+            p *= np.poly1d([1.0, -x])
+        for _ in range((10 - nreal) // 2):
+            a, b = rng.uniform(-2, 2), rng.uniform(0.1, 2)
+            p *= np.poly1d([1.0, -2 * a, a * a + b * b])
+        c = list(p.coeffs[::-1]) + [0.0] * (10 - p.order)
+        if k % 3 == 1:
+            c[10] = 0.0 if k % 2 else 3e-17 * max(abs(v) for v in c)              # leading coefficient lost: degree 9 (or lower below)
+        if k % 6 == 5:
+            c[9] = 1e-18 * max(abs(v) for v in c)
+        polys.append([float(v) for v in c])
+    reduced = 0
+    for c in polys:
+        a, b = _roots_sequential(c), _roots_kernel_form(c)
+        assert a == b, (c, a, b)                              # bit-identical (== on floats), same count, same order
+        mx = max(abs(v) for v in c)
+        reduced += abs(c[10] / mx) < 1e-15
+    assert reduced >= 6                                       # the reduced-degree path was exercised
