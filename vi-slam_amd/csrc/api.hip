@@ -318,7 +318,7 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
     HIPCHK(ctx, hipMemset(pl->d_p2, 0, (size_t)npairs * mcap * 2 * sizeof(float)));
     HIPCHK(ctx, hipMemset(pl->d_pose, 0, (size_t)npairs * sizeof(PoseOut)));
     // cv::RNG sample tables only for small M (the reference pipeline: M <= root^2); larger M replays the stream on the device
-    { int rc2 = vis_build_sample_table(ctx, std::min(mcap, 1024)); if (rc2) { plan_destroy(pl); return rc2; } }
+    { int rc2 = vis_build_sample_table(ctx, std::min(mcap, 8192)); if (rc2) { plan_destroy(pl); return rc2; } }
     *out = pl;
     return VIS_OK;
 }
@@ -327,9 +327,12 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
 // stream depends only on (seed, M), so the per-pair sequential RNG walk is replaced by a table row.
 int vis_build_sample_table(vis_ctx* ctx, int max_m) {
     const int iters = ctx->p.ransac_max_iters;
+    // as many rows as fit in 256 MB (2000 iterations: M <= 6715, i.e. config 3's ~3100 symmetric matches come from the table; pairs with
+    // more correspondences than the table has rows replay the stream on the device, one thread per pair: 0.43 ms at M = 3100)
+    max_m = (int)std::min<size_t>((size_t)max_m, 5 + ((size_t)256 << 20) / ((size_t)std::max(iters, 1) * 20));
     if (ctx->d_sample_table && ctx->sample_max_m >= max_m && ctx->sample_iters == iters && ctx->sample_seed == ctx->p.ransac_seed) return VIS_OK;
     if (ctx->d_sample_table) { sync_all(ctx); (void)hipFree(ctx->d_sample_table); ctx->d_sample_table = nullptr; ctx->sample_max_m = 0; }
-    if (max_m < 6 || (size_t)(max_m - 5) * iters * 5 * 4 > ((size_t)256 << 20)) return VIS_OK;     // no table: device replay
+    if (max_m < 6) return VIS_OK;                                  // no table: device replay
     std::vector<int32_t> tab((size_t)(max_m - 5) * iters * 5);
     for (int M = 6; M <= max_m; M++) {
         unsigned long long state = ctx->p.ransac_seed ? ctx->p.ransac_seed : 0xffffffffULL;

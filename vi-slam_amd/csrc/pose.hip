@@ -1024,7 +1024,13 @@ __global__ __launch_bounds__(64) void k_ransac_scan(PoseParams P, int hi, const 
                                                     int32_t* __restrict__ worklist) {
     const int pair = blockIdx.x, lane = threadIdx.x;
     int32_t* rs = rstate + (size_t)pair * RS;
-    if (rs[5] != 0) { if (rs[5] == 1 && lane == 0) { rs[2] = 0; rs[3] = 0; rs[1] = 5; rs[7] = 1; rs[4] = 1; } return; }
+    if (rs[5] != 0) {
+        if (rs[5] == 1 && lane == 0) {
+            rs[2] = 0; rs[3] = 0; rs[1] = 5; rs[7] = 1; rs[4] = 1;
+            if (worklist && hi == 0) worklist[1 + atomicAdd(&worklist[0], 1)] = pair;     // no first chunk ran: its one hypothesis is still to be solved
+        }
+        return;
+    }
     int niters = rs[0], maxGood = rs[1], iter = rs[4], bi = rs[2], bm = rs[3];
     const int M = rs[6];
     const int32_t* hb = hbest + (size_t)pair * P.max_iters;
@@ -1270,15 +1276,19 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
         const int first_chunk = 16;
         const bool roots16 = false;
 #endif
-        const int first = std::min(ctx->p.ransac_adaptive ? first_chunk : 16, std::max(max_iters, 1));
+        // adaptive runs: the first 16 hypotheses of every pair, then only the pairs whose bound is still above 16 (work list).  With
+        // the adaptive stop off every pair needs every hypothesis: no first chunk, the first scan (hi = 0) only builds the work list.
+        const int first = ctx->p.ransac_adaptive ? std::min(first_chunk, std::max(max_iters, 1)) : 0;
         const size_t S = (size_t)npairs * max_iters;
         HIPCHK(ctx, hipMemsetAsync(d_worklist, 0, sizeof(int32_t), st));
-        hipLaunchKernelGGL(k_ransac_hyp, dim3((first + QH - 1) / QH, npairs), dim3(64), HYP_LDS_BYTES, st, P, 0, first, npairs, d_n1, d_n2,
-                           d_samples, d_rstate, d_hyp, S);
-        hipLaunchKernelGGL(k_hyp_roots, dim3(npairs), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_hyp, S, (const int32_t*)nullptr, 0);
-        hipLaunchKernelGGL(k_hyp_models, dim3((npairs + 15) / 16), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_hyp, S, d_models, (const int32_t*)nullptr, 0);
-        hipLaunchKernelGGL(k_hyp_score, dim3(npairs), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_n1, d_n2, d_hyp, S, d_models,
-                           d_counts, (const int32_t*)nullptr, 0);
+        if (first > 0) {
+            hipLaunchKernelGGL(k_ransac_hyp, dim3((first + QH - 1) / QH, npairs), dim3(64), HYP_LDS_BYTES, st, P, 0, first, npairs, d_n1, d_n2,
+                               d_samples, d_rstate, d_hyp, S);
+            hipLaunchKernelGGL(k_hyp_roots, dim3(npairs), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_hyp, S, (const int32_t*)nullptr, 0);
+            hipLaunchKernelGGL(k_hyp_models, dim3((npairs + 15) / 16), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_hyp, S, d_models, (const int32_t*)nullptr, 0);
+            hipLaunchKernelGGL(k_hyp_score, dim3(npairs), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_n1, d_n2, d_hyp, S, d_models,
+                               d_counts, (const int32_t*)nullptr, 0);
+        }
         hipLaunchKernelGGL(k_ransac_scan, dim3(npairs), dim3(64), 0, st, P, first, d_counts, d_rstate, d_worklist);
         if (max_iters > first) {
             const int chunks = (max_iters - first + 63) / 64;
