@@ -69,39 +69,46 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ desc, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// MFMA formulation of the same 2-NN (default path).  Every hot kernel of this library is bound by the
-// integer VALU issue rate (~0.62 T wave-instructions/s measured, tools/valu_peak.hip); the matrix pipe is
-// idle.  With descriptor bits expanded to int8 +64/-64, sum_k a_k b_k = 4096 * (256 - 2*Hamming), so one
-// v_mfma_i32_32x32x32_i8 chain (K = 256 = 8 instructions) yields a 32 x 32 block of exact distances -- already in
-// key form, because the chain starts from the (tile, register) index in the 13 free low bits -- and the VALU only
-// maintains the top-2 keys: 2 instructions (v_med3_i32, v_min_i32) per distance instead of 19.
-// Columns (lane & 31) = the 32 descriptors whose neighbours this wave tracks (B operand, in registers);
-// rows = the swept set, staged through LDS 32 descriptors at a time (row stride 272 B: conflict-free
-// ds_read_b128).  Results are bit-identical to k_knn2 (same key order): tests/test_match_gpu.py.
+// MFMA formulation of the same 2-NN (default path).  Every hot kernel of this library is bound by the integer VALU issue rate
+// (~0.62 T wave-instructions/s measured, tools/valu_peak.hip); the matrix pipe is idle.  Descriptor bits become FP4 (e2m1) +1 / -1,
+// two to a byte (128 B per descriptor), and the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 multiplies them with both scales
+// at 2^6: sum_k a_k b_k = 4096 * (256 - 2*Hamming), exact in the f32 accumulator (every partial sum is an integer below 2^22).
+// gfx950 issues this instruction in the cycles of v_mfma_i32_32x32x32_i8 at twice the K (tools/mfma_f4_probe.hip: 37.6 against
+// 36.2 cycles, 8.6 against 4.5 P MAC/s), so a 32 x 32 block of exact distances is a chain of 4 instead of 8 MFMAs, on half the
+// operand bytes.  The block is already in key form, because the chain starts from 2^20 + (tile, register) index -- 8192 * Hamming
+// lands on top of the 13 free low bits -- and the VALU only maintains the top-2 keys: 2 instructions (v_med3_i32, v_min_i32 on
+// the bit patterns: non-negative floats order like integers) per distance instead of 19.
+// Columns (lane & 31) = the 32 descriptors whose neighbours this wave tracks (B operand, in registers); rows = the swept set,
+// staged through LDS 32 descriptors at a time (row stride 144 B: conflict-free ds_read_b128).  Results are bit-identical to
+// k_knn2 (same key order): tests/test_match_gpu.py.
 typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
+// 32 descriptor bits -> 32 FP4 nibbles (16 bytes): bit k of the descriptor = element k, 1 -> +1 (0x2), 0 -> -1 (0xA)
 __global__ __launch_bounds__(256) void k_expand(const uint8_t* __restrict__ desc, const int32_t* __restrict__ nkp, int kcap,
                                                 int8_t* __restrict__ X, int rec_first, int rec_count) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long dsc = gid >> 4;
-    const int part = (int)(gid & 15);
+    const long long dsc = gid >> 3;
+    const int part = (int)(gid & 7);
     const int rec_i = (int)(dsc / kcap), i = (int)(dsc - (long long)rec_i * kcap);
     if (rec_i >= rec_count) return;
     const int rec = rec_first + rec_i;
     if (i >= min(nkp[rec], kcap)) return;
-    const uint8_t* d = desc + ((size_t)rec * kcap + i) * 32 + 2 * part;
-    const uint32_t bits = (uint32_t)d[0] | ((uint32_t)d[1] << 8);
+    const uint32_t bits = *reinterpret_cast<const uint32_t*>(desc + ((size_t)rec * kcap + i) * 32 + 4 * part);
     uint32_t o[4];
 #pragma unroll
     for (int n = 0; n < 4; n++) {
-        const uint32_t spread = (((bits >> (4 * n)) & 0xFu) * 0x00204081u) & 0x01010101u;     // 4 bits -> 4 bytes of 0/1
-        o[n] = 0xC0C0C0C0u ^ (spread << 7);                                                     // 1 -> +64 (0x40), 0 -> -64 (0xC0)
+        uint32_t x = (bits >> (8 * n)) & 0xFFu;                   // 8 bits -> bit 4 k of a dword
+        x = (x | (x << 12)) & 0x000F000Fu;
+        x = (x | (x << 6)) & 0x03030303u;
+        x = (x | (x << 3)) & 0x11111111u;
+        o[n] = 0x22222222u | ((~x & 0x11111111u) << 3);          // magnitude 1, sign bit set where the descriptor bit is 0
     }
-    *reinterpret_cast<uint4*>(X + ((size_t)rec * kcap + i) * 256 + 16 * part) = make_uint4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<uint4*>(X + ((size_t)rec * kcap + i) * 128 + 16 * part) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
-#define KM_ROW 17            // uint4 per LDS row: 256 B of descriptor + 16 B pad
+#define KM_ROW 9             // uint4 per LDS row: 128 B of descriptor + 16 B pad
 __device__ __forceinline__ int imed3(int a, int b, int c) {
     int d;
     asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
@@ -109,7 +116,7 @@ __device__ __forceinline__ int imed3(int a, int b, int c) {
 }
 
 // NC = column groups of 32 fixed descriptors per wave.  NC = 2: every 16-byte LDS read of a swept row feeds two MFMA chains
-// (the LDS pipe and the staging traffic per MFMA halve, one barrier per 16 MFMAs instead of 8) at the price of 64 + 32
+// (the LDS pipe and the staging traffic per MFMA halve, one barrier per 8 MFMAs instead of 4) at the price of 32 + 32
 // operand / accumulator registers per lane.
 template <int NC>
 __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, const int32_t* __restrict__ nkp, int kcap,
@@ -133,58 +140,62 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
     const int fidx0 = fbase + wave * (32 * NC) + col;
-    v4i bf[NC][8];
+    // operand layout of the 32x32x64 FP4 form (probed with exact data): lane (r, h) holds elements k = 32 h .. 32 h + 31 of row /
+    // column r as 16 bytes, low nibble first; K step ks covers descriptor bits 64 ks .. 64 ks + 63
+    v8i bf[NC][4];
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-        const int8_t* xf = X + ((size_t)rf * kcap + min(fidx0 + 32 * c, nf - 1)) * 256 + 16 * h;
+        const int8_t* xf = X + ((size_t)rf * kcap + min(fidx0 + 32 * c, nf - 1)) * 128 + 16 * h;
 #pragma unroll
-        for (int ks = 0; ks < 8; ks++) {
-            // the fixed operand is negated (+-64 bytes: x ^ 0x80 swaps 0x40 and 0xC0), so the chain adds -dot =
+        for (int ks = 0; ks < 4; ks++) {
+            // the fixed operand is negated (x ^ 0x8 per nibble flips the FP4 sign), so the chain adds -dot =
             // 4096 * (2 * Hamming - 256) onto its start value
             const v4i x = *reinterpret_cast<const v4i*>(xf + 32 * ks);
-            bf[c][ks] = v4i{x[0] ^ (int)0x80808080, x[1] ^ (int)0x80808080, x[2] ^ (int)0x80808080, x[3] ^ (int)0x80808080};
+            bf[c][ks] = v8i{x[0] ^ (int)0x88888888, x[1] ^ (int)0x88888888, x[2] ^ (int)0x88888888, x[3] ^ (int)0x88888888, 0, 0, 0, 0};
         }
     }
-    const int8_t* xs = X + (size_t)rs * kcap * 256;
+    const int8_t* xs = X + (size_t)rs * kcap * 128;
     const int ntiles = (ns + 31) / 32;
-    // staging of the next swept tile: global loads are issued before the MFMA chain of the current tile, the LDS
-    // writes after it (the load latency is covered by the wave's own compute, not only by other waves)
-    const int st_row0 = tid >> 4, st_row1 = (tid + 256) >> 4, st_c = tid & 15;
-    uint4 pre0, pre1;
-#define STAGE_LOAD(t_) do { pre0 = *reinterpret_cast<const uint4*>(xs + (size_t)min((t_) * 32 + st_row0, ns - 1) * 256 + 16 * st_c); \
-                            pre1 = *reinterpret_cast<const uint4*>(xs + (size_t)min((t_) * 32 + st_row1, ns - 1) * 256 + 16 * st_c); } while (0)
-#define STAGE_STORE(buf_) do { tile[buf_][st_row0 * KM_ROW + st_c] = pre0; tile[buf_][st_row1 * KM_ROW + st_c] = pre1; } while (0)
-    // Descriptor bytes are +-64, so the dot products are multiples of 8192 and the 13 low bits of an accumulator are free:
-    // the chain STARTS from (tile << 4) | accumulator register, and the finished accumulator IS the running key
-    // 8192 * Hamming - 2^20 + (tile << 4 | register) -- no per-element key construction.  Inside a lane the register order
-    // is the row order, so (tile, register) breaks ties exactly like the row index; the true row index is restored before
-    // the two half-lanes of a column are merged.  Keys are signed; INT_MAX = none.
+    // staging of the next swept tile (32 rows x 128 B = one uint4 per thread): the global load is issued before the MFMA chain of
+    // the current tile, the LDS write after it (the load latency is covered by the wave's own compute, not only by other waves)
+    const int st_row = tid >> 3, st_c = tid & 7;
+    uint4 pre;
+#define STAGE_LOAD(t_) do { pre = *reinterpret_cast<const uint4*>(xs + (size_t)min((t_) * 32 + st_row, ns - 1) * 128 + 16 * st_c); } while (0)
+#define STAGE_STORE(buf_) do { tile[buf_][st_row * KM_ROW + st_c] = pre; } while (0)
+    // The dot products are multiples of 8192 after the 2^20 offset, so the 13 low bits of an accumulator are free: the chain
+    // STARTS from 2^20 + ((tile << 4) | accumulator register), and the finished accumulator IS the running key
+    // 8192 * Hamming + (tile << 4 | register) -- no per-element key construction.  Inside a lane the register order is the row
+    // order, so (tile, register) breaks ties exactly like the row index; the true row index is restored before the two
+    // half-lanes of a column are merged.  Keys are compared as the bit patterns of non-negative floats; INT_MAX = none.
     int k0[NC], k1[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) { k0[c] = 0x7FFFFFFF; k1[c] = 0x7FFFFFFF; }
-    v16i cstart = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+    v16f cstart;
+#pragma unroll
+    for (int r = 0; r < 16; r++) cstart[r] = 1048576.f + (float)r;
     if (ntiles > 0) { STAGE_LOAD(0); STAGE_STORE(0); }
     __syncthreads();
     for (int t = 0; t < ntiles; t++) {
         if (t + 1 < ntiles) STAGE_LOAD(t + 1);
         const uint4* tb = tile[t & 1] + col * KM_ROW + h;
-        v16i acc[NC];
+        v16f acc[NC];
 #pragma unroll
         for (int c = 0; c < NC; c++) acc[c] = cstart;
 #pragma unroll
-        for (int ks = 0; ks < 8; ks++) {
+        for (int ks = 0; ks < 4; ks++) {
             const uint4 au = tb[2 * ks];
-            const v4i a = {(int)au.x, (int)au.y, (int)au.z, (int)au.w};
+            const v8i a = {(int)au.x, (int)au.y, (int)au.z, (int)au.w, 0, 0, 0, 0};
 #pragma unroll
-            for (int c = 0; c < NC; c++) acc[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[c][ks], acc[c], 0, 0, 0);
+            for (int c = 0; c < NC; c++)      // cbsz = blgp = 4: FP4 e2m1 on both sides; scales 2^6 (e8m0 133): products +-4096
+                acc[c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bf[c][ks], acc[c], 4, 4, 0, 133, 0, 133);
         }
-        cstart += 16;
+        cstart += 16.f;
         if (t * 32 + 32 <= ns) {
 #pragma unroll
             for (int c = 0; c < NC; c++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const int key = acc[c][r];
+                    const int key = __float_as_int(acc[c][r]);
                     k1[c] = imed3(k0[c], k1[c], key);            // k0 <= k1: second smallest of the three
                     k0[c] = min(k0[c], key);
                 }
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, 
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int trow = toff + (r & 3) + 8 * (r >> 2);
-                    const int key = trow < ns ? acc[c][r] : 0x7FFFFFFF;
+                    const int key = trow < ns ? __float_as_int(acc[c][r]) : 0x7FFFFFFF;
                     k1[c] = imed3(k0[c], k1[c], key);
                     k0[c] = min(k0[c], key);
                 }
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, 
 #undef STAGE_STORE
     // (Hamming << 16) | row: the record format of k_filter / the popcount kernel
     auto true_key = [&](int k) -> uint32_t {
-        const uint32_t u = (uint32_t)(k + (1 << 20)), lo = u & 8191u, r = lo & 15u;
+        const uint32_t u = (uint32_t)__int_as_float(k), lo = u & 8191u, r = lo & 15u;       // the float IS the integer key (exact)
         const uint32_t row = (lo >> 4) * 32u + 4u * (uint32_t)h + (r & 3u) + 8u * (r >> 2);
         return k == 0x7FFFFFFF ? 0xFFFFFFFFu : (((u >> 13) << 16) | row);
     };
@@ -369,7 +380,7 @@ __global__ __launch_bounds__(NT) void k_filter(const vis_keypoint* __restrict__ 
 
 int launch_expand(vis_ctx* ctx, Plan* pl, int rec_first, int rec_count) {
     if (rec_count <= 0 || !pl->d_descx) return VIS_OK;
-    const long long threads = (long long)rec_count * pl->kcap * 16;
+    const long long threads = (long long)rec_count * pl->kcap * 8;
     hipLaunchKernelGGL(k_expand, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, pl->d_desc, pl->d_nkp, pl->kcap,
                        pl->d_descx, rec_first, rec_count);
     HIPCHK(ctx, hipGetLastError());
