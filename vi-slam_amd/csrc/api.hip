@@ -277,7 +277,7 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
     DALLOC(pl->d_kps, (size_t)nrec * kcap); DALLOC(pl->d_desc, (size_t)nrec * kcap * 32); DALLOC(pl->d_nkp, nrec);
     HIPCHK(ctx, hipMemset(pl->d_nkp, 0, (size_t)nrec * 4));
     HIPCHK(ctx, hipMemset(pl->d_desc, 0, (size_t)nrec * kcap * 32));
-    DALLOC(pl->d_descx, (size_t)nrec * kcap * 256);
+    DALLOC(pl->d_descx, (size_t)nrec * kcap * 128);
     for (int sidx = 0; sidx < nsets; sidx++) {
         DALLOC(pl->d_pq[sidx], npairs); DALLOC(pl->d_pt[sidx], npairs); DALLOC(pl->d_pqn[sidx], npairs);
         const int base = sidx * pl->rec_per_set;
@@ -575,7 +575,7 @@ extern "C" int vis_bf_knn2_hamming_host(vis_ctx* ctx, const uint8_t* desc_q, int
     if (n_q > 65535 || n_t > 65535) return VIS_E_INVALID;
     (void)hipSetDevice(ctx->device);
     const int kcap = std::max(std::max(n_q, n_t), 1);
-    int rc = ensure_scratch(ctx, (size_t)kcap * 32 * 2 + (size_t)kcap * 8 * 2 + (size_t)kcap * 512 + 8192);
+    int rc = ensure_scratch(ctx, (size_t)kcap * 32 * 2 + (size_t)kcap * 8 * 2 + (size_t)kcap * 256 + 8192);
     if (rc) return rc;
     Carver cv{(char*)ctx->d_scratch, 0};
     Plan tp;
@@ -583,7 +583,7 @@ extern "C" int vis_bf_knn2_hamming_host(vis_ctx* ctx, const uint8_t* desc_q, int
     tp.d_desc = cv.take<uint8_t>((size_t)kcap * 64);
     tp.d_nkp = cv.take<int32_t>(2); tp.d_pair_q = cv.take<int32_t>(1); tp.d_pair_t = cv.take<int32_t>(1);
     tp.d_knn12 = cv.take<uint32_t>((size_t)kcap * 2); tp.d_knn21 = cv.take<uint32_t>((size_t)kcap * 2);
-    tp.d_descx = cv.take<int8_t>((size_t)kcap * 512);
+    tp.d_descx = cv.take<int8_t>((size_t)kcap * 256);
     const int32_t nk[2] = {n_q, n_t}, zero = 0, one = 1;
     if (n_q) HIPCHK(ctx, hipMemcpy(tp.d_desc, desc_q, (size_t)n_q * 32, hipMemcpyHostToDevice));
     if (n_t) HIPCHK(ctx, hipMemcpy(tp.d_desc + (size_t)kcap * 32, desc_t, (size_t)n_t * 32, hipMemcpyHostToDevice));

@@ -64,7 +64,7 @@ struct Plan {
     vis_keypoint* d_kps = nullptr;           // nrec x kcap
     uint8_t* d_desc = nullptr;               // nrec x kcap x 32
     int32_t* d_nkp = nullptr;                // nrec
-    int8_t* d_descx = nullptr;               // nrec x kcap x 256: descriptor bits as int8 +64/-64 (MFMA matcher operand)
+    int8_t* d_descx = nullptr;               // nrec x kcap x 128: descriptor bits as FP4 (e2m1) +1/-1, two per byte (MFMA matcher operand)
     // pairs
     int32_t* d_pair_q = nullptr;             // npairs: query record index (-1 = no pair)
     int32_t* d_pair_t = nullptr;
