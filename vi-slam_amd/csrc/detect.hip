@@ -6,8 +6,8 @@
 // oracle/orb.cpp (tests/test_detect_gpu.py).
 //
 // Kernel chain per batch of B frames (all on one stream, no host sync):
-//   k_resize   (per level l>=1)  cv::resize INTER_LINEAR 8-bit fixed point, level l-1 -> l
-//   k_fast     (1 launch)        all levels, all frames: 128x32 tile of the emit region + halo -> LDS, packed 16-bit
+//   k_resize   (per level l>=1)  cv::resize INTER_LINEAR 8-bit fixed point, level l-1 -> l (k_resize_tab: its tables, once per plan)
+//   k_fast     (1 launch)        all levels, all frames: 128x32 tile of the emit region + halo -> LDS, byte-SWAR
 //                                pretest on every position, dense FAST-9/16 cornerScore on the survivors, 3x3 NMS +
 //                                border cull; candidates into the tile's own slot (no global atomics)
 //   k_select   (1 launch)        block per (frame,level): 256-bin score histogram = retainBest(2*quota) cut,
@@ -23,9 +23,10 @@
 #include <vector>
 
 // ------------------------------------------------------------------------------------------------
-// k_resize: one thread = 4 horizontally adjacent destination pixels (one 32-bit store).  The two source
-// rows are fetched as (unaligned) dwords covering the <= 12 source bytes the four outputs touch, the
-// coefficient tables as one 16-byte vector each; bytes are picked with v_alignbyte.
+// k_resize: one thread = 4 horizontally adjacent destination pixels (one 32-bit store) x RS_ROWS rows.  Narrow variant (every
+// ORB pyramid step): source rows as the three aligned dwords around the 8-byte window the four outputs touch, coefficient
+// records from the per-level table of k_resize_tab.  Wide variant (scale up to 3, or levels narrower than 48 px): 12-byte
+// windows as unaligned dwords, coefficients in registers, bytes picked with v_alignbyte.
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 
 // XCD-aware work mapping.  Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8), each
@@ -65,7 +66,6 @@ __device__ __forceinline__ void resize_coef(int d, double scale, int slen, int& 
 #ifndef RS_ROWS
 #define RS_ROWS 5            // destination rows per thread (10: 110 VGPRs = 4 waves per SIMD and 0.49 ms for the pyramid of 1024 frames; 5: 63 VGPRs = 8 waves, 0.455 ms)
 #endif
-typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
 typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 
