@@ -832,13 +832,7 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
     if (detect) {
         // this record set was last read by the matcher two batches ago
         if (pl->match_pending[cur]) HIPCHK(ctx, hipStreamWaitEvent(sA, ctx->ev_match_done[cur], 0));
-        if (pl->carry_from > 0) {      // previous batch's last frame -> record 0 of this set
-            const int c = pl->carry_from;
-            HIPCHK(ctx, hipMemcpyAsync(pl->d_kps + (size_t)base * pl->kcap, pl->d_kps + (size_t)c * pl->kcap, (size_t)pl->kcap * sizeof(vis_keypoint), hipMemcpyDeviceToDevice, sA));
-            HIPCHK(ctx, hipMemcpyAsync(pl->d_desc + (size_t)base * pl->kcap * 32, pl->d_desc + (size_t)c * pl->kcap * 32, (size_t)pl->kcap * 32, hipMemcpyDeviceToDevice, sA));
-            HIPCHK(ctx, hipMemcpyAsync(pl->d_nkp + base, pl->d_nkp + c, 4, hipMemcpyDeviceToDevice, sA));
-            have_prev = true;
-        }
+        if (pl->carry_from > 0) have_prev = true;      // previous batch's last frame -> record 0 of this set: copied by launch_detect's first kernel
     }
     // Camera::Update (src/Camera.cpp:63-72): the half pyramid of every frame of the batch.  Nothing of the detect chain reads it
     // and it is pure streaming work, so it runs on a stream of its own beside the (vector-ALU bound) detect kernels; the detect
@@ -864,7 +858,7 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
         pl->half_valid = true;
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[0], sA);
-    if (detect) { VisRange r_("vis: ORB detect + describe"); rc = launch_detect(ctx, pl, d_frames, n, base + 1); if (rc) return rc; }
+    if (detect) { VisRange r_("vis: ORB detect + describe"); rc = launch_detect(ctx, pl, d_frames, n, base + 1, pl->carry_from > 0 ? pl->carry_from : -1); if (rc) return rc; }
     else if (ctx->ev_ok) for (int i = 1; i <= 4; i++) (void)hipEventRecord(ctx->ev[i], sA);
     if (update_queued) HIPCHK(ctx, hipStreamWaitEvent(sA, ctx->ev_update_done, 0));
     HIPCHK(ctx, hipEventRecord(ctx->ev_detect_done, sA));

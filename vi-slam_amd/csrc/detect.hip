@@ -1076,11 +1076,38 @@ int build_fast_tiles(vis_ctx* ctx, Plan* pl) {
     return VIS_OK;
 }
 
-int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int rec0) {
+// The small clears and copies in front of a batch as ONE launch: every hipMemsetAsync / hipMemcpyAsync is a launch of its own
+// (5 us each with its gaps) on the stream that carries the detect chain -- six of them were 1 % of the step.
+struct SmallOps { uint32_t* dst[6]; const uint32_t* src[6]; uint32_t end[6]; int n; };     // job j: dwords [end[j-1], end[j]), src == nullptr: clear
+__global__ __launch_bounds__(256) void k_small_ops(SmallOps J) {
+    const uint32_t total = J.end[J.n - 1];
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        int j = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) j += (k < J.n - 1 && i >= J.end[k]) ? 1 : 0;
+        const uint32_t o = i - (j ? J.end[j - 1] : 0u);
+        J.dst[j][o] = J.src[j] ? J.src[j][o] : 0u;
+    }
+}
+
+int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int rec0, int carry_rec) {
     hipStream_t st = ctx->stream;
     const int L = pl->L;
-    HIPCHK(ctx, hipMemsetAsync(pl->d_tile_cnt, 0, sizeof(int32_t) * (size_t)pl->B * pl->total_tiles, st));
-    HIPCHK(ctx, hipMemsetAsync(pl->d_seg_cnt, 0, sizeof(int32_t) * (size_t)pl->B * L, st));
+    {
+        SmallOps J = {}; uint32_t e = 0; int k = 0;
+        auto job = [&](void* d, const void* s, size_t bytes) { J.dst[k] = (uint32_t*)d; J.src[k] = (const uint32_t*)s; e += (uint32_t)(bytes / 4); J.end[k] = e; k++; };
+        job(pl->d_tile_cnt, nullptr, sizeof(int32_t) * (size_t)pl->B * pl->total_tiles);
+        job(pl->d_seg_cnt, nullptr, sizeof(int32_t) * (size_t)pl->B * L);
+        if (pl->speculate) job(pl->d_fix, nullptr, sizeof(int32_t));
+        if (carry_rec >= 0) {          // the previous batch's last frame -> the record in front of this batch's first (rec0 - 1)
+            const size_t d = (size_t)(rec0 - 1), c = (size_t)carry_rec;
+            job(pl->d_kps + d * pl->kcap, pl->d_kps + c * pl->kcap, (size_t)pl->kcap * sizeof(vis_keypoint));
+            job(pl->d_desc + d * pl->kcap * 32, pl->d_desc + c * pl->kcap * 32, (size_t)pl->kcap * 32);
+            job(pl->d_nkp + d, pl->d_nkp + c, 4);
+        }
+        J.n = k;
+        hipLaunchKernelGGL(k_small_ops, dim3((unsigned)std::min<uint32_t>(1024u, (e + 255u) / 256u)), dim3(256), 0, st, J);
+    }
     DetLevels D; fill_det_levels(pl, d_frames, D);
     DescArgs G;
     if (!pl->d_angle_tab) {
@@ -1112,7 +1139,6 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[1], st);
     const int t_base = ctx->p.fast_threshold;
     const int32_t* tau = pl->speculate ? pl->d_tau : nullptr;            // batched streams only (see fast_tile)
-    if (pl->speculate) HIPCHK(ctx, hipMemsetAsync(pl->d_fix, 0, sizeof(int32_t), st));
     {
         hipLaunchKernelGGL(k_fast, dim3(8, pl->total_tiles, (n + 7) / 8), dim3(256), 0, st, (const FastTile*)pl->d_fast_tiles, d_frames,
                            pl->total_tiles, t_base, ctx->p.edge_threshold, pl->d_tile_cnt, n, vis_fast_stamps(), tau);
