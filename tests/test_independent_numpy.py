@@ -9,6 +9,10 @@ algorithms*: a second implementation written from the definition, not from the o
   (d) k_fast's SWAR pretest (vi-slam_amd/csrc/detect.hip) replayed in numpy uint32 arithmetic: it never rejects a FAST corner
   (e) the root finder in the form the pose kernels run it (fixed levels on a zero-padded polynomial, compacted interval walk,
       guard-free bisection steps) replayed in Python floats                                   vs the sequential algorithm, bit for bit
+  (f) BF-Hamming 2-NN from unpacked bits + stable sort                                         vs orc_knn2_hamming (exact, ties included)
+  (g) Harris response and intensity-centroid angle of the oracle's keypoints in float64        vs the oracle (2e-5 relative / 0.35 degree)
+  (h) the 8-bit Gaussian as exact int64 sums of the Q8 taps; rBRIEF descriptors re-derived from
+      the blurred level (float32 rotation, round-half-even, LSB-first packing)                 vs the oracle (exact)
 """
 import numpy as np
 import pytest
@@ -343,3 +347,108 @@ def test_root_finder_kernel_formulation_is_the_sequential_algorithm(orc):
         mx = max(abs(v) for v in c)
         reduced += abs(c[10] / mx) < 1e-15
     assert reduced >= 6                                       # the reduced-degree path was exercised
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (f) BF-Hamming 2-NN from unpacked bits with a stable sort; (g) Harris response and intensity-centroid angle of the oracle's
+#     keypoints re-derived in float64 from the pyramid; (h) the fixed-point 7x7 Gaussian against a float64 one (+-1 LSB) and the
+#     rBRIEF descriptors re-derived from the blurred level with the rotation / rounding / bit order written out here.
+def test_knn2_hamming_from_unpacked_bits(orc):
+    rng = np.random.default_rng(5)
+    d1 = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    d2 = rng.integers(0, 256, (257, 32), dtype=np.uint8)
+    d2[40] = d2[7]; d2[200] = d2[7]; d1[5] = d2[7]; d1[6] = d2[7] ^ np.uint8(1)          # exact ties and distance 0 / 1
+    o12, o21 = orc.knn2_hamming(d1, d2)
+    b1, b2 = np.unpackbits(d1, axis=1).astype(np.int16), np.unpackbits(d2, axis=1).astype(np.int16)
+    dist = (b1[:, None, :] != b2[None, :, :]).sum(-1)
+    for o, dm in ((o12, dist), (o21, dist.T)):
+        order = np.argsort(dm, axis=1, kind="stable")[:, :2]                                # ties: lowest index first
+        assert np.array_equal(o["trainIdx"], order)
+        assert np.array_equal(o["distance"], np.take_along_axis(dm, order, 1).astype(np.float32))
+        assert np.array_equal(o["queryIdx"], np.arange(len(dm))[:, None].repeat(2, 1))
+
+
+def _pattern():
+    import os
+    import re
+    txt = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vi-slam_amd", "csrc", "orb_pattern.inc")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    v = np.array([float(x.rstrip("f")) for x in re.findall(r"-?\d+(?:\.\d*)?f?", txt)], np.float32)
+    assert v.size == 1024
+    return v.reshape(256, 4)
+
+
+def test_harris_angle_and_descriptors_rederived(vislam, orc):
+    p = vislam.default_params()
+    p.nfeatures, p.nlevels, p.w_size, p.h_size = 300, 4, 320, 240
+    cv = vislam.synth_canvas(1024, 0xE0C00001)
+    img = vislam.synth_frame(cv, 9, 320, 240)
+    op = orc.Params()
+    for f, _ in p._fields_:
+        setattr(op, f, getattr(p, f))
+    kps, desc = orc.orb_detect_compute(op, img)
+    assert len(kps) > 150
+    ws, hs, sc, _ = orc.level_geometry(op, 320, 240)
+    levels = [img]
+    for l in range(1, 4):
+        levels.append(orc.resize_linear(levels[-1], int(ws[l]), int(hs[l])))
+    # (h1) fixed-point blur vs float64 Gaussian (sigma 2, 7 taps, reflect-101 border)
+    # cv::GaussianBlur on 8-bit images (OpenCV 3.2: createSeparableLinearFilter with an integer kernel, bits = 8): the float
+    # taps are rounded to Q8 one by one -- [18 34 49 55 49 34 18], sum 257, i.e. a gain of (257/256)^2 -- both passes are exact
+    # integer sums and the only rounding is the final (x + 2^15) >> 16.  Re-derived here in int64; the exact Gaussian is within
+    # that gain + half a grey level.
+    x = np.arange(7) - 3.0
+    g = np.exp(-x * x / 8.0); g /= g.sum()
+    gq = np.rint(g.astype(np.float32) * 256).astype(np.int64)
+    assert gq.tolist() == [18, 34, 49, 55, 49, 34, 18]
+    blurred = []
+    for lv in levels:
+        fb = orc.gaussian_blur7(lv)
+        pad = np.pad(lv.astype(np.int64), 3, mode="reflect")
+        hh = sum(gq[i] * pad[:, i:i + lv.shape[1]] for i in range(7))
+        vv = sum(gq[i] * hh[i:i + lv.shape[0], :] for i in range(7))
+        assert np.array_equal(fb.astype(np.int64), (vv + 32768) >> 16)
+        padf = pad.astype(np.float64)
+        he = sum(g[i] * padf[:, i:i + lv.shape[1]] for i in range(7))
+        ve = sum(g[i] * he[i:i + lv.shape[0], :] for i in range(7))
+        assert np.abs(fb - ve * (257.0 / 256.0) ** 2).max() <= 0.5 + 0.3                   # + the rounding of the individual taps
+        blurred.append(fb)
+    umax = [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    pat = _pattern()
+    bits_equal = 0
+    for k, dsc in zip(kps, desc):
+        l = int(k["octave"]); lv = levels[l].astype(np.float64); s = float(sc[l])
+        xl, yl = int(round(float(k["x"]) / s)), int(round(float(k["y"]) / s))
+        assert abs(xl * np.float32(s) - k["x"]) < 1e-3 and abs(yl * np.float32(s) - k["y"]) < 1e-3
+        # (g1) Harris, block 7, k = 0.04
+        a = b = c = 0.0
+        for dy in range(-3, 4):
+            for dx in range(-3, 4):
+                q = lv[yl + dy - 1:yl + dy + 2, xl + dx - 1:xl + dx + 2]
+                ix = (q[1, 2] - q[1, 0]) * 2 + (q[0, 2] - q[0, 0]) + (q[2, 2] - q[2, 0])
+                iy = (q[2, 1] - q[0, 1]) * 2 + (q[2, 0] - q[0, 0]) + (q[2, 2] - q[0, 2])
+                a += ix * ix; b += iy * iy; c += ix * iy
+        r = (a * b - c * c - 0.04 * (a + b) ** 2) * (1.0 / (4 * 7 * 255.0)) ** 4
+        assert abs(r - float(k["response"])) <= 2e-5 * max(abs(r), 1e-12), (r, k["response"])
+        # (g2) intensity centroid over the radius-15 disc
+        m10 = m01 = 0.0
+        for v in range(-15, 16):
+            u = np.arange(-umax[abs(v)], umax[abs(v)] + 1)
+            row = lv[yl + v, xl + u]
+            m10 += (u * row).sum(); m01 += v * row.sum()
+        ang = np.degrees(np.arctan2(m01, m10)) % 360.0
+        d = abs(ang - float(k["angle"])); d = min(d, 360.0 - d)
+        assert d < 0.35, (ang, k["angle"])                                                   # fastAtan2 is a 0.3-degree polynomial
+        # (h2) rBRIEF on the blurred level: rotate by the keypoint's angle in float32, round half to even, compare, pack LSB first
+        ar = np.float32(k["angle"]) * np.float32(np.pi / 180.0)
+        ca, sa = np.float32(np.cos(np.float64(ar))), np.float32(np.sin(np.float64(ar)))
+        bl = blurred[l]
+        def val(px, py):
+            fx = np.float32(px * ca) - np.float32(py * sa)
+            fy = np.float32(px * sa) + np.float32(py * ca)
+            return bl[yl + np.rint(fy).astype(np.int64), xl + np.rint(fx).astype(np.int64)].astype(np.int32)
+        t = (val(pat[:, 0], pat[:, 1]) < val(pat[:, 2], pat[:, 3])).astype(np.uint8)
+        mine = np.packbits(t.reshape(32, 8)[:, ::-1], axis=1).ravel()
+        bits_equal += int((np.unpackbits(mine) == np.unpackbits(dsc)).sum())
+        assert np.array_equal(mine, dsc), (int(k["octave"]), xl, yl)
+    assert bits_equal == 256 * len(kps)
