@@ -13,6 +13,7 @@ algorithms*: a second implementation written from the definition, not from the o
   (g) Harris response and intensity-centroid angle of the oracle's keypoints in float64        vs the oracle (2e-5 relative / 0.35 degree)
   (h) the 8-bit Gaussian as exact int64 sums of the Q8 taps; rBRIEF descriptors re-derived from
       the blurred level (float32 rotation, round-half-even, LSB-first packing)                 vs the oracle (exact)
+  (i) recoverPose from numpy SVDs (four candidates, DLT triangulation, cheirality vote)        vs orc_recover_pose (same winner / count, 1e-9)
 """
 import numpy as np
 import pytest
@@ -452,3 +453,68 @@ def test_harris_angle_and_descriptors_rederived(vislam, orc):
         bits_equal += int((np.unpackbits(mine) == np.unpackbits(dsc)).sum())
         assert np.array_equal(mine, dsc), (int(k["octave"]), xl, yl)
     assert bits_equal == 256 * len(kps)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (i) recoverPose from its definition: numpy SVD of E, the four (R, t) candidates, DLT triangulation by numpy SVD, the cheirality
+#     vote with the 50-unit distance bound -- against the oracle's Jacobi-SVD realisation (same winner, same count, R and t to 1e-9)
+def test_recover_pose_from_numpy_svd(vislam, orc):
+    rng = np.random.default_rng(21)
+    p = vislam.default_params()
+    p.fy = p.fx
+    op = orc.Params()
+    for f, _ in p._fields_:
+        setattr(op, f, getattr(p, f))
+    K = np.array([[p.fx, 0, p.cx], [0, p.fx, p.cy], [0, 0, 1.0]])
+    for trial in range(6):
+        n = 60
+        X = np.column_stack([rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), rng.uniform(3, 9, n)])
+        w = rng.normal(0, 0.15, 3)
+        th = np.linalg.norm(w)
+        Kx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]) / th
+        R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+        t = rng.normal(0, 1, 3); t /= np.linalg.norm(t)
+        x1 = (K @ X.T).T; x1 = x1[:, :2] / x1[:, 2:]
+        X2 = X @ R.T + t
+        x2 = (K @ X2.T).T; x2 = x2[:, :2] / x2[:, 2:]
+        if trial >= 3:                                                                       # some points behind / far away
+            x2[:8] = rng.uniform(0, 480, (8, 2))
+        x1 = x1.astype(np.float32); x2 = x2.astype(np.float32)
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        E = tx @ R
+        Ro, to, no = orc.recover_pose(op, E, x1, x2)
+        # --- from the definition
+        q1 = (x1.astype(np.float64) - [p.cx, p.cy]) / p.fx
+        q2 = (x2.astype(np.float64) - [p.cx, p.cy]) / p.fx
+        U, _, Vt = np.linalg.svd(E)
+        if np.linalg.det(U) < 0: U = -U
+        if np.linalg.det(Vt) < 0: Vt = -Vt
+        W = np.array([[0, 1.0, 0], [-1, 0, 0], [0, 0, 1]])
+        cands = [(U @ W @ Vt, U[:, 2]), (U @ W.T @ Vt, U[:, 2]), (U @ W @ Vt, -U[:, 2]), (U @ W.T @ Vt, -U[:, 2])]
+        P0 = np.hstack([np.eye(3), np.zeros((3, 1))])
+        good = []
+        for Rc, tc in cands:
+            P1 = np.hstack([Rc, tc[:, None]])
+            cnt = 0
+            for a, b in zip(q1, q2):
+                A = np.array([a[0] * P0[2] - P0[0], a[1] * P0[2] - P0[1], b[0] * P1[2] - P1[0], b[1] * P1[2] - P1[1]])
+                Q = np.linalg.svd(A)[2][-1]
+                ok = Q[2] * Q[3] > 0
+                Q = Q / Q[3]
+                ok = ok and Q[2] < 50
+                Q2 = P1 @ Q
+                ok = ok and Q2[2] > 0 and Q2[2] < 50
+                cnt += bool(ok)
+            good.append(cnt)
+        if good[0] >= max(good[1:]):
+            sel = 0
+        elif good[1] >= good[0] and good[1] >= good[2] and good[1] >= good[3]:
+            sel = 1
+        elif good[2] >= good[0] and good[2] >= good[1] and good[2] >= good[3]:
+            sel = 2
+        else:
+            sel = 3
+        assert no == good[sel], (good, no)
+        assert np.abs(Ro - cands[sel][0]).max() < 1e-9 and np.abs(to - cands[sel][1]).max() < 1e-9
+        if trial < 3:
+            assert np.abs(Ro - R).max() < 1e-5 and np.abs(to - t).max() < 1e-5                # and it is the true motion
