@@ -258,7 +258,10 @@ int  vis_align_batch(vis_ctx* ctx, const vis_align_params* ap, const uint8_t* d_
                      const float* d_pts, const int32_t* d_npts, int max_pts,
                      const vis_se3f* d_init, vis_align_result* d_out);
 /* the same on the pairs of the last vis_batch_run (stages must have included MATCH): the matched points come from the
- * plan (the grid-filtered good matches of every pair).  Pair 0 (frame 0 against the carried frame) is skipped. */
+ * plan (the grid-filtered good matches of every pair).  Pair 0 (frame 0 against the carried frame) is skipped.
+ * Runs on the context's POSE stream, ordered behind everything queued on the context's stream so far (the gradients) and
+ * behind the matcher, so that it overlaps the next vis_batch_run: d_frames, the gradient buffers and d_out are in use until
+ * vis_batch_sync -- or until a later vis_gradient_batch / vis_batch_align / vis_feeder_submit of this context, which wait for it. */
 int  vis_batch_align(vis_ctx* ctx, const vis_align_params* ap, const uint8_t* d_frames, int n,
                      const uint8_t* d_gray, const int16_t* d_gx, const int16_t* d_gy,
                      const vis_se3f* d_init, vis_align_result* d_out);

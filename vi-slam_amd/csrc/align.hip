@@ -574,8 +574,21 @@ extern "C" int vis_batch_align(vis_ctx* ctx, const vis_align_params* ap, const u
     Plan* pl = ctx->batch;
     if (!pl || pl->last_n < 1 || n != pl->last_n) return VIS_E_STATE;
     if (ctx->p.pose_input != VIS_POSE_GOOD) return VIS_E_STATE;                       // needs the grid-filtered matches in d_p1
-    // the matcher of the last batch runs on its own stream: order this stream after it
-    if (pl->match_pending[pl->last_base / pl->rec_per_set]) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_match_done[pl->last_base / pl->rec_per_set], 0));
+    // One persistent workgroup per pair, a chain of dependent iterations: latency-bound work that fits beside the next batch's
+    // detect chain.  It runs on the pose stream, behind (a) everything queued on the context's stream so far -- the gradients of
+    // these frames -- and (b) the matcher of the last batch; what may not overtake it (the next filter rewriting the matched
+    // points, the next vis_gradient_batch, the feeder's next copy into these frames) waits for ev_align_done.
+    (void)hipSetDevice(ctx->device);
+    hipStream_t sA = ctx->stream, sP = ctx->pose_stream;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_align_fork, sA));
+    HIPCHK(ctx, hipStreamWaitEvent(sP, ctx->ev_align_fork, 0));
+    if (pl->match_pending[pl->last_base / pl->rec_per_set]) HIPCHK(ctx, hipStreamWaitEvent(sP, ctx->ev_match_done[pl->last_base / pl->rec_per_set], 0));
     // d_p1 = the matched keypoints of the query frame of every pair (getGoodMatches, src/Matcher.cpp:295-303): pair i = (frame i-1, frame i)
-    return vis_align_batch(ctx, ap, d_frames, pl->w, pl->h, pl->stride, n, d_gray, d_gx, d_gy, pl->d_p1, pl->d_ngood, pl->root * pl->root, d_init, d_out);
+    ctx->stream = sP;
+    const int rc = vis_align_batch(ctx, ap, d_frames, pl->w, pl->h, pl->stride, n, d_gray, d_gx, d_gy, pl->d_p1, pl->d_ngood, pl->root * pl->root, d_init, d_out);
+    ctx->stream = sA;
+    if (rc) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_align_done, sP));
+    ctx->align_pending = true;
+    return VIS_OK;
 }

@@ -89,7 +89,9 @@ extern "C" int vis_create(int device, vis_ctx** out) {
         hipEventCreateWithFlags(&ctx->ev_match_done[1], hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->update_stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_update_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_update_done, hipEventDisableTiming) != hipSuccess) { delete ctx; return VIS_E_HIP; }
+        hipEventCreateWithFlags(&ctx->ev_update_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_align_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_align_done, hipEventDisableTiming) != hipSuccess) { delete ctx; return VIS_E_HIP; }
     ctx->ev_ok = true;
     for (int i = 0; i < 12; i++) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) ctx->ev_ok = false;
     *out = ctx;
@@ -111,6 +113,8 @@ extern "C" void vis_destroy(vis_ctx* ctx) {
     if (ctx->ev_pose_done) (void)hipEventDestroy(ctx->ev_pose_done);
     if (ctx->ev_pose_start) (void)hipEventDestroy(ctx->ev_pose_start);
     if (ctx->ev_results_done) (void)hipEventDestroy(ctx->ev_results_done);
+    if (ctx->ev_align_fork) (void)hipEventDestroy(ctx->ev_align_fork);
+    if (ctx->ev_align_done) (void)hipEventDestroy(ctx->ev_align_done);
     if (ctx->match_stream) { (void)hipStreamSynchronize(ctx->match_stream); (void)hipStreamDestroy(ctx->match_stream); }
     if (ctx->ev_detect_done) (void)hipEventDestroy(ctx->ev_detect_done);
     if (ctx->ev_match_start) (void)hipEventDestroy(ctx->ev_match_start);
@@ -126,7 +130,7 @@ static void sync_all(vis_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->match_stream) (void)hipStreamSynchronize(ctx->match_stream);
     if (ctx->pose_stream) (void)hipStreamSynchronize(ctx->pose_stream);
-    ctx->pose_pending = false; ctx->results_pending = false;
+    ctx->pose_pending = false; ctx->results_pending = false; ctx->align_pending = false;
     if (ctx->batch) ctx->batch->match_pending[0] = ctx->batch->match_pending[1] = false;
 }
 
@@ -432,6 +436,8 @@ extern "C" int vis_gradient_batch(vis_ctx* ctx, const uint8_t* d_frames, int w, 
     }
     if (((uintptr_t)d_gx | (uintptr_t)d_gy | (uintptr_t)d_g | (uintptr_t)d_gray) & 15) { ctx->err = "vis_gradient_batch: output buffers must be 16-byte aligned"; return VIS_E_INVALID; }
     (void)hipSetDevice(ctx->device);
+    // a vis_batch_align still in flight on the pose stream reads the previous gradients (usually these very buffers)
+    if (ctx->align_pending) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_align_done, 0));
     const size_t frame_bytes = (size_t)stride * h;
     int rc = launch_half_pyramid_batch(ctx, d_frames, w, h, stride, frame_bytes, n, d_gray);
     if (rc) return rc;
@@ -876,6 +882,8 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
             if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[5], sM);
             // the filter rewrites the pose inputs of the previous batch: wait until its pose work is done
             if (ctx->pose_pending) { hipError_t e = hipStreamWaitEvent(sM, ctx->ev_pose_done, 0); if (e != hipSuccess) rc = VIS_E_HIP; }
+            // ... and the previous batch's alignment (vis_batch_align reads the matched points on the pose stream)
+            if (!rc && ctx->align_pending) { hipError_t e = hipStreamWaitEvent(sM, ctx->ev_align_done, 0); if (e != hipSuccess) rc = VIS_E_HIP; }
             // ... and until the previous batch's results have left the device
             if (!rc && ctx->results_pending) { hipError_t e = hipStreamWaitEvent(sM, ctx->ev_results_done, 0); if (e != hipSuccess) rc = VIS_E_HIP; }
             if (!rc) rc = launch_filter(ctx, pl, n);
@@ -908,7 +916,7 @@ extern "C" int vis_batch_sync(vis_ctx* ctx) {
     if (ctx->match_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->match_stream));
     const bool had_pose = ctx->pose_pending;
     if (ctx->pose_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->pose_stream));
-    ctx->pose_pending = false; ctx->results_pending = false;
+    ctx->pose_pending = false; ctx->results_pending = false; ctx->align_pending = false;
     if (ctx->batch) ctx->batch->match_pending[0] = ctx->batch->match_pending[1] = false;
     if (ctx->ev_ok) {
         collect_detect_timings(ctx);

@@ -180,6 +180,7 @@ extern "C" int vis_feeder_submit(vis_feeder* f, int which, int n, const uint8_t*
         ctx->err = "vis_feeder_submit: the batch plan's geometry (w, h, stride == w) does not match the feeder"; return VIS_E_INVALID;
     }
     if (f->busy[which]) HIPCHK(ctx, hipStreamWaitEvent(f->copy_stream, f->consumed[which], 0));    // detect of the batch that used d_buf[which]
+    if (ctx->align_pending) HIPCHK(ctx, hipStreamWaitEvent(f->copy_stream, ctx->ev_align_done, 0));  // ... and an alignment that may still read it
     HIPCHK(ctx, hipMemcpyAsync(f->d_buf[which], f->h_buf[which], f->frame_bytes * n, hipMemcpyHostToDevice, f->copy_stream));
     HIPCHK(ctx, hipEventRecord(f->copied[which], f->copy_stream));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, f->copied[which], 0));

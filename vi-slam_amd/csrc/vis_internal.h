@@ -111,6 +111,8 @@ struct vis_ctx {
     hipStream_t update_stream = nullptr;     // VIS_STAGE_UPDATE (Camera::Update): streaming work beside the VALU-bound detect chain
     hipEvent_t ev_update_fork = nullptr, ev_update_done = nullptr;
     bool pose_pending = false;
+    // vis_batch_align runs on the pose stream (beside the next batch's detect chain): what may not overtake it waits for this event
+    hipEvent_t ev_align_fork = nullptr, ev_align_done = nullptr; bool align_pending = false;
     bool pose_attr_set = false;              // > 64 KiB LDS opt-in of the RANSAC solver kernels done on this context's device
     hipEvent_t ev_results_done = nullptr; bool results_pending = false;   // D2H of the last batch's results (vis_batch_results_async)
     vis_params p;
