@@ -163,3 +163,44 @@ def test_align_batch_explicit_points_and_init(vislam, orc, ctx, canvas):
         cand = [orc.patch_points(kp, W, H, l) for l in range(5)]
         init = None if t == 1 else i2
         _same(res[t], orc.estimate_pose_features(oap, W, H, l0, l1, ogx, ogy, cand, init))
+
+
+def test_batch_align_is_not_overtaken_by_the_next_step(vislam, canvas):
+    """vis_batch_align runs on the pose stream beside the next batch's detect chain.  The next step rewrites what it reads
+    -- the plan's matched points (filter), the caller's gradient buffers (vis_gradient_batch into the SAME buffers) --
+    so a pipelined run (no sync between the steps) must give every step exactly the results of a step-by-step run."""
+    import torch
+    W, H, n = 752, 480, 48
+    p = vislam.default_params()
+    c = vislam.Context(0, p)
+    sets = [np.stack([vislam.synth_frame(canvas, 100 * s + 7 * t, W, H) for t in range(n)]) for s in range(3)]
+    devs = [torch.from_numpy(f).cuda() for f in sets]
+    c.batch_plan(W, H, W, n)
+    fe = vislam.gradient_frame_elems(W, H)
+    gray = torch.zeros(n * fe, dtype=torch.uint8, device="cuda")
+    gx = torch.zeros(n * fe, dtype=torch.int16, device="cuda"); gy = torch.zeros_like(gx)
+    g = torch.zeros(n * fe, dtype=torch.uint8, device="cuda")
+    ap = vislam.default_align_params()
+    sz = n * C.sizeof(vislam.AlignResult)
+
+    def step(d, out):
+        c.batch_run(d.data_ptr(), n, vislam.STAGE_DETECT | vislam.STAGE_MATCH)
+        c.gradient_batch(d.data_ptr(), W, H, W, n, gray.data_ptr(), gx.data_ptr(), gy.data_ptr(), g.data_ptr())
+        c.batch_align(ap, d.data_ptr(), n, gray.data_ptr(), gx.data_ptr(), gy.data_ptr(), 0, out.data_ptr())
+
+    ref = []
+    c.batch_reset()
+    for d in devs:                                                    # step by step
+        out = torch.zeros(sz, dtype=torch.uint8, device="cuda")
+        step(d, out); c.batch_sync(); torch.cuda.synchronize()
+        ref.append(out.cpu().numpy().copy())
+    for rep in range(3):                                              # pipelined, a few times (a missing wait is a race)
+        c.batch_reset()
+        outs = [torch.zeros(sz, dtype=torch.uint8, device="cuda") for _ in devs]
+        for d, out in zip(devs, outs):
+            step(d, out)
+        c.batch_sync(); torch.cuda.synchronize()
+        for k, (out, r) in enumerate(zip(outs, ref)):
+            assert np.array_equal(out.cpu().numpy(), r), (rep, k)
+    assert any(r.any() for r in ref)
+    c.close()
