@@ -327,9 +327,10 @@ def main():
             # addGPUKeyframe (detect, match + filters, computeGradient, patch points) + EstimatePoseFeatures, for every frame of the batch
             def main_step(i):
                 d = stream.ptr((i % R) * B)
-                ctx.batch_run(d, B, vislam.STAGE_DETECT | vislam.STAGE_MATCH)
-                ctx.gradient_batch(d, W, H, W, B, gray.data_ptr(), gxb.data_ptr(), gyb.data_ptr(), gb.data_ptr())
-                ctx.batch_align(apar, d, B, gray.data_ptr(), gxb.data_ptr(), gyb.data_ptr(), 0, outb.data_ptr())
+                # half pyramid + gradients into the plan's buffers on the side stream (beside the detect chain), alignment on the
+                # pose stream (beside the next batch's detect chain)
+                ctx.batch_run(d, B, vislam.STAGE_DETECT | vislam.STAGE_MATCH | vislam.STAGE_GRADIENT)
+                ctx.batch_align(apar, d, B, 0, 0, 0, 0, outb.data_ptr())
             for i in range(3):
                 main_step(i)
             ctx.batch_sync(); torch.cuda.synchronize()

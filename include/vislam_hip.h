@@ -299,7 +299,12 @@ int  vis_batch_reset(vis_ctx* ctx);
 enum { VIS_STAGE_DETECT = 1, VIS_STAGE_MATCH = 2, VIS_STAGE_POSE = 4, VIS_STAGE_ALL = 7,
        /* Camera::Update (src/Camera.cpp:63-72) for every frame of the batch: the 4 half-resolution levels into a plan-owned
         * buffer (vis_batch_half_pyramid), at the head of the detect chain.  Needs w, h multiples of 16. */
-       VIS_STAGE_UPDATE = 8, VIS_STAGE_FRAME = 15 };
+       VIS_STAGE_UPDATE = 8, VIS_STAGE_FRAME = 15,
+       /* Camera::computeGradient (src/Camera.cpp:167-184; inside addGPUKeyframe, src/CameraGPU.cpp:154) for every frame of the
+        * batch: Scharr dx / dy (CV_16S, scale 3) and the blended magnitude on the 5 half-pyramid levels, into plan-owned buffers
+        * (vis_batch_gradients), on the same side stream as Camera::Update -- pure streaming work beside the detect chain.
+        * Implies VIS_STAGE_UPDATE.  Overwrites the previous batch's gradients: it waits for a vis_batch_align still reading them. */
+       VIS_STAGE_GRADIENT = 16 };
 /* Asynchronous: d_frames = n_frames images resident in HBM (dev ptr, row stride from the plan, frame stride =
  * stride*h).  The context runs three streams: the detect chain (the stream set with vis_set_stream / the context's
  * own), the matcher, and the RANSAC/pose stage; consecutive calls overlap (detect of batch i+1 with match and pose of
@@ -311,6 +316,12 @@ int  vis_batch_sync(vis_ctx* ctx);
  * like d_gray of vis_gradient_batch (levels dense and back to back inside a frame, level 0's part untouched);
  * VIS_E_STATE if the stage has not run.  Valid until the next vis_batch_run / vis_batch_plan. */
 int  vis_batch_half_pyramid(vis_ctx* ctx, const uint8_t** d_half, size_t* frame_elems);
+/* the gradients the last vis_batch_run(... | VIS_STAGE_GRADIENT) wrote: DEVICE pointers laid out like the outputs of
+ * vis_gradient_batch (d_gray = the half pyramid of vis_batch_half_pyramid); any pointer may be NULL.  VIS_E_STATE if the
+ * stage has not run.  Valid until the next vis_batch_run / vis_batch_plan.  vis_batch_align takes them when its three
+ * gradient arguments are NULL. */
+int  vis_batch_gradients(vis_ctx* ctx, const uint8_t** d_gray, const int16_t** d_gx, const int16_t** d_gy, const uint8_t** d_g,
+                         size_t* frame_elems);
 /* copy results of the last batch to host (synchronises). Any pointer may be NULL. */
 int  vis_batch_get_keypoints(vis_ctx* ctx, int frame, vis_keypoint* kps, uint8_t* desc,
                              int cap, int* n_out);

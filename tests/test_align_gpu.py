@@ -204,3 +204,58 @@ def test_batch_align_is_not_overtaken_by_the_next_step(vislam, canvas):
             assert np.array_equal(out.cpu().numpy(), r), (rep, k)
     assert any(r.any() for r in ref)
     c.close()
+
+
+def test_stage_gradient_matches_gradient_batch_and_feeds_the_alignment(vislam, canvas):
+    """VIS_STAGE_GRADIENT (plan-owned gradients on the side stream of vis_batch_run) = vis_gradient_batch on the same frames,
+    and vis_batch_align with NULL gradient pointers = the same call with explicit buffers; pipelined steps included."""
+    import torch
+    W, H, n = 752, 480, 24
+    c = vislam.Context(0, vislam.default_params())
+    sets = [np.stack([vislam.synth_frame(canvas, 50 * s + 5 * t, W, H) for t in range(n)]) for s in range(2)]
+    devs = [torch.from_numpy(f).cuda() for f in sets]
+    c.batch_plan(W, H, W, n)
+    fe = vislam.gradient_frame_elems(W, H)
+    gray = torch.zeros(n * fe, dtype=torch.uint8, device="cuda")
+    gx = torch.zeros(n * fe, dtype=torch.int16, device="cuda"); gy = torch.zeros_like(gx)
+    g = torch.zeros(n * fe, dtype=torch.uint8, device="cuda")
+    ap = vislam.default_align_params()
+    sz = n * C.sizeof(vislam.AlignResult)
+    ref = []
+    for d in devs:                                                    # explicit buffers, step by step
+        out = torch.zeros(sz, dtype=torch.uint8, device="cuda")
+        c.batch_run(d.data_ptr(), n, vislam.STAGE_DETECT | vislam.STAGE_MATCH)
+        c.gradient_batch(d.data_ptr(), W, H, W, n, gray.data_ptr(), gx.data_ptr(), gy.data_ptr(), g.data_ptr())
+        c.batch_align(ap, d.data_ptr(), n, gray.data_ptr(), gx.data_ptr(), gy.data_ptr(), 0, out.data_ptr())
+        c.batch_sync(); torch.cuda.synchronize()
+        ref.append((out.cpu().numpy().copy(), gray.cpu().numpy().copy(), gx.cpu().numpy().copy(), gy.cpu().numpy().copy(), g.cpu().numpy().copy()))
+    c.batch_reset()
+    with pytest.raises(Exception):                                    # no gradients given, none in the plan
+        c.batch_run(devs[0].data_ptr(), n, vislam.STAGE_DETECT | vislam.STAGE_MATCH)
+        c.batch_align(ap, devs[0].data_ptr(), n, 0, 0, 0, 0, torch.zeros(sz, dtype=torch.uint8, device="cuda").data_ptr())
+    c.batch_sync()
+    c.batch_reset()
+    outs = [torch.zeros(sz, dtype=torch.uint8, device="cuda") for _ in devs]
+    for k, (d, out) in enumerate(zip(devs, outs)):                    # plan-owned gradients, pipelined
+        c.batch_run(d.data_ptr(), n, vislam.STAGE_DETECT | vislam.STAGE_MATCH | vislam.STAGE_GRADIENT)
+        c.batch_align(ap, d.data_ptr(), n, 0, 0, 0, 0, out.data_ptr())
+    c.batch_sync(); torch.cuda.synchronize()
+    pg, px, py, pgg, pfe = c.batch_gradients()
+    assert pfe == fe
+    for out, r in zip(outs, ref):
+        assert np.array_equal(out.cpu().numpy(), r[0])
+    # the plan's buffers hold the LAST batch's gradients
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    def fetch(ptr, nbytes):
+        host = np.empty(nbytes, np.uint8)
+        assert hip.hipMemcpy(ctypes.c_void_p(host.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(nbytes), 2) == 0     # D2H
+        return host
+    last = ref[-1]
+    lv0 = W * H
+    got_gray = fetch(pg, n * fe).reshape(n, fe)[:, lv0:]
+    assert np.array_equal(got_gray, last[1].reshape(n, fe)[:, lv0:])                          # levels 1..4 (level 0 is the frame)
+    assert np.array_equal(fetch(px, n * fe * 2).view(np.int16), last[2])
+    assert np.array_equal(fetch(py, n * fe * 2).view(np.int16), last[3])
+    assert np.array_equal(fetch(pgg, n * fe), last[4])
+    c.close()

@@ -574,6 +574,10 @@ extern "C" int vis_batch_align(vis_ctx* ctx, const vis_align_params* ap, const u
     Plan* pl = ctx->batch;
     if (!pl || pl->last_n < 1 || n != pl->last_n) return VIS_E_STATE;
     if (ctx->p.pose_input != VIS_POSE_GOOD) return VIS_E_STATE;                       // needs the grid-filtered matches in d_p1
+    if (!d_gray && !d_gx && !d_gy) {                                                   // the plan's own gradients (VIS_STAGE_GRADIENT of the last vis_batch_run)
+        if (!pl->grad_valid) { ctx->err = "vis_batch_align: no gradient buffers given and the last vis_batch_run had no VIS_STAGE_GRADIENT"; return VIS_E_STATE; }
+        d_gray = pl->d_half; d_gx = pl->d_gx; d_gy = pl->d_gy;
+    }
     // One persistent workgroup per pair, a chain of dependent iterations: latency-bound work that fits beside the next batch's
     // detect chain.  It runs on the pose stream, behind (a) everything queued on the context's stream so far -- the gradients of
     // these frames -- and (b) the matcher of the last batch; what may not overtake it (the next filter rewriting the matched

@@ -227,7 +227,7 @@ void plan_destroy(Plan* pl) {
         F(pl->d_pyr[l]); F(pl->d_rs_tab[l]);
         F(pl->d_cand[l]); F(pl->d_seg_kp[l]);
     }
-    F(pl->d_fast_tiles); F(pl->d_tile_cnt); F(pl->d_seg_cnt); F(pl->d_flags); F(pl->d_angle_tab); F(pl->d_half); F(pl->d_tau); F(pl->d_seg_cut); F(pl->d_fix);
+    F(pl->d_fast_tiles); F(pl->d_tile_cnt); F(pl->d_seg_cnt); F(pl->d_flags); F(pl->d_angle_tab); F(pl->d_half); F(pl->d_gx); F(pl->d_gy); F(pl->d_g); F(pl->d_tau); F(pl->d_seg_cut); F(pl->d_fix);
     F(pl->d_kps); F(pl->d_desc); F(pl->d_nkp); F(pl->d_descx);
     for (int i = 0; i < 2; i++) { F(pl->d_pq[i]); F(pl->d_pt[i]); F(pl->d_pqn[i]); }
     F(pl->d_knn12); F(pl->d_knn21);
@@ -844,19 +844,29 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
     // and it is pure streaming work, so it runs on a stream of its own beside the (vector-ALU bound) detect kernels; the detect
     // stream joins it at the end of its chain, so "the detect stream is done" still means "d_frames may be reused".
     hipStream_t sU = ctx->update_stream;
-    pl->half_valid = false;
+    pl->half_valid = false; pl->grad_valid = false;
     bool update_queued = false;
-    if (stages & VIS_STAGE_UPDATE) {
+    if (stages & (VIS_STAGE_UPDATE | VIS_STAGE_GRADIENT)) {
         VisRange r_("vis: Camera::Update half pyramid");
         if ((pl->w & 15) || (pl->h & 15)) { ctx->err = "VIS_STAGE_UPDATE: w, h must be multiples of 16"; return VIS_E_INVALID; }
         if (!pl->d_half) HIPCHK(ctx, hipMalloc((void**)&pl->d_half, (size_t)pl->B * vis_grad_frame_elems(pl->w, pl->h)));
         // the frames were produced on the detect stream (or before the call): order the side stream behind it
         HIPCHK(ctx, hipEventRecord(ctx->ev_update_fork, sA));
         HIPCHK(ctx, hipStreamWaitEvent(sU, ctx->ev_update_fork, 0));
+        // the previous batch's alignment (vis_batch_align on the pose stream) may still read the half pyramid / the gradients
+        if (ctx->align_pending) HIPCHK(ctx, hipStreamWaitEvent(sU, ctx->ev_align_done, 0));
         if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[10], sU);
         ctx->stream = sU;
         rc = launch_half_pyramid_batch(ctx, d_frames, pl->w, pl->h, pl->stride, (size_t)pl->stride * pl->h, n, pl->d_half);
         ctx->stream = sA;
+        if (!rc && (stages & VIS_STAGE_GRADIENT)) {
+            const size_t fe = vis_grad_frame_elems(pl->w, pl->h);
+            if (!pl->d_gx) { HIPCHK(ctx, hipMalloc((void**)&pl->d_gx, (size_t)pl->B * fe * 2)); HIPCHK(ctx, hipMalloc((void**)&pl->d_gy, (size_t)pl->B * fe * 2)); HIPCHK(ctx, hipMalloc((void**)&pl->d_g, (size_t)pl->B * fe)); }
+            ctx->stream = sU;
+            rc = launch_gradient(ctx, d_frames, pl->w, pl->h, pl->stride, (size_t)pl->stride * pl->h, n, pl->d_half, 3 /* the reference's Scharr scale, src/Camera.cpp:172 */, pl->d_gx, pl->d_gy, pl->d_g);
+            ctx->stream = sA;
+            if (!rc) pl->grad_valid = true;
+        }
         if (rc) return rc;
         if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[11], sU);
         HIPCHK(ctx, hipEventRecord(ctx->ev_update_done, sU));
@@ -941,6 +951,18 @@ extern "C" int vis_batch_half_pyramid(vis_ctx* ctx, const uint8_t** d_half, size
     Plan* pl = ctx->batch;
     if (!pl->half_valid || !pl->d_half) return VIS_E_STATE;
     *d_half = pl->d_half;
+    if (frame_elems) *frame_elems = vis_grad_frame_elems(pl->w, pl->h);
+    return VIS_OK;
+}
+
+extern "C" int vis_batch_gradients(vis_ctx* ctx, const uint8_t** d_gray, const int16_t** d_gx, const int16_t** d_gy, const uint8_t** d_g, size_t* frame_elems) {
+    if (!ctx || !ctx->batch) return VIS_E_STATE;
+    Plan* pl = ctx->batch;
+    if (!pl->grad_valid || !pl->d_gx) return VIS_E_STATE;
+    if (d_gray) *d_gray = pl->d_half;
+    if (d_gx) *d_gx = pl->d_gx;
+    if (d_gy) *d_gy = pl->d_gy;
+    if (d_g) *d_g = pl->d_g;
     if (frame_elems) *frame_elems = vis_grad_frame_elems(pl->w, pl->h);
     return VIS_OK;
 }

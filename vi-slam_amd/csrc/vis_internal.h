@@ -60,6 +60,9 @@ struct Plan {
     int32_t* d_fix = nullptr;                // 1 + B x L
     uint8_t* d_half = nullptr;               // VIS_STAGE_UPDATE: B x vis_grad_frame_elems(w, h) half pyramids (allocated on first use)
     bool half_valid = false;
+    // VIS_STAGE_GRADIENT: Scharr gradients of the batch (Camera::computeGradient) beside the detect chain, plan-owned, allocated on first use
+    int16_t* d_gx = nullptr; int16_t* d_gy = nullptr; uint8_t* d_g = nullptr;
+    bool grad_valid = false;
     // records
     vis_keypoint* d_kps = nullptr;           // nrec x kcap
     uint8_t* d_desc = nullptr;               // nrec x kcap x 32

@@ -100,6 +100,7 @@ assert KEYPOINT_DTYPE.itemsize == 28 and DMATCH_DTYPE.itemsize == 16
 SYM_REFERENCE_EFFECTIVE, SYM_INTENDED = 0, 1
 STAGE_DETECT, STAGE_MATCH, STAGE_POSE, STAGE_ALL = 1, 2, 4, 7
 STAGE_UPDATE, STAGE_FRAME = 8, 15          # Camera::Update's half pyramid at the head of the detect chain; FRAME = ALL | UPDATE
+STAGE_GRADIENT = 16                        # Camera::computeGradient into plan-owned buffers, beside the detect chain (implies UPDATE)
 
 # every symbol include/vislam_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -114,7 +115,7 @@ ABI_SYMBOLS = [
     "vis_image_list", "vis_image_time", "vis_pgm_info", "vis_image_read",
     "vis_feeder_create", "vis_feeder_destroy", "vis_feeder_host_buffer", "vis_feeder_submit", "vis_feeder_release",
     "vis_default_align_params", "vis_estimate_pose_features", "vis_align_batch", "vis_batch_align",
-    "vis_synth_frame_parallax", "vis_synth_frames_device", "vis_batch_results_async", "vis_batch_half_pyramid", "vis_batch_fast_thresholds",
+    "vis_synth_frame_parallax", "vis_synth_frames_device", "vis_batch_results_async", "vis_batch_half_pyramid", "vis_batch_gradients", "vis_batch_fast_thresholds",
     "vis_se3_exp", "vis_se3_mul", "vis_se3_from_rt", "vis_se3_matrix",
 ]
 
@@ -182,6 +183,7 @@ def _load():
     lib.vis_synth_frames_device.argtypes = [vp, vp, ci, C.c_uint64, ci, ci, ci, ci, ci, ci, vp]
     lib.vis_batch_results_async.argtypes = [vp, vp, vp, vp, ci]
     lib.vis_batch_half_pyramid.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.vis_batch_gradients.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.vis_batch_fast_thresholds.argtypes = [vp, vp, C.POINTER(C.c_int32)]
     lib.vis_se3_exp.argtypes = [vp, C.POINTER(Se3f)]; lib.vis_se3_exp.restype = None
     lib.vis_se3_mul.argtypes = [C.POINTER(Se3f), C.POINTER(Se3f), C.POINTER(Se3f)]; lib.vis_se3_mul.restype = None
@@ -449,8 +451,9 @@ class Context:
 
     def batch_align(self, ap, d_frames_ptr, n, d_gray_ptr, d_gx_ptr, d_gy_ptr, d_init_ptr, d_out_ptr):
         """alignment of the pairs of the last batch_run, matched points taken from the plan; asynchronous"""
-        self._chk(lib.vis_batch_align(self._h, C.byref(ap), C.c_void_p(d_frames_ptr), n, C.c_void_p(d_gray_ptr), C.c_void_p(d_gx_ptr),
-                                      C.c_void_p(d_gy_ptr), C.c_void_p(d_init_ptr) if d_init_ptr else None, C.c_void_p(d_out_ptr)),
+        nz = lambda q: C.c_void_p(q) if q else None                 # 0 = NULL: gradient pointers all NULL -> the plan's (STAGE_GRADIENT)
+        self._chk(lib.vis_batch_align(self._h, C.byref(ap), C.c_void_p(d_frames_ptr), n, nz(d_gray_ptr), nz(d_gx_ptr),
+                                      nz(d_gy_ptr), nz(d_init_ptr), C.c_void_p(d_out_ptr)),
                   "vis_batch_align")
 
     # -- CameraGPU::detectAndComputeGPUFeatures ---------------------------------------------------------
@@ -563,6 +566,12 @@ class Context:
         d, fe = C.c_void_p(0), C.c_size_t(0)
         self._chk(lib.vis_batch_half_pyramid(self._h, C.byref(d), C.byref(fe)), "vis_batch_half_pyramid")
         return d.value, fe.value
+
+    def batch_gradients(self):
+        """(gray, gx, gy, g device pointers, frame_elems) of the gradients the last batch_run(..., STAGE_GRADIENT) wrote"""
+        p = [C.c_void_p() for _ in range(4)]; fe = C.c_size_t()
+        self._chk(lib.vis_batch_gradients(self._h, C.byref(p[0]), C.byref(p[1]), C.byref(p[2]), C.byref(p[3]), C.byref(fe)), "vis_batch_gradients")
+        return p[0].value, p[1].value, p[2].value, p[3].value, fe.value
 
     def batch_results(self, n):
         """synchronous convenience: (pose records, good matches n x root^2, counts) of the last batch"""
