@@ -759,18 +759,20 @@ DEV void roots_level_lane(const double (&c)[11], double B, double (*prev)[64], i
     nprev = ncur;
 }
 
-__global__ __launch_bounds__(256) void k_hyp_roots_lane(PoseParams P, int h0, int h_end, const int32_t* __restrict__ rstate,
+__global__ __launch_bounds__(256) void k_hyp_roots_lane(PoseParams P, int h0, int h_end, int npairs, const int32_t* __restrict__ rstate,
                                                         double* __restrict__ hyp, size_t S, const int32_t* __restrict__ worklist, int chunks) {
     __shared__ double sh_prev[4][10][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double (*prev)[64] = sh_prev[wv];
-    const int total = worklist[0] * chunks;                        // items of 64 consecutive hypotheses of one pair
+    // items: 64 consecutive hypotheses of one work-list pair, or (first chunk, worklist == nullptr) 16 of each of four pairs
+    const int total = worklist ? worklist[0] * chunks : (npairs + 3) / 4;
     int32_t* flags = reinterpret_cast<int32_t*>(hyp + (size_t)HR_DOUBLES * S);
     int32_t* nrs = flags + S;
     for (int item = blockIdx.x * 4 + wv; item < total; item += gridDim.x * 4) {
-        const int pair = worklist[1 + item / chunks];
-        const int h = h0 + (item % chunks) * 64 + lane;
-        const bool active = h < rstate[(size_t)pair * RS] && h < h_end && h < max(P.max_iters, 1);
+        const int pair_raw = worklist ? worklist[1 + item / chunks] : item * 4 + (lane >> 4);
+        const int pair = min(pair_raw, npairs - 1);
+        const int h = worklist ? h0 + (item % chunks) * 64 + lane : h0 + (lane & 15);
+        const bool active = pair_raw < npairs && h < rstate[(size_t)pair * RS] && h < h_end && h < max(P.max_iters, 1);
         const size_t slot = (size_t)pair * P.max_iters + (active ? h : 0);       // inactive lanes never dereference it; kept in range anyway
         const int flag = active ? flags[slot] : 0;
         double c[11];
@@ -1284,7 +1286,12 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
         if (first > 0) {
             hipLaunchKernelGGL(k_ransac_hyp, dim3((first + QH - 1) / QH, npairs), dim3(64), HYP_LDS_BYTES, st, P, 0, first, npairs, d_n1, d_n2,
                                d_samples, d_rstate, d_hyp, S);
-            hipLaunchKernelGGL(k_hyp_roots, dim3(npairs), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_hyp, S, (const int32_t*)nullptr, 0);
+            // 16 lanes per polynomial for a handful of pairs (a single call's latency), one polynomial per lane for a batch: a
+            // third of the vector instructions, and the longer chain of the pose stream is hidden behind the detect chain (+0.5 %)
+            if (npairs >= 64)
+                hipLaunchKernelGGL(k_hyp_roots_lane, dim3((npairs + 15) / 16), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_hyp, S, (const int32_t*)nullptr, 0);
+            else
+                hipLaunchKernelGGL(k_hyp_roots, dim3(npairs), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_hyp, S, (const int32_t*)nullptr, 0);
             hipLaunchKernelGGL(k_hyp_models, dim3((npairs + 15) / 16), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_hyp, S, d_models, (const int32_t*)nullptr, 0);
             hipLaunchKernelGGL(k_hyp_score, dim3(npairs), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_n1, d_n2, d_hyp, S, d_models,
                                d_counts, (const int32_t*)nullptr, 0);
@@ -1300,7 +1307,7 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
                 hipLaunchKernelGGL(k_hyp_roots, dim3(nsub), dim3(256), 0, st, P, first, max_iters, npairs, d_rstate, d_hyp, S,
                                    (const int32_t*)d_worklist, chunks);
             else           // one hypothesis per lane
-                hipLaunchKernelGGL(k_hyp_roots_lane, dim3(std::min(2048, (npairs * chunks + 3) / 4)), dim3(256), 0, st, P, first, max_iters, d_rstate,
+                hipLaunchKernelGGL(k_hyp_roots_lane, dim3(std::min(2048, (npairs * chunks + 3) / 4)), dim3(256), 0, st, P, first, max_iters, npairs, d_rstate,
                                    d_hyp, S, (const int32_t*)d_worklist, chunks);
             hipLaunchKernelGGL(k_hyp_models, dim3(std::min(4096, (npairs * chunks + 3) / 4)), dim3(256), 0, st, P, first, max_iters, npairs, d_rstate,
                                d_hyp, S, d_models, (const int32_t*)d_worklist, chunks);
