@@ -49,34 +49,49 @@ DEV void cross3(const double* a, const double* b, double* c) {
 }
 DEV double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 
-__device__ void jacobi_eig(int n, double* A, double* V) {
-    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+// cyclic Jacobi eigen-decomposition of a symmetric N x N matrix (oracle/pose.cpp jacobi_eig: same rotations in the same order).
+// N is a template parameter and every index a constant: the matrices stay in registers (the run-time-n form kept them in
+// scratch memory and spent more instructions on addresses than on the rotations).
+template <int N>
+__device__ __forceinline__ void jacobi_eig(double (&A)[N * N], double (&V)[N * N]) {
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int j = 0; j < N; j++) V[i * N + j] = (i == j) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 30; sweep++) {
         double off = 0;
-        for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j];
+#pragma unroll
+        for (int i = 0; i < N; i++)
+#pragma unroll
+            for (int j = i + 1; j < N; j++) off += A[i * N + j] * A[i * N + j];
         if (off < 1e-300) break;
-        for (int p = 0; p < n; p++)
-            for (int q = p + 1; q < n; q++) {
-                const double apq = A[p * n + q];
+#pragma unroll
+        for (int p = 0; p < N; p++)
+#pragma unroll
+            for (int q = p + 1; q < N; q++) {
+                const double apq = A[p * N + q];
                 if (fabs(apq) < 1e-300) continue;
-                const double app = A[p * n + p], aqq = A[q * n + q];
+                const double app = A[p * N + p], aqq = A[q * N + q];
                 const double theta = (aqq - app) / (2.0 * apq);
                 const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                 const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                for (int k = 0; k < n; k++) {
-                    const double akp = A[k * n + p], akq = A[k * n + q];
-                    A[k * n + p] = c * akp - s * akq;
-                    A[k * n + q] = s * akp + c * akq;
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    const double akp = A[k * N + p], akq = A[k * N + q];
+                    A[k * N + p] = c * akp - s * akq;
+                    A[k * N + q] = s * akp + c * akq;
                 }
-                for (int k = 0; k < n; k++) {
-                    const double apk = A[p * n + k], aqk = A[q * n + k];
-                    A[p * n + k] = c * apk - s * aqk;
-                    A[q * n + k] = s * apk + c * aqk;
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    const double apk = A[p * N + k], aqk = A[q * N + k];
+                    A[p * N + k] = c * apk - s * aqk;
+                    A[q * N + k] = s * apk + c * aqk;
                 }
-                for (int k = 0; k < n; k++) {
-                    const double vkp = V[k * n + p], vkq = V[k * n + q];
-                    V[k * n + p] = c * vkp - s * vkq;
-                    V[k * n + q] = s * vkp + c * vkq;
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    const double vkp = V[k * N + p], vkq = V[k * N + q];
+                    V[k * N + p] = c * vkp - s * vkq;
+                    V[k * N + q] = s * vkp + c * vkq;
                 }
             }
     }
@@ -1075,7 +1090,7 @@ __device__ void svd3_decompose(const double* E, double* U, double* Vt) {
         double s = 0; for (int k = 0; k < 3; k++) s += E[3 * k + i] * E[3 * k + j];
         A[3 * i + j] = s;
     }
-    jacobi_eig(3, A, V);
+    jacobi_eig<3>(A, V);
     int ord[3] = {0, 1, 2};
     // sort by descending eigenvalue, ties keep index order
     for (int i = 0; i < 3; i++) for (int j = i + 1; j < 3; j++) {
@@ -1116,9 +1131,14 @@ __device__ bool cheirality(const double* R, const double* t, double x1, double y
         double s = 0; for (int k = 0; k < 4; k++) s += A[4 * k + i] * A[4 * k + j];
         AtA[4 * i + j] = s;
     }
-    jacobi_eig(4, AtA, V);
-    int mn = 0; for (int i = 1; i < 4; i++) if (AtA[5 * i] < AtA[5 * mn]) mn = i;
-    const double X[4] = {V[mn], V[4 + mn], V[8 + mn], V[12 + mn]};
+    jacobi_eig<4>(AtA, V);
+    // eigenvector of the smallest eigenvalue (first one on ties), picked with selects: no run-time index into the register arrays
+    int mn = 0; double dmin = AtA[0];
+#pragma unroll
+    for (int i = 1; i < 4; i++) if (AtA[5 * i] < dmin) { dmin = AtA[5 * i]; mn = i; }
+    double X[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) X[k] = mn == 0 ? V[4 * k] : mn == 1 ? V[4 * k + 1] : mn == 2 ? V[4 * k + 2] : V[4 * k + 3];
     bool ok = (X[2] * X[3]) > 0;
     const double Xn[3] = {X[0] / X[3], X[1] / X[3], X[2] / X[3]};
     ok = ok && (Xn[2] < 50.0);
