@@ -14,6 +14,8 @@ algorithms*: a second implementation written from the definition, not from the o
   (h) the 8-bit Gaussian as exact int64 sums of the Q8 taps; rBRIEF descriptors re-derived from
       the blurred level (float32 rotation, round-half-even, LSB-first packing)                 vs the oracle (exact)
   (i) recoverPose from numpy SVDs (four candidates, DLT triangulation, cheirality vote)        vs orc_recover_pose (same winner / count, 1e-9)
+  (j) the cyclic Jacobi iteration on A^T A and on D A^T A D, D = diag(1, 1, 1, -1) (t -> -t): V' = D V D bit for bit -- the
+      identity k_pose_final uses to triangulate once for (R, t) and (R, -t)
 """
 import numpy as np
 import pytest
@@ -518,3 +520,68 @@ def test_recover_pose_from_numpy_svd(vislam, orc):
         assert np.abs(Ro - cands[sel][0]).max() < 1e-9 and np.abs(to - cands[sel][1]).max() < 1e-9
         if trial < 3:
             assert np.abs(Ro - R).max() < 1e-5 and np.abs(to - t).max() < 1e-5                # and it is the true motion
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (j) k_pose_final triangulates a correspondence once for [R | t] and derives the vote for [R | -t] from the same eigenvector:
+#     negating t negates column 3 of the DLT matrix, A' = A D, and the cyclic Jacobi iteration (oracle/pose.cpp jacobi_eig) is
+#     exactly equivariant under that sign change -- V' = D V D bit for bit -- unless some rotation with column 3 has theta == +-0.
+def _jacobi(A):
+    n = len(A)
+    A = [row[:] for row in A]
+    V = [[1.0 if i == j else 0.0 for j in range(n)] for i in range(n)]
+    zero_theta = False
+    for _ in range(30):
+        off = 0.0
+        for i in range(n):
+            for j in range(i + 1, n):
+                off += A[i][j] * A[i][j]
+        if off < 1e-300:
+            break
+        for p in range(n):
+            for q in range(p + 1, n):
+                apq = A[p][q]
+                if abs(apq) < 1e-300:
+                    continue
+                theta = (A[q][q] - A[p][p]) / (2.0 * apq)
+                zero_theta |= (q == n - 1 and theta == 0.0)
+                t = (1.0 if theta >= 0 else -1.0) / (abs(theta) + (theta * theta + 1.0) ** 0.5)
+                c = 1.0 / (t * t + 1.0) ** 0.5
+                s = t * c
+                for k in range(n):
+                    akp, akq = A[k][p], A[k][q]
+                    A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq
+                for k in range(n):
+                    apk, aqk = A[p][k], A[q][k]
+                    A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk
+                for k in range(n):
+                    vkp, vkq = V[k][p], V[k][q]
+                    V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq
+    return A, V, zero_theta
+
+
+def test_jacobi_is_equivariant_under_negating_the_last_column():
+    rng = np.random.default_rng(9)
+    D = [1.0, 1.0, 1.0, -1.0]
+    checked = 0
+    for trial in range(300):
+        x1, y1, x2, y2 = rng.uniform(-0.6, 0.6, 4)
+        w = rng.normal(0, 0.3, 3); th = np.linalg.norm(w)
+        Kx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]) / th
+        R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+        t = rng.normal(0, 1, 3); t /= np.linalg.norm(t)
+        def ata(tt):
+            P = [[float(R[r][c]) for c in range(3)] + [float(tt[r])] for r in range(3)]
+            A = [[-1.0, 0.0, float(x1), 0.0], [0.0, -1.0, float(y1), 0.0],
+                 [float(x2) * P[2][c] - P[0][c] for c in range(4)], [float(y2) * P[2][c] - P[1][c] for c in range(4)]]
+            return [[sum(A[k][i] * A[k][j] for k in range(4)) for j in range(4)] for i in range(4)]
+        Ap, Vp, z = _jacobi(ata(t))
+        An, Vn, _ = _jacobi(ata(-t))
+        if z:
+            continue                                                                        # the kernel decomposes the second candidate itself then
+        checked += 1
+        for i in range(4):
+            assert An[i][i] == Ap[i][i]
+            for j in range(4):
+                assert Vn[i][j] == D[i] * Vp[i][j] * D[j], (trial, i, j)
+    assert checked >= 290

@@ -53,7 +53,7 @@ DEV double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * 
 // N is a template parameter and every index a constant: the matrices stay in registers (the run-time-n form kept them in
 // scratch memory and spent more instructions on addresses than on the rotations).
 template <int N>
-__device__ __forceinline__ void jacobi_eig(double (&A)[N * N], double (&V)[N * N]) {
+__device__ __forceinline__ void jacobi_eig(double (&A)[N * N], double (&V)[N * N], bool* zero_theta_last = nullptr) {
 #pragma unroll
     for (int i = 0; i < N; i++)
 #pragma unroll
@@ -73,6 +73,9 @@ __device__ __forceinline__ void jacobi_eig(double (&A)[N * N], double (&V)[N * N
                 if (fabs(apq) < 1e-300) continue;
                 const double app = A[p * N + p], aqq = A[q * N + q];
                 const double theta = (aqq - app) / (2.0 * apq);
+                // (theta == +-0 takes t = +1 whatever the sign of apq: the one place where negating row / column N-1 of A does not
+                // simply negate the matching entries of everything that follows -- see cheirality_pair)
+                if (zero_theta_last && q == N - 1 && theta == 0.0) *zero_theta_last = true;
                 const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                 const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
 #pragma unroll
@@ -1120,18 +1123,26 @@ DEV void mat3_mul(const double* A, const double* B, double* C) {
     }
 }
 
-__device__ bool cheirality(const double* R, const double* t, double x1, double y1, double x2, double y2) {
+// DLT triangulation of one correspondence under P = [R | t] (4 x 4 Jacobi eigen-decomposition of A^T A, eigenvector of the smallest
+// eigenvalue) + the cheirality test of recoverPose (depth positive and below 50 in both cameras); X_out = the homogeneous point
+__device__ __forceinline__ bool cheirality(const double* R, const double* t, double x1, double y1, double x2, double y2, double* X_out, bool* zero_theta) {
     const double P[12] = {R[0], R[1], R[2], t[0], R[3], R[4], R[5], t[1], R[6], R[7], R[8], t[2]};
     double A[16];
     A[0] = -1; A[1] = 0;  A[2] = x1; A[3] = 0;
     A[4] = 0;  A[5] = -1; A[6] = y1; A[7] = 0;
+#pragma unroll
     for (int c = 0; c < 4; c++) { A[8 + c] = x2 * P[8 + c] - P[c]; A[12 + c] = y2 * P[8 + c] - P[4 + c]; }
     double AtA[16], V[16];
-    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) {
-        double s = 0; for (int k = 0; k < 4; k++) s += A[4 * k + i] * A[4 * k + j];
-        AtA[4 * i + j] = s;
-    }
-    jacobi_eig<4>(AtA, V);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) s += A[4 * k + i] * A[4 * k + j];
+            AtA[4 * i + j] = s;
+        }
+    jacobi_eig<4>(AtA, V, zero_theta);
     // eigenvector of the smallest eigenvalue (first one on ties), picked with selects: no run-time index into the register arrays
     int mn = 0; double dmin = AtA[0];
 #pragma unroll
@@ -1139,12 +1150,67 @@ __device__ bool cheirality(const double* R, const double* t, double x1, double y
     double X[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) X[k] = mn == 0 ? V[4 * k] : mn == 1 ? V[4 * k + 1] : mn == 2 ? V[4 * k + 2] : V[4 * k + 3];
+    if (X_out) { X_out[0] = X[0]; X_out[1] = X[1]; X_out[2] = X[2]; X_out[3] = X[3]; }
     bool ok = (X[2] * X[3]) > 0;
     const double Xn[3] = {X[0] / X[3], X[1] / X[3], X[2] / X[3]};
     ok = ok && (Xn[2] < 50.0);
     const double z2 = ((P[8] * Xn[0] + P[9] * Xn[1]) + P[10] * Xn[2]) + P[11];
     ok = ok && (z2 > 0) && (z2 < 50.0);
     return ok;
+}
+
+// The votes of one correspondence for [R | t] AND [R | -t] from ONE eigen-decomposition.  Negating t negates column 3 of the DLT
+// matrix (its first two rows have a zero there), i.e. A' = A D with D = diag(1, 1, 1, -1), so A'^T A' = D (A^T A) D: every entry of
+// the matrix, and of everything the Jacobi rotations compute from it, is the same number with the sign D gives it -- IEEE add,
+// multiply, divide and sqrt commute with negation exactly, and the convergence tests look at squares and magnitudes only.  The
+// eigenvector of the second problem is therefore X' = D X bit for bit, and its test runs on (X0, X1, X2, -X3) with -t.  The one
+// operation that is not odd is `theta >= 0 ? 1 : -1` at theta == +-0 (two equal diagonal entries in a rotation with column 3);
+// the decomposition reports that case and the second candidate is then decomposed on its own, as the oracle does.
+__device__ __forceinline__ void cheirality_pair(const double* R, const double* t, double x1, double y1, double x2, double y2, bool& ok_pos, bool& ok_neg) {
+    double tt[3] = {t[0], t[1], t[2]};
+    ok_pos = ok_neg = false;
+#pragma nounroll
+    for (int pass = 0; pass < 2; pass++) {                         // ONE copy of the decomposition in the code: the second pass is the rare fallback
+        double X[4]; bool zt = false;
+        const bool ok = cheirality(R, tt, x1, y1, x2, y2, X, &zt);
+        tt[0] = -tt[0]; tt[1] = -tt[1]; tt[2] = -tt[2];
+        if (pass == 1) { ok_neg = ok; break; }
+        ok_pos = ok;
+        if (!__any(zt)) {                                          // (wave-uniform exit: lanes with the special case carry the others through the second pass)
+            const double X3 = -X[3];
+            bool o = (X[2] * X3) > 0;
+            const double Xn[3] = {X[0] / X3, X[1] / X3, X[2] / X3};
+            o = o && (Xn[2] < 50.0);
+            const double z2 = ((R[6] * Xn[0] + R[7] * Xn[1]) + R[8] * Xn[2]) + tt[2];
+            ok_neg = o && (z2 > 0) && (z2 < 50.0);
+            break;
+        }
+    }
+}
+
+// recoverPose, part 1: the four (R, t) candidates of every pair's essential matrix (Jacobi SVD, decomposeEssentialMat), ONE PAIR
+// PER LANE.  As thread 0 of k_pose_final's per-pair workgroup this serial chain kept four waves' registers resident for tens of
+// microseconds each -- on the low-priority stream, but in the way of the detect kernels' workgroups (the headline moved by 2 % with
+// this kernel's register count).  cand[pair]: R1 (9), R2 (9), t (3) doubles -- kept in the hypothesis buffer, which is free by now.
+__global__ __launch_bounds__(64) void k_pose_svd(PoseParams P, const double* __restrict__ models, const int32_t* __restrict__ rstate,
+                                                 const double* __restrict__ E_in, double* __restrict__ cand, int npairs) {
+    const int pair = blockIdx.x * 64 + threadIdx.x;
+    if (pair >= npairs) return;
+    const int32_t* rs = rstate + (size_t)pair * RS;
+    const bool have = E_in ? true : (rs[2] >= 0);
+    if (!have) return;
+    double E[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) E[i] = E_in ? E_in[(size_t)pair * 9 + i] : models[((size_t)pair * P.max_iters + rs[2]) * 90 + 9 * rs[3] + i];
+    double U[9], Vt[9]; svd3_decompose(E, U, Vt);
+    const double W[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1}, Wt[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1};
+    double T[9], R1[9], R2[9];
+    mat3_mul(U, W, T); mat3_mul(T, Vt, R1);
+    mat3_mul(U, Wt, T); mat3_mul(T, Vt, R2);
+    double* c = cand + (size_t)pair * 21;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { c[i] = R1[i]; c[9 + i] = R2[i]; }
+    c[18] = U[2]; c[19] = U[5]; c[20] = U[8];
 }
 
 // winner's inlier mask + recoverPose.  do_pose = 0 -> only the mask / E (findEssentialMat).  grid (pairs, nsplit): the M Sampson
@@ -1155,7 +1221,7 @@ __device__ bool cheirality(const double* R, const double* t, double x1, double y
 __global__ __launch_bounds__(256) void k_pose_final(PoseParams P, const double* __restrict__ n1, const double* __restrict__ n2,
                                                     const double* __restrict__ models, int32_t* rstate,
                                                     const double* __restrict__ E_in, uint8_t* __restrict__ mask_out,
-                                                    PoseOut* __restrict__ out, int do_pose) {
+                                                    PoseOut* __restrict__ out, int do_pose, const double* __restrict__ cand) {
     __shared__ double sE[9], sR[2][9], sT[3];
     __shared__ int sgood[4], sinl;
     const int pair = blockIdx.x, tid = threadIdx.x, nsplit = gridDim.y, part = blockIdx.y;
@@ -1177,20 +1243,18 @@ __global__ __launch_bounds__(256) void k_pose_final(PoseParams P, const double* 
             if (f) atomicAdd(&sinl, 1);
         }
     }
-    if (tid == 0 && do_pose && have) {                             // every workgroup of the pair derives the same four candidates
-        double U[9], Vt[9]; svd3_decompose(sE, U, Vt);
-        const double W[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1}, Wt[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1};
-        double T[9];
-        mat3_mul(U, W, T); mat3_mul(T, Vt, sR[0]);
-        mat3_mul(U, Wt, T); mat3_mul(T, Vt, sR[1]);
-        sT[0] = U[2]; sT[1] = U[5]; sT[2] = U[8];
+    if (tid < 21 && do_pose && have) {                              // the pair's candidates (k_pose_svd)
+        const double v = cand[(size_t)pair * 21 + tid];
+        if (tid < 18) sR[tid / 9][tid % 9] = v; else sT[tid - 18] = v;
     }
     __syncthreads();
     if (do_pose && have) {
-        for (int w = part * 256 + tid; w < 4 * M; w += 256 * nsplit) {
+        for (int w = part * 256 + tid; w < 2 * M; w += 256 * nsplit) {       // (rotation c, point i): votes for (R_c, t) and (R_c, -t)
             const int c = w / M, i = w - c * M;
-            const double tt[3] = {c < 2 ? sT[0] : -sT[0], c < 2 ? sT[1] : -sT[1], c < 2 ? sT[2] : -sT[2]};
-            if (cheirality(sR[c & 1], tt, a[2 * i], a[2 * i + 1], b[2 * i], b[2 * i + 1])) atomicAdd(&sgood[c], 1);
+            bool okp, okn;
+            cheirality_pair(sR[c], sT, a[2 * i], a[2 * i + 1], b[2 * i], b[2 * i + 1], okp, okn);
+            if (okp) atomicAdd(&sgood[c], 1);
+            if (okn) atomicAdd(&sgood[c + 2], 1);
         }
     }
     __syncthreads();
@@ -1337,7 +1401,8 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
         }
     }
     const int nsplit = std::max(1, std::min(32, (4 * mcap + 4095) / 4096));       // ~16 triangulations per thread
-    hipLaunchKernelGGL(k_pose_final, dim3(npairs, nsplit), dim3(256), 0, st, P, d_n1, d_n2, d_models, d_rstate, d_E_in, d_mask, d_pose, do_pose);
+    if (do_pose) hipLaunchKernelGGL(k_pose_svd, dim3((npairs + 63) / 64), dim3(64), 0, st, P, (const double*)d_models, (const int32_t*)d_rstate, d_E_in, d_hyp, npairs);
+    hipLaunchKernelGGL(k_pose_final, dim3(npairs, nsplit), dim3(256), 0, st, P, d_n1, d_n2, d_models, d_rstate, d_E_in, d_mask, d_pose, do_pose, (const double*)d_hyp);
     HIPCHK(ctx, hipGetLastError());
     return VIS_OK;
 }
