@@ -16,6 +16,8 @@ algorithms*: a second implementation written from the definition, not from the o
   (i) recoverPose from numpy SVDs (four candidates, DLT triangulation, cheirality vote)        vs orc_recover_pose (same winner / count, 1e-9)
   (j) the cyclic Jacobi iteration on A^T A and on D A^T A D, D = diag(1, 1, 1, -1) (t -> -t): V' = D V D bit for bit -- the
       identity k_pose_final uses to triangulate once for (R, t) and (R, -t)
+  (k) Matcher::computeBestMatches (ratio, mutual best, y sort, 7 x 7 grid with float32 running bounds) from the reference's
+      control flow, both symmetry modes                                                        vs orc_good_matches (exact)
 """
 import numpy as np
 import pytest
@@ -585,3 +587,71 @@ def test_jacobi_is_equivariant_under_negating_the_last_column():
             for j in range(4):
                 assert Vn[i][j] == D[i] * Vp[i][j] * D[j], (trial, i, j)
     assert checked >= 290
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (k) Matcher::computeBestMatches (src/Matcher.cpp:96-244, 309-352) written out again in Python from the reference's control
+#     flow, with the behaviour DESIGN.md specifies where the reference has undefined behaviour (second direction effectively not
+#     ratio-filtered, column index clamped, empty input -> empty output, stable y sort) -- against orc_good_matches on real keypoints
+def _best_matches_py(p, kps1, knn12, knn21, intended):
+    ratio = float(np.float32(p.ratio))                         # double nn_match_ratio = 0.8f
+    def survives(row):                                         # nnFilter: two neighbours and not d0 > ratio * d1
+        return row[1]["trainIdx"] >= 0 and not (float(row[0]["distance"]) > ratio * float(row[1]["distance"]))
+    sym = []
+    for q in range(len(knn12)):
+        r1 = knn12[q]
+        if r1[0]["trainIdx"] < 0 or not survives(r1):
+            continue
+        t = int(r1[0]["trainIdx"])
+        r2 = knn21[t]                                          # the aux2 entry whose queryIdx is t
+        if r2[0]["trainIdx"] < 0 or (intended and not survives(r2)):
+            continue
+        if int(r2[0]["trainIdx"]) == q:
+            sym.append((q, t, np.float32(r1[0]["distance"])))
+    order = sorted(range(len(sym)), key=lambda i: (np.float32(kps1[sym[i][0]]["y"]), i))       # sortIdx on pt.y, made stable
+    srt = [sym[i] for i in order]
+    root = int(np.floor(np.sqrt(p.n_cells)))
+    winw = np.float32(p.w_size / np.floor(np.sqrt(p.n_cells)))
+    winh = np.float32(p.h_size / np.floor(np.sqrt(p.n_cells)))
+    good = []
+    it = 0
+    h_final = winh
+    for _ in range(root):
+        if it >= len(srt):
+            break
+        cell = [None] * root
+        while it < len(srt) and np.float32(kps1[srt[it][0]]["y"]) <= h_final:
+            w_final = winw
+            i = 0
+            while np.float32(kps1[srt[it][0]]["x"]) > w_final:
+                w_final = np.float32(w_final + winw)
+                i += 1
+            i = min(i, root - 1)
+            if cell[i] is None or srt[it][2] < cell[i][2]:
+                cell[i] = srt[it]
+            it += 1
+        good += [c for c in cell if c is not None]
+        h_final = np.float32(h_final + winh)
+    return sym, good
+
+
+@pytest.mark.parametrize("intended", [0, 1])
+def test_match_filters_rederived(vislam, orc, intended):
+    p = vislam.default_params()
+    p.nfeatures, p.nlevels, p.w_size, p.h_size, p.sym_mode = 600, 8, 640, 480, intended
+    op = orc.Params()
+    for f, _ in p._fields_:
+        setattr(op, f, getattr(p, f))
+    cv = vislam.synth_canvas(2048, 0xE0C00001)
+    frames = [vislam.synth_frame(cv, t, 640, 480) for t in (0, 3, 11)]
+    det = [orc.orb_detect_compute(op, f) for f in frames]
+    total = 0
+    for (k1, d1), (k2, d2) in zip(det[:-1], det[1:]):
+        knn12, knn21 = orc.knn2_hamming(d1, d2)
+        good, sym = orc.good_matches(op, k1, k2, knn12, knn21)
+        psym, pgood = _best_matches_py(p, k1, knn12, knn21, intended)
+        assert [(int(m["queryIdx"]), int(m["trainIdx"]), float(m["distance"])) for m in sym] == [(q, t, float(d)) for q, t, d in psym]
+        assert [(int(m["queryIdx"]), int(m["trainIdx"]), float(m["distance"])) for m in good] == [(q, t, float(d)) for q, t, d in pgood]
+        assert 10 <= len(pgood) <= 49
+        total += len(pgood)
+    assert total > 40
