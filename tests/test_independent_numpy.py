@@ -18,6 +18,8 @@ algorithms*: a second implementation written from the definition, not from the o
       identity k_pose_final uses to triangulate once for (R, t) and (R, -t)
   (k) Matcher::computeBestMatches (ratio, mutual best, y sort, 7 x 7 grid with float32 running bounds) from the reference's
       control flow, both symmetry modes                                                        vs orc_good_matches (exact)
+  (l) VISystem::F2FRansac from the reference's statements (bearings, epipolar-plane normals, log10 inlier test, strictly
+      larger count wins)                                                                       vs orc_f2f_ransac (same count, 1e-6)
 """
 import numpy as np
 import pytest
@@ -655,3 +657,48 @@ def test_match_filters_rederived(vislam, orc, intended):
         assert 10 <= len(pgood) <= 49
         total += len(pgood)
     assert total > 40
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (l) VISystem::F2FRansac (src/VISystem.cpp:612-769) written out again with numpy from the reference's statements: unit bearings
+#     in double from float pixel coordinates and float intrinsics, normal_i = v1 x (R v2), d = normalise(n_a x n_b) for the given
+#     sample pairs, count of -1000 / log10(|d . n_i|) < threshold, strictly larger count wins, result = scale * (float)d
+def test_f2f_ransac_rederived(vislam, orc):
+    p = vislam.default_params()
+    op = orc.Params()
+    for f, _ in p._fields_:
+        setattr(op, f, getattr(p, f))
+    rng = np.random.default_rng(31)
+    KP = vislam.KEYPOINT_DTYPE
+    for trial, m in enumerate((40, 12, 3, 2)):
+        w = rng.normal(0, 0.05, 3); th = np.linalg.norm(w)
+        Kx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]) / th
+        R = (np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx).astype(np.float32)
+        X = np.column_stack([rng.uniform(-2, 2, m), rng.uniform(-1.5, 1.5, m), rng.uniform(3, 9, m)])
+        t = rng.normal(0, 0.3, 3)
+        a = np.zeros(m, KP); b = np.zeros(m, KP)
+        X2 = (X - t) @ R.astype(np.float64)                                                  # frame 2 sees R^T (X - t)
+        a["x"] = p.fx * X[:, 0] / X[:, 2] + p.cx; a["y"] = p.fy * X[:, 1] / X[:, 2] + p.cy
+        b["x"] = p.fx * X2[:, 0] / X2[:, 2] + p.cx + rng.normal(0, 0.3, m); b["y"] = p.fy * X2[:, 1] / X2[:, 2] + p.cy + rng.normal(0, 0.3, m)
+        idx = rng.integers(0, max(m - 1, 1), (1000, 2)).astype(np.int32)
+        scale = 0.37
+        got, cnt = orc.f2f_ransac(op, a, b, R, idx, scale)
+        fx, fy, cx, cy = (np.float32(v) for v in (p.fx, p.fy, p.cx, p.cy))
+        def bearing(k):
+            v = np.array([np.float64((k["x"] - cx) / fx), np.float64((k["y"] - cy) / fy), 1.0])     # float arithmetic, then double
+            return v / np.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
+        normals = [np.cross(bearing(a[i]), R.astype(np.float64) @ bearing(b[i])) for i in range(m)]
+        best, cmax = np.zeros(3, np.float32), 0
+        for i1, i2 in idx:
+            d = np.cross(normals[i1], normals[i2])
+            if not d.any():
+                continue
+            d = d / np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])
+            c = 0
+            for n in normals:
+                with np.errstate(divide="ignore"):
+                    c += bool(-1000.0 / np.log10(abs(float(d @ n))) < p.f2f_threshold)
+            if c > cmax:
+                cmax, best = c, d.astype(np.float32)
+        assert cnt == cmax, (trial, cnt, cmax)
+        assert np.abs(got - np.float32(scale) * best).max() <= 1e-6, (trial, got, best)
