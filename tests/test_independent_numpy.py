@@ -20,6 +20,8 @@ algorithms*: a second implementation written from the definition, not from the o
       control flow, both symmetry modes                                                        vs orc_good_matches (exact)
   (l) VISystem::F2FRansac from the reference's statements (bearings, epipolar-plane normals, log10 inlier test, strictly
       larger count wins)                                                                       vs orc_f2f_ransac (same count, 1e-6)
+  (m) the RANSAC loop of findEssentialMat in Python (cv::RNG stream, getSubset, float Sampson test, accept rule,
+      RANSACUpdateNumIters; candidate models from the oracle's solver)                         vs orc_essential_ransac (iterations, mask, E exact)
 """
 import numpy as np
 import pytest
@@ -702,3 +704,68 @@ def test_f2f_ransac_rederived(vislam, orc):
                 cmax, best = c, d.astype(np.float32)
         assert cnt == cmax, (trial, cnt, cmax)
         assert np.abs(got - np.float32(scale) * best).max() <= 1e-6, (trial, got, best)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (m) the RANSAC loop of findEssentialMat (RANSACPointSetRegistrator::run) written out again in Python: cv::RNG's multiply-with-
+#     carry stream, getSubset (five distinct indices, redraw on duplicates), float Sampson error against the float threshold,
+#     "strictly more than max(best, 4) inliers" accept rule, RANSACUpdateNumIters -- with the oracle's minimal solver for the
+#     candidate models -- against orc_essential_ransac: same iteration count, same mask, same E
+def test_ransac_loop_rederived(vislam, orc):
+    import math
+    p = vislam.default_params()
+    p.fy = p.fx
+    op = orc.Params()
+    for f, _ in p._fields_:
+        setattr(op, f, getattr(p, f))
+    rng = np.random.default_rng(4)
+    for trial, (n, nout, noise) in enumerate(((49, 0, 0.0), (60, 18, 0.4), (25, 10, 0.8), (7, 1, 0.2))):
+        X = np.column_stack([rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), rng.uniform(3, 9, n)])
+        w = rng.normal(0, 0.1, 3); th = np.linalg.norm(w)
+        Kx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]) / th
+        R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+        t = rng.normal(0, 0.5, 3)
+        X2 = X @ R.T + t
+        x1 = np.column_stack([p.fx * X[:, 0] / X[:, 2] + p.cx, p.fx * X[:, 1] / X[:, 2] + p.cy]) + rng.normal(0, noise, (n, 2))
+        x2 = np.column_stack([p.fx * X2[:, 0] / X2[:, 2] + p.cx, p.fx * X2[:, 1] / X2[:, 2] + p.cy]) + rng.normal(0, noise, (n, 2))
+        x2[:nout] = rng.uniform(0, 480, (nout, 2))
+        x1 = x1.astype(np.float32); x2 = x2.astype(np.float32)
+        oE, omask, oninl, oiters = orc.essential_ransac(op, x1, x2)
+        # --- the loop, from its definition
+        q1 = (x1.astype(np.float64) - [p.cx, p.cy]) * (1.0 / p.fx)
+        q2 = (x2.astype(np.float64) - [p.cx, p.cy]) * (1.0 / p.fx)
+        thr = np.float32((p.ransac_threshold / p.fx) ** 2)
+        state = p.ransac_seed if p.ransac_seed else 0xFFFFFFFF
+        def nxt():
+            nonlocal state
+            state = ((state & 0xFFFFFFFF) * 4164903690 + (state >> 32)) & 0xFFFFFFFFFFFFFFFF
+            return state & 0xFFFFFFFF
+        niters, best_good, best_mask, bestE, it = max(p.ransac_max_iters, 1), 0, np.zeros(n, np.uint8), np.zeros((3, 3)), 0
+        while it < niters:
+            idx = []
+            while len(idx) < 5:
+                v = nxt() % n
+                if v not in idx:
+                    idx.append(v)
+            for E in orc.five_point(q1[idx], q2[idx]):
+                Ex = q1 @ E[:, :2].T + E[:, 2]                    # rows of E applied to (x1, y1, 1)
+                Et = q2 @ E[:2, :] + E[2, :]                      # E^T applied to (x2, y2, 1)
+                num = ((q2[:, 0] * Ex[:, 0] + q2[:, 1] * Ex[:, 1]) + Ex[:, 2]) ** 2
+                den = ((Ex[:, 0] ** 2 + Ex[:, 1] ** 2) + Et[:, 0] ** 2) + Et[:, 1] ** 2
+                mask = ((num / den).astype(np.float32) <= thr).astype(np.uint8)
+                good = int(mask.sum())
+                if good > max(best_good, 4):
+                    best_good, best_mask, bestE = good, mask, E
+                    if p.ransac_adaptive:
+                        ep = min(max((n - good) / n, 0.0), 1.0)
+                        num_l = max(1.0 - p.ransac_prob, 2.2250738585072014e-308)
+                        den_l = 1.0 - (1.0 - ep) ** 5
+                        if den_l < 2.2250738585072014e-308:
+                            niters = 0
+                        else:
+                            a, b = math.log(num_l), math.log(den_l)
+                            niters = niters if (b >= 0 or -a >= niters * (-b)) else int(np.rint(a / b))
+            it += 1
+        assert (oninl, oiters) == (best_good, it), (trial, oninl, oiters, best_good, it)
+        assert np.array_equal(omask, best_mask)
+        assert np.abs(oE - bestE).max() == 0
