@@ -831,6 +831,7 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
     hipStream_t sA = ctx->stream, sM = ctx->match_stream, sP = ctx->pose_stream;
     ctx->tm.launches_total = 0;
     const bool detect = (stages & VIS_STAGE_DETECT) != 0;
+    if ((stages & (VIS_STAGE_UPDATE | VIS_STAGE_GRADIENT)) && ((pl->w & 15) || (pl->h & 15))) { ctx->err = "VIS_STAGE_UPDATE: w, h must be multiples of 16"; return VIS_E_INVALID; }
     const int cur = detect ? (pl->run_count & 1) : (pl->last_base / pl->rec_per_set);   // run_count is committed only when every launch succeeded
     const int base = cur * pl->rec_per_set;
     int rc = VIS_OK;
@@ -843,15 +844,20 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
     // Camera::Update (src/Camera.cpp:63-72): the half pyramid of every frame of the batch.  Nothing of the detect chain reads it
     // and it is pure streaming work, so it runs on a stream of its own beside the (vector-ALU bound) detect kernels; the detect
     // stream joins it at the end of its chain, so "the detect stream is done" still means "d_frames may be reused".
+    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[0], sA);
+    if (detect) { VisRange r_("vis: ORB detect + describe"); rc = launch_detect(ctx, pl, d_frames, n, base + 1, pl->carry_from > 0 ? pl->carry_from : -1,
+                                                                             (stages & (VIS_STAGE_UPDATE | VIS_STAGE_GRADIENT)) ? ctx->ev_update_fork : nullptr); if (rc) return rc; }
+    else if (ctx->ev_ok) for (int i = 1; i <= 4; i++) (void)hipEventRecord(ctx->ev[i], sA);
     hipStream_t sU = ctx->update_stream;
     pl->half_valid = false; pl->grad_valid = false;
     bool update_queued = false;
     if (stages & (VIS_STAGE_UPDATE | VIS_STAGE_GRADIENT)) {
         VisRange r_("vis: Camera::Update half pyramid");
-        if ((pl->w & 15) || (pl->h & 15)) { ctx->err = "VIS_STAGE_UPDATE: w, h must be multiples of 16"; return VIS_E_INVALID; }
         if (!pl->d_half) HIPCHK(ctx, hipMalloc((void**)&pl->d_half, (size_t)pl->B * vis_grad_frame_elems(pl->w, pl->h)));
-        // the frames were produced on the detect stream (or before the call): order the side stream behind it
-        HIPCHK(ctx, hipEventRecord(ctx->ev_update_fork, sA));
+        // the frames were produced on the detect stream (or before the call): the side stream is ordered behind it -- behind the
+        // PYRAMID launches of this batch's detect chain (launch_detect recorded the event there): the resize chain streams at HBM
+        // speed itself, the kernels after it are vector-ALU bound, and that is where streaming work fits beside them
+        if (!detect) HIPCHK(ctx, hipEventRecord(ctx->ev_update_fork, sA));
         HIPCHK(ctx, hipStreamWaitEvent(sU, ctx->ev_update_fork, 0));
         // the previous batch's alignment (vis_batch_align on the pose stream) may still read the half pyramid / the gradients
         if (ctx->align_pending) HIPCHK(ctx, hipStreamWaitEvent(sU, ctx->ev_align_done, 0));
@@ -873,9 +879,6 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
         update_queued = true;
         pl->half_valid = true;
     }
-    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[0], sA);
-    if (detect) { VisRange r_("vis: ORB detect + describe"); rc = launch_detect(ctx, pl, d_frames, n, base + 1, pl->carry_from > 0 ? pl->carry_from : -1); if (rc) return rc; }
-    else if (ctx->ev_ok) for (int i = 1; i <= 4; i++) (void)hipEventRecord(ctx->ev[i], sA);
     if (update_queued) HIPCHK(ctx, hipStreamWaitEvent(sA, ctx->ev_update_done, 0));
     HIPCHK(ctx, hipEventRecord(ctx->ev_detect_done, sA));
     if (stages & (VIS_STAGE_MATCH | VIS_STAGE_POSE)) HIPCHK(ctx, hipStreamWaitEvent(sM, ctx->ev_detect_done, 0));

@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(256) void k_small_ops(SmallOps J) {
     }
 }
 
-int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int rec0, int carry_rec) {
+int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int rec0, int carry_rec, hipEvent_t after_resize) {
     hipStream_t st = ctx->stream;
     const int L = pl->L;
     {
@@ -1137,6 +1137,7 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
                                pl->d_pyr[l], V.w, V.h, V.stride, V.frame_bytes, scale_x, scale_y, bxc, per_frame, n, (const uint32_t*)nullptr);
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[1], st);
+    if (after_resize) HIPCHK(ctx, hipEventRecord(after_resize, st));      // the side stream's streaming work starts here (vis_batch_run)
     const int t_base = ctx->p.fast_threshold;
     const int32_t* tau = pl->speculate ? pl->d_tau : nullptr;            // batched streams only (see fast_tile)
     {
