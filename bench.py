@@ -405,22 +405,22 @@ def main():
         q3.nfeatures, q3.nlevels, q3.w_size, q3.h_size = 4000, 4, 1920, 1080
         q3.fy = q3.fx
         q3.ransac_adaptive, q3.ransac_max_iters, q3.pose_input = 0, 2000, 1
-        guarded("config3_s1080", lambda: dict(run_leg(dev, 1920, 1080, 32, 2, q3, 0xE0C00003, 8192, 5, 2),
+        guarded("config3_s1080", lambda: dict(run_leg(dev, 1920, 1080, 128, 2, q3, 0xE0C00003, 8192, 5, 2),
                 what="BASELINE configs[2]: 1920x1080, 4-level pyramid, 4000 kps/frame, 4000x4000 knn both directions, essential RANSAC with a FIXED "
-                     "2000 iterations on the un-gridded symmetric matches (pose_input = SYM) + recoverPose; 32 frames per step"))
+                     "2000 iterations on the un-gridded symmetric matches (pose_input = SYM) + recoverPose; 128 frames per step"))
         q5 = vislam.default_params()
         q5.nfeatures, q5.nlevels, q5.w_size, q5.h_size = 8000, 8, 3840, 2160
         q5.fy = q5.fx
         def leg5():
-            r = run_leg(dev, 3840, 2160, 8, 2, q5, 0xE0C00005, 8192, 5, 2)
+            r = run_leg(dev, 3840, 2160, 32, 2, q5, 0xE0C00005, 8192, 5, 2)
             n5 = 8000
             kn = r["kernels_ms_per_step"]["ms_knn"]
             r["matcher"] = {"pairs_per_distance_matrix": n5 * n5, "valu_lane_ops_per_matrix": 16 * n5 * n5,
-                            "distance_matrices_per_s": 8 / (kn * 1e-3) if kn > 0 else None,
-                            "equivalent_popcount_lane_ops_per_s": 16.0 * n5 * n5 * 8 / (kn * 1e-3) if kn > 0 else None,
-                            "note": "one matrix serves both knn directions (the reference computes it twice); computed on the int8 matrix cores, "
+                            "distance_matrices_per_s": 32 / (kn * 1e-3) if kn > 0 else None,
+                            "equivalent_popcount_lane_ops_per_s": 16.0 * n5 * n5 * 32 / (kn * 1e-3) if kn > 0 else None,
+                            "note": "one matrix serves both knn directions (the reference computes it twice); computed on the FP4 matrix cores (e2m1 +-1, exact), "
                                     "the lane-op figure is the xor+popcount work it replaces (SURVEY 8(d))"}
-            r["what"] = "BASELINE configs[4]: 3840x2160, 8 levels, 8000 kps/frame, 8000x8000 BF-Hamming all-pairs, filters, pose; 8 frames per step"
+            r["what"] = "BASELINE configs[4]: 3840x2160, 8 levels, 8000 kps/frame, 8000x8000 BF-Hamming all-pairs, filters, pose; 32 frames per step"
             return r
         guarded("config5_s2160", leg5)
 
