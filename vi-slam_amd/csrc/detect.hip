@@ -699,11 +699,15 @@ __global__ __launch_bounds__(256) void k_tau_update(const int32_t* __restrict__ 
 // k_describe: one wave per keypoint
 #define PR 21                 // raw patch radius: 18 (max rotated sample offset) + 3 (blur taps)
 #define PW 43
+#ifdef VIS_DESC_VALU_HPASS     // A/B build: the round-3 horizontal pass on the vector ALU
 #define PS 44                 // raw patch LDS row stride
+#else
+#define PS 48                 // raw patch LDS row stride: 16-byte rows, the MFMA A operand of the row pass is one aligned ds_read_b128
+#endif
 #define HW 40                 // horizontally blurred columns stored (patch cols 3..42; samples use 3..39)
 #define HTS 46                // the row-blurred patch is stored TRANSPOSED: hbT[col][row], 46 u16 per column (odd dword
                               // stride): the 7 vertical taps of a sample are then 4 consecutive dwords
-#define WAVE_LDS (PW * PS + HW * HTS * 2 + 8)     // bytes per wave, multiple of 4
+#define WAVE_LDS ((PW * PS + HW * HTS * 2 + 8 + 15) / 16 * 16)     // bytes per wave, multiple of 16 (>= 4 spare bytes behind the blur buffer)
 
 // the rBRIEF pattern as floats (x0, y0, x1, y1 per bit): the rotation works on floats, and 1024 int8 -> float conversions
 // per keypoint are not free
@@ -823,21 +827,68 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
             run += l < D.L ? SC.c[l] : 0;
         }
     }
+#ifdef VIS_DESC_VALU_HPASS
+#define PATCH_BIAS 0u
+#define PATCH_DOT4(p, w) ((int)__builtin_amdgcn_udot4((p), (w), 0u, false))
+#else
+    // The patch is kept in LDS as SIGNED bytes (pixel - 128: the i8 matrix instruction has no unsigned form).  The IC moments do not
+    // notice: sum u (I - 128) = sum u I and sum v (I - 128) = sum v I over the symmetric disc, in exact integers.
+#define PATCH_BIAS 0x80808080u
+#define PATCH_DOT4(p, w) (__builtin_amdgcn_sdot4((int)(p), (int)(w), 0, false))
+    // B operand of the row pass (see there): dword q of lane (g, j) = taps e .. e + 3, e = 16 g + 4 q - j, taps outside 0 .. 6 = 0
+    typedef int v4i_t0 __attribute__((ext_vector_type(4)));
+    v4i_t0 hp_b;
+    {
+        const unsigned long long K = (unsigned long long)G.k0 | ((unsigned long long)G.k1 << 32);
+        const int e0 = 16 * (lane >> 4) - (lane & 15);
+        uint32_t bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int e = e0 + 4 * q;
+            bq[q] = (e >= 7 || e <= -4) ? 0u : (e >= 0 ? (uint32_t)(K >> (8 * (e & 7))) : (uint32_t)(K << (8 * ((-e) & 7))));
+        }
+        hp_b = v4i_t0{(int)bq[0], (int)bq[1], (int)bq[2], (int)bq[3]};
+    }
+    const int hp_c0 = 128 * (G.kq[0] + G.kq[1] + G.kq[2] + G.kq[3] + G.kq[4] + G.kq[5] + G.kq[6]);
+#endif
     const int lrs = (lane * 47) >> 9, lc = lane - lrs * 11;          // patch map: lane = (row % 5 [+ spare rows], dword); lane / 11
     uint8_t* const lw = raw + lrs * PS + 4 * lc;
-    for (int g = kb * 4 + wv; g < total; g += (int)gridDim.y * 4) {
+    const uint2* const ic_tb = reinterpret_cast<const uint2*>(G.angle_tab) + min(lane, 62);
+    // The kept-keypoint record (x, y, response, y << 16 | x) is wave-uniform: it comes through the SCALAR cache, and the record of the
+    // wave's NEXT keypoint is requested one iteration ahead, so its HBM latency runs beside this keypoint's work instead of in front
+    // of the patch loads (a keypoint was a chain of four exposed memory round trips: record -> patch -> IC weights -> pattern).
+    typedef uint32_t u32x4_s __attribute__((ext_vector_type(4)));
+    auto rec_request = [&](int gq) -> u32x4_s {
+        const int lq = __popcll(__builtin_amdgcn_ballot_w64(gq >= vstart)) - 1;
+        const int iq = gq - __builtin_amdgcn_readlane(vstart, lq);
+        const float4* p = D.lv[lq].seg_kp + ((size_t)f * D.lv[lq].keep_cap + iq);
+        // a load through the CONSTANT address space with a wave-uniform address = s_load_dwordx4 that the compiler's own wait-count
+        // bookkeeping tracks (k_select wrote the records in an earlier launch; nothing in this kernel writes them)
+        return *(const __attribute__((address_space(4))) u32x4_s*)(uintptr_t)p;
+    };
+    const int gstride = (int)gridDim.y * 4;
+    int g = kb * 4 + wv;
+    if (g >= total) return;
+    // the rBRIEF pattern of this lane's four bits stays in registers for all keypoints of the wave (it was re-read per keypoint:
+    // 4 of a keypoint's 21 vector memory instructions and one more exposed round trip)
+    float4 pat[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) pat[k] = *reinterpret_cast<const float4*>(g_pattern + 4 * (lane + 64 * k));
+    u32x4_s rec_next = rec_request(g);
+    for (; g < total; g += gstride) {
+    const u32x4_s rec = rec_next;
     const int lev = __popcll(__builtin_amdgcn_ballot_w64(g >= vstart)) - 1;       // level-major packed index -> (level, index in level)
-    const int idx = g - __builtin_amdgcn_readlane(vstart, lev);
     const LevelArgs& A = D.lv[lev];
     const int stride = A.stride;
-    const float4 kpr = A.seg_kp[(size_t)f * A.keep_cap + idx];
-    const uint32_t xy = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(kpr.w));
+    struct { float x, y, z; } kpr = {__uint_as_float(rec.x), __uint_as_float(rec.y), __uint_as_float(rec.z)};
+    const uint32_t xy = rec.w;
     const int x0 = (int)(xy & 0xFFFFu), y0 = (int)(xy >> 16);
     const uint8_t* img = A.img + (size_t)f * A.frame_bytes + (size_t)(y0 - PR) * stride + (x0 - PR);
     // 43 rows x 44 bytes as 11 unaligned dwords per row; lane = (row % 5, dword), 9 loads cover rows 0..44, all in flight
     // before the first LDS write.  No predicates: the spare lanes 55..63 copy rows 5, 10, .. 45 once more, rows beyond 42
     // repeat row 42, and what is stored beyond row 42 lands in the first bytes of the blur buffer, which the horizontal
     // pass rewrites before anything reads it.
+    uint2 icw[5];
     {
         const uint32_t goff = (uint32_t)(__mul24(lrs, stride) + 4 * lc);
         const int gstep = 5 * stride;
@@ -847,8 +898,12 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
         // rows 40 .. 45: clamped to the last patch row (with the smallest legal edge_threshold, 22, rows 43 .. 45 may lie
         // below the image)
         v[8] = *reinterpret_cast<const u32_unaligned*>(img + (uint32_t)(__mul24(min(lrs + 40, PW - 1), stride) + 4 * lc));
+        // the IC weight records of this lane travel with the patch (their L2 latency is not paid a second time behind the barrier)
 #pragma unroll
-        for (int k = 0; k < 9; k++) *reinterpret_cast<uint32_t*>(lw + k * 5 * PS) = v[k];
+        for (int k = 0; k < 5; k++) icw[k] = ic_tb[63 * k];
+        rec_next = rec_request(min(g + gstride, total - 1));
+#pragma unroll
+        for (int k = 0; k < 9; k++) *reinterpret_cast<uint32_t*>(lw + k * 5 * PS) = v[k] ^ PATCH_BIAS;
     }
     WAVE_SYNC();
     // IC angle over the radius-15 disc: each (row, dword) item is two byte dot products against a
@@ -858,19 +913,19 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
     if (lane < 63) {
         const int rs = (lane * 57) >> 9, dw = lane - rs * 9;          // lane / 9
         const uint8_t* pr = raw + (PR - 15 + rs) * PS + 4 + 4 * dw;
-        const uint2* tb = reinterpret_cast<const uint2*>(G.angle_tab) + lane;
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const uint32_t pixw = *reinterpret_cast<const uint32_t*>(pr + k * 7 * PS);
-            const uint2 wm = tb[63 * k];
-            const int a = (int)__builtin_amdgcn_udot4(pixw, wm.x, 0u, false);
-            const int b = (int)__builtin_amdgcn_udot4(pixw, wm.y, 0u, false);
+            const uint2 wm = icw[k];
+            const int a = PATCH_DOT4(pixw, wm.x);
+            const int b = PATCH_DOT4(pixw, wm.y);
             sA += a; sB += b; sC += __mul24(rs + 7 * k - 15, b);
         }
     }
     sA = wave_sum(sA); sB = wave_sum(sB); sC = wave_sum(sC);
     const int m10 = sA - 16 * sB, m01 = sC;
     const float angle = fast_atan2_deg((float)m01, (float)m10);
+#ifdef VIS_DESC_VALU_HPASS
     // horizontal 7-tap pass over all rows, patch columns 3..42.  One task = (row pair, group of 4 outputs):
     // 2 x 3 dword reads, byte windows by v_alignbyte, 2 x v_dot4_u32_u8 per output; the two rows of a column are
     // one dword of the transposed buffer (hbT[col][row], 23 dwords per column).  lane = (pair % 6, group).
@@ -898,6 +953,48 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
             }
         }
     }
+#else
+    // Horizontal 7-tap pass on the MATRIX pipe: H = (patch - 128) x T + 128 * sum(w) with the banded constant T[k][c] = w[k - c],
+    // exact in the i32 accumulators of v_mfma_i32_16x16x64_i8.  Tile (t, n) = rows 16t .. 16t+15, blur columns 16n .. 16n+15: the A
+    // operand of lane (g, i) is the 16 patch bytes of row 16t + i from column 16n + 16g (one aligned ds_read_b128; only the first
+    // 22 columns meet a non-zero weight), the B operand -- lane (g, j): w[16g + s - j], s = 0 .. 15 -- is the SAME for every tile
+    // (the band only moves with the columns A starts at).  Lane (g, j) receives rows 16t + 4g .. + 3 of column 16n + j = two
+    // dwords of the transposed blur buffer: 2 v_perm_b32 + one 8-byte LDS store per tile instead of 80 v_dot4 per keypoint.
+    // Rows 43 .. 47 (beyond the patch: whatever follows it in LDS) only reach blur rows that no sample touches; the store of
+    // lanes g = 3 of the tiles t = 2 runs two rows over the column's 46 -- into rows 0, 1 of the next column, which the t = 0
+    // tile of that column writes AFTERWARDS (one wave's LDS stores execute in order; the last column runs into the spare bytes).
+    {
+        const int hi_ = lane & 15, hg = lane >> 4;
+        const uint8_t* abase = raw + hi_ * PS + 16 * hg;
+        uint32_t* wbase = hb32 + hi_ * (HTS / 2) + 2 * hg;
+        typedef int v4i_t __attribute__((ext_vector_type(4)));
+        const v4i_t cin = {hp_c0, hp_c0, hp_c0, hp_c0};
+        const bool c2 = hi_ < HW - 32;           // the third column tile holds blur columns 32 .. 39 only (the matrix instruction itself always runs with every lane)
+        // the three column tiles of a row tile together: loads, matrix instructions, packs (the accumulators stay in VGPRs:
+        // -amdgpu-mfma-vgpr-form, Makefile); the store addresses of the second / third column tile are re-formed per keypoint
+        // (two full-rate adds) instead of living in registers across the loop
+        auto row_tiles = [&](int t) {
+            v4i_t av[3], d[3];
+#pragma unroll
+            for (int n = 0; n < 3; n++) av[n] = *reinterpret_cast<const v4i_t*>(abase + t * 16 * PS + 16 * n);
+#pragma unroll
+            for (int n = 0; n < 3; n++) d[n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[n], hp_b, cin, 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < 3; n++) {
+                const uint32_t lo = __builtin_amdgcn_perm((uint32_t)d[n].y, (uint32_t)d[n].x, 0x05040100u);
+                const uint32_t hi = __builtin_amdgcn_perm((uint32_t)d[n].w, (uint32_t)d[n].z, 0x05040100u);
+                uint32_t wofs = (uint32_t)(n * 16 * (HTS / 2) * 4);
+                asm volatile("" : "+v"(wofs));                       // keep it an add in the loop, not nine hoisted addresses
+                uint32_t* w = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(wbase) + wofs) + t * 8;
+                if (n < 2 || c2) { w[0] = lo; w[1] = hi; }
+            }
+        };
+        row_tiles(2);
+        WAVE_SYNC();
+        row_tiles(1);
+        row_tiles(0);
+    }
+#endif
     WAVE_SYNC();
     float ang = angle;
     ang *= G.rad_per_deg;
@@ -910,8 +1007,7 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
                                  + (uint32_t)((PR - 3) * (HTS * 2) + 2 * (PR - 3)));
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int bit = lane + 64 * k;
-        const float4 pt = *reinterpret_cast<const float4*>(g_pattern + 4 * bit);
+        const float4 pt = pat[k];
         int val[2];
 #pragma unroll
         for (int e = 0; e < 2; e++) {
@@ -925,7 +1021,15 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
             const float rx = rintf(fx), ry = rintf(fy);
             const uint32_t ab = (uint32_t)(int)__fmaf_rn(rx, (float)(HTS * 2), __fmaf_rn(ry, 2.f, tap0_f));
             const uint32_t* cw = (const uint32_t*)(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(ab & ~3u);
+            (void)cw;
             const uint32_t sh = ab & 2u;
+#if defined(VIS_TIMING_NOCONFLICT)       // timing experiment (results wrong): every lane gathers at its own bank
+            cw = (const uint32_t*)(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(hb32) + 16u * (uint32_t)lane + (ab & 0x800u));
+#endif
+#if defined(VIS_TIMING_ONEREAD)          // timing experiment (results wrong): one 16-bit gather per sample, no vertical taps
+            val[e] = *(const uint16_t*)(const __attribute__((address_space(3))) uint16_t*)(uintptr_t)(ab & ~1u);
+            continue;
+#endif
             const uint32_t w0 = cw[0], w1 = cw[1], w2 = cw[2], w3 = cw[3];
             typedef unsigned short us2 __attribute__((ext_vector_type(2)));
             const uint32_t t0 = __builtin_amdgcn_alignbyte(w1, w0, sh), t1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
