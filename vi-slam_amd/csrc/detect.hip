@@ -790,10 +790,34 @@ __device__ __forceinline__ int wave_sum(int v) {
            __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 
+// Three wave sums at once (exact integers, any order): after the first two butterfly steps the lanes of a quad carry DIFFERENT sums
+// (lane & 3 = 0: a, 1: b, 2 and 3: c), the remaining steps move whole quads -- row rotations by 4 and 8, then gfx950's
+// v_permlane16_swap / v_permlane32_swap between the rows -- so every lane ends with the total of its own sum: 17 vector
+// instructions + 3 v_readlane instead of 3 x (4 + 4 v_readlane + 3 scalar adds).
+__device__ __forceinline__ void wave_sum3(int& a, int& b, int& c) {
+    const int lane = (int)__lane_id();
+    a += __builtin_amdgcn_update_dpp(0, a, 0xB1, 0xF, 0xF, false);     // quad_perm [1,0,3,2]
+    b += __builtin_amdgcn_update_dpp(0, b, 0xB1, 0xF, 0xF, false);
+    c += __builtin_amdgcn_update_dpp(0, c, 0xB1, 0xF, 0xF, false);
+    int v = (lane & 1) ? b : a;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);     // quad_perm [2,3,0,1]
+    c += __builtin_amdgcn_update_dpp(0, c, 0x4E, 0xF, 0xF, false);
+    int w = (lane & 2) ? c : v;
+    w += __builtin_amdgcn_update_dpp(0, w, 0x124, 0xF, 0xF, false);    // row_ror:4
+    w += __builtin_amdgcn_update_dpp(0, w, 0x128, 0xF, 0xF, false);    // row_ror:8
+    typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+    v2u_t r = __builtin_amdgcn_permlane16_swap((unsigned)w, (unsigned)w, false, false);   // rows (0,1) and (2,3)
+    w = (int)(r.x + r.y);
+    r = __builtin_amdgcn_permlane32_swap((unsigned)w, (unsigned)w, false, false);         // the two halves
+    w = (int)(r.x + r.y);
+    a = __builtin_amdgcn_readlane(w, 0); b = __builtin_amdgcn_readlane(w, 1); c = __builtin_amdgcn_readlane(w, 2);
+}
+
 // Everything that identifies the keypoint (level, index, patch origin) is wave-uniform and is kept in SGPRs
 // (v_readfirstlane), so per-lane addresses are 32-bit offsets from scalar bases; lane -> (row, column)
 // mappings are fixed per phase, so the unrolled loops only add constants.
-__global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const int32_t* __restrict__ seg_cnt,
+// (at most 96 SGPRs: from 97 on the hardware admits one workgroup fewer per CU than the 7 that LDS and VGPRs allow)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96), amdgpu_waves_per_eu(7, 8))) void k_describe(DetLevels D, DescArgs G, const int32_t* __restrict__ seg_cnt,
                                                   vis_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                   int32_t* __restrict__ nkp, int kcap, int rec0,
                                                   int32_t* __restrict__ flags, int nframes) {
@@ -874,36 +898,40 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
     float4 pat[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) pat[k] = *reinterpret_cast<const float4*>(g_pattern + 4 * (lane + 64 * k));
-    u32x4_s rec_next = rec_request(g);
+    // Software pipeline over the wave's keypoints: the 9 patch dwords of the NEXT keypoint are requested in the middle of this one
+    // (right after the row pass has read the patch out of LDS) and stay in registers until the top of the next iteration; the record
+    // that gives their address was requested an iteration earlier through the scalar cache.  A keypoint was a chain of four exposed
+    // memory round trips (record -> patch -> IC weights -> pattern); now none of them is in front of its arithmetic.
+    uint32_t pv[9];
+    auto patch_request = [&](const u32x4_s& r, int gq) {
+        const int lq = __popcll(__builtin_amdgcn_ballot_w64(gq >= vstart)) - 1;
+        const LevelArgs& Aq = D.lv[lq];
+        const int sq = Aq.stride;
+        const int xq = (int)(r.w & 0xFFFFu), yq = (int)(r.w >> 16);
+        const uint8_t* img = Aq.img + (size_t)f * Aq.frame_bytes + (size_t)(yq - PR) * sq + (xq - PR);
+        // 43 rows x 44 bytes as 11 unaligned dwords per row; lane = (row % 5, dword), 9 loads cover rows 0..44.  No predicates: the
+        // spare lanes 55..63 copy rows 5, 10, .. 45 once more, rows beyond 42 repeat row 42, and what is stored beyond row 42 lands
+        // in the first bytes of the blur buffer, which the row pass rewrites before anything reads it.
+        const uint32_t goff = (uint32_t)(__mul24(lrs, sq) + 4 * lc);
+        const int gstep = 5 * sq;
+#pragma unroll
+        for (int k = 0; k < 8; k++) pv[k] = *reinterpret_cast<const u32_unaligned*>((img + (size_t)k * gstep) + goff);
+        // rows 40 .. 45: clamped to the last patch row (with the smallest legal edge_threshold, 22, rows 43 .. 45 may lie below the image)
+        pv[8] = *reinterpret_cast<const u32_unaligned*>(img + (uint32_t)(__mul24(min(lrs + 40, PW - 1), sq) + 4 * lc));
+    };
+    u32x4_s rec = rec_request(g);
+    u32x4_s rec_next = rec_request(min(g + gstride, total - 1));
+    patch_request(rec, g);
     for (; g < total; g += gstride) {
-    const u32x4_s rec = rec_next;
     const int lev = __popcll(__builtin_amdgcn_ballot_w64(g >= vstart)) - 1;       // level-major packed index -> (level, index in level)
     const LevelArgs& A = D.lv[lev];
-    const int stride = A.stride;
     struct { float x, y, z; } kpr = {__uint_as_float(rec.x), __uint_as_float(rec.y), __uint_as_float(rec.z)};
-    const uint32_t xy = rec.w;
-    const int x0 = (int)(xy & 0xFFFFu), y0 = (int)(xy >> 16);
-    const uint8_t* img = A.img + (size_t)f * A.frame_bytes + (size_t)(y0 - PR) * stride + (x0 - PR);
-    // 43 rows x 44 bytes as 11 unaligned dwords per row; lane = (row % 5, dword), 9 loads cover rows 0..44, all in flight
-    // before the first LDS write.  No predicates: the spare lanes 55..63 copy rows 5, 10, .. 45 once more, rows beyond 42
-    // repeat row 42, and what is stored beyond row 42 lands in the first bytes of the blur buffer, which the horizontal
-    // pass rewrites before anything reads it.
     uint2 icw[5];
     {
-        const uint32_t goff = (uint32_t)(__mul24(lrs, stride) + 4 * lc);
-        const int gstep = 5 * stride;
-        uint32_t v[9];
-#pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = *reinterpret_cast<const u32_unaligned*>((img + (size_t)k * gstep) + goff);
-        // rows 40 .. 45: clamped to the last patch row (with the smallest legal edge_threshold, 22, rows 43 .. 45 may lie
-        // below the image)
-        v[8] = *reinterpret_cast<const u32_unaligned*>(img + (uint32_t)(__mul24(min(lrs + 40, PW - 1), stride) + 4 * lc));
-        // the IC weight records of this lane travel with the patch (their L2 latency is not paid a second time behind the barrier)
 #pragma unroll
         for (int k = 0; k < 5; k++) icw[k] = ic_tb[63 * k];
-        rec_next = rec_request(min(g + gstride, total - 1));
 #pragma unroll
-        for (int k = 0; k < 9; k++) *reinterpret_cast<uint32_t*>(lw + k * 5 * PS) = v[k] ^ PATCH_BIAS;
+        for (int k = 0; k < 9; k++) *reinterpret_cast<uint32_t*>(lw + k * 5 * PS) = pv[k] ^ PATCH_BIAS;
     }
     WAVE_SYNC();
     // IC angle over the radius-15 disc: each (row, dword) item is two byte dot products against a
@@ -922,7 +950,7 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
             sA += a; sB += b; sC += __mul24(rs + 7 * k - 15, b);
         }
     }
-    sA = wave_sum(sA); sB = wave_sum(sB); sC = wave_sum(sC);
+    wave_sum3(sA, sB, sC);
     const int m10 = sA - 16 * sB, m01 = sC;
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 #ifdef VIS_DESC_VALU_HPASS
@@ -995,6 +1023,10 @@ __global__ __launch_bounds__(256) void k_describe(DetLevels D, DescArgs G, const
         row_tiles(0);
     }
 #endif
+    // the patch has left LDS: request the next keypoint's (and the record of the one after it)
+    rec = rec_next;
+    patch_request(rec, min(g + gstride, total - 1));
+    rec_next = rec_request(min(g + 2 * gstride, total - 1));
     WAVE_SYNC();
     float ang = angle;
     ang *= G.rad_per_deg;
