@@ -345,6 +345,9 @@ __device__ __forceinline__ pk16 pretest_axis(pk16 c, pk16 n, pk16 so, pk16 e, pk
 // pair of scalar loads instead of a level search + two integer divisions in SALU code
 struct FastTile { const uint8_t* img; uint32_t* cand; uint32_t frame_bytes; int w, h, stride, ox, oy; uint32_t ntiles_tile; int level; };   // ntiles_tile = ntiles << 16 | tile
 static_assert(sizeof(FastTile) == 48, "FastTile is read as s_load_dwordx8 + x4");
+#ifndef FAST_SPARSE_MAX
+#define FAST_SPARSE_MAX 6                   // fullest lane of a wave up to which the queue append walks set bits (fast_tile)
+#endif
 #define TILE_CAND_CAP (FT_W * FT_H / 4)     // 3x3 NMS bound per FT_W x FT_H tile: a tile's slot can never overflow
 
 // ONE launch for all pyramid levels of all frames.  Grid (8, tiles, ceil(frames / 8)): blockIdx.x is the XCD the workgroup
@@ -449,8 +452,9 @@ __device__ __forceinline__ void fast_tile(const FastTile& V, const uint8_t* __re
         const uint32_t kB = (uint32_t)(2 * K - 3) * 0x01010101u;
         const uint32_t passall = swar ? 0u : 0xFFFFFFFFu;
         constexpr int NIT = (SC_H + 7) / 8;
+        static_assert(NIT <= 8, "one mask byte per pixel of the unit");
         uint32_t pm[NIT];                                                // pass bits of the thread's unit in iteration it (bits 7, 15, 23, 31)
-        int n = 0;                                                       // candidates of this thread
+        uint32_t mask = 0;                                               // the same bits in ONE register
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
             pm[it] = 0;
@@ -471,9 +475,11 @@ __device__ __forceinline__ void fast_tile(const FastTile& V, const uint8_t* __re
                 const uint32_t nbright = ((dn + kB) & (ds + kB)) | ((de + kB) & (dw + kB));   // bit 7 set: a pair without a bright pixel
                 const uint32_t pass = (dark | ~nbright | passall) & cm;
                 pm[it] = pass;
-                n += __popc(pass);
+                mask |= (pass >> (7 - it)) & (0x01010101u << it);         // bit 8 j + it: pixel j of iteration it
+
             }
         }
+        int n = __popc(mask);                                            // candidates of this thread
         // halo score columns 0 and 129 (NMS neighbours of the first/last tile column): byte-wise test by the first 2*SC_H threads
         bool hp = false;
         int hpos = 0;
@@ -507,6 +513,28 @@ __device__ __forceinline__ void fast_tile(const FastTile& V, const uint8_t* __re
             uint32_t a_idx = q_base + 2u * (uint32_t)(qb + incl - n);           // byte address of the thread's next entry
             const uint32_t a_scr = q_base + 2u * (uint32_t)(SC_H * SC_W + lane);
             const int pos0 = (tid >> 5) * SC_W + 4 * q + 1;
+            // With the speculative threshold about 3 % of the positions pass (S-752), clustered: a thread has 0 .. 4 candidates, the
+            // fullest lane of a wave 4.4 on average -- a loop over the set bits (11 instructions and ONE store per round, the wave
+            // runs max-over-lanes rounds) then beats the fixed 80 instructions + 20 stores of the dense form below, which stays for
+            // waves with a crowded lane (corner-dense images, the fix-up pass at the base threshold).
+            int nmax = n - (hp ? 1 : 0);
+            nmax = max(nmax, __builtin_amdgcn_update_dpp(0, nmax, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+            nmax = max(nmax, __builtin_amdgcn_update_dpp(0, nmax, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+            nmax = max(nmax, __builtin_amdgcn_update_dpp(0, nmax, 0x141, 0xF, 0xF, false));    // row_half_mirror
+            nmax = max(nmax, __builtin_amdgcn_update_dpp(0, nmax, 0x140, 0xF, 0xF, false));    // row_mirror
+            const int wmax = max(max(__builtin_amdgcn_readlane(nmax, 0), __builtin_amdgcn_readlane(nmax, 16)),
+                                 max(__builtin_amdgcn_readlane(nmax, 32), __builtin_amdgcn_readlane(nmax, 48)));
+            if (wmax <= FAST_SPARSE_MAX) {
+                uint32_t m = mask;
+                for (int r = 0; r < wmax; r++) {                                  // wave-uniform trip count
+                    const bool has = m != 0;
+                    const int b = __builtin_ctz(m | 0x80000000u);
+                    m &= m - 1;
+                    const int pos = pos0 + (b & 7) * (8 * SC_W) + (b >> 3);
+                    *(lds_u16*)(uintptr_t)(has ? a_idx : a_scr) = (uint16_t)pos;
+                    a_idx += has ? 2u : 0u;
+                }
+            } else
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
 #pragma unroll
@@ -993,7 +1021,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96), amdgpu_wav
     // tile of that column writes AFTERWARDS (one wave's LDS stores execute in order; the last column runs into the spare bytes).
     {
         const int hi_ = lane & 15, hg = lane >> 4;
-        const uint8_t* abase = raw + hi_ * PS + 16 * hg;
+        // lanes g = 2, 3 only ever meet zero weights: they all read the patch's first bytes (one broadcast address per 16-lane
+        // group instead of 16 more addresses for the bank arbiter: the LDS array is this kernel's busiest unit, SQ_LDS_IDX_ACTIVE 97 %)
+        const uint8_t* abase = hg < 2 ? raw + hi_ * PS + 16 * hg : raw;
         uint32_t* wbase = hb32 + hi_ * (HTS / 2) + 2 * hg;
         typedef int v4i_t __attribute__((ext_vector_type(4)));
         const v4i_t cin = {hp_c0, hp_c0, hp_c0, hp_c0};
