@@ -15,6 +15,7 @@ Beside `value` the line carries (rank 0, N = 1 only, all OUTSIDE the timed regio
   legs.s752_fixed1000   the same stream with ransac_adaptive = 0: 1000 hypotheses per pair (the pose kernels loaded)
   legs.s752_parallax    "S-752P": two depth layers + independently moving objects (adaptive RANSAC does real work)
   legs.s752_results_d2h the headline step + a pinned, overlapped D2H copy of poses and good matches every step
+  legs.s752_mispredicted_thresholds  alternating incoherent batches: the cost of wrong FAST threshold predictions (redone inside the step)
   legs.config3_s1080    BASELINE configs[2]: 1920x1080, 4 levels, 4000 kps, RANSAC 2000 fixed iterations on the symmetric matches
   legs.config5_s2160    BASELINE configs[4]: 3840x2160, 8000 kps, 8000 x 8000 all-pairs
   legs.align_n4         SURVEY 8(f) N4: half pyramid + gradients + batched Gauss-Newton photometric alignment
@@ -141,9 +142,37 @@ def kernel_rooflines(fam, launches_fast, px, nfeat, B, nlevels):
     return out, alg
 
 
+MFMA_FP4_PEAK_PFLOPS = 10.0      # MI355X_MICROARCH.md "Matrix cores": FP6/FP4 dense ~10 PFLOP/s (the 20 PF headline figure includes 2:1 sparsity)
+
+
+def matcher_roofline(ms_knn, n_desc, pairs, pmc_path=None):
+    """north_star: 'L2-hit / VALU utilisation for the matcher against the chip's roofline'.  The matcher is k_expand + k_knn_mfma
+    (v_mfma_scale_f32_32x32x64_f8f6f4 on FP4 +-1 operands, exact).  Per frame pair the kernel computes TWO n x n distance matrices
+    (query->train and its transpose: the grid has a direction dimension, each direction keeps the row-wise top-2 of its own matrix),
+    256 multiply-accumulates per distance.  `achieved` = those MACs x 2 FLOP / ms_knn of THIS run (HIP events, k_expand included);
+    busy / hit fractions come from the committed counter passes (profiles/pmc_traffic.json, other run, same kernels)."""
+    if not ms_knn or ms_knn <= 0:
+        return None
+    macs = 2.0 * n_desc * n_desc * 256 * pairs
+    pf = macs * 2 / (ms_knn * 1e-3) / 1e15
+    out = {"bound": "mfma-fp4", "kernel": "k_expand + k_knn_mfma", "achieved_PFLOPs": pf, "achieved_PMACs": pf / 2, "peak": MFMA_FP4_PEAK_PFLOPS, "unit": "PFLOP/s",
+           "frac": pf / MFMA_FP4_PEAK_PFLOPS, "ms_knn": ms_knn, "descriptors_per_frame": n_desc, "pairs_per_step": pairs,
+           "distance_matrices_per_pair": 2, "macs_per_step": macs, "mfma_busy_frac": None, "l2_hit": None}
+    try:
+        raw = json.load(open(pmc_path or os.path.join(ROOT, "profiles", "pmc_traffic.json")))["raw"]["k_knn_mfma"]
+        hit, miss = raw["TCC_HIT_sum"]["mean"], raw["TCC_MISS_sum"]["mean"]
+        out["l2_hit"] = hit / (hit + miss)
+        # SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD; GRBM_GUI_ACTIVE is summed over the 8 XCDs: cycles x 1024 SIMDs
+        out["mfma_busy_frac"] = raw["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (raw["GRBM_GUI_ACTIVE"]["mean"] / 8 * 1024)
+        out["counters_from"] = "profiles/pmc_traffic.json raw.k_knn_mfma (TCC_HIT_sum, TCC_MISS_sum, SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE; 512 frames per launch)"
+    except Exception as e:
+        out["counters_error"] = repr(e)
+    return out
+
+
 def run_leg(dev, w, h, B, R, params, seed, canvas_dim, steps, warmup, stages=None, parallax=False, want_pose=True, d2h=False):
-    if stages is None:                                   # Camera::Update needs w, h multiples of 16 (752x480 and 3840x2160 are, 1920x1080 is not)
-        stages = vislam.STAGE_FRAME if (w % 16 == 0 and h % 16 == 0) else vislam.STAGE_ALL
+    if stages is None:                                   # every leg runs Camera::Update inside the step, like the headline (1080p included since round 4)
+        stages = vislam.STAGE_FRAME
     ctx = vislam.Context(dev.index or 0, params)
     try:
         st = Stream(ctx, dev, w, h, B * R, seed, canvas_dim, parallax)
@@ -401,6 +430,48 @@ def main():
                 what="S-752P: two depth layers (1.5x parallax) + independently moving objects; adaptive RANSAC, same parameters as the headline"))
         guarded("s752_results_d2h", lambda: dict(run_leg(dev, W, H, B, R, p, vdist.SINGLE_SEED, 4096, 20, 3, d2h=True, want_pose=False),
                 what="headline step + D2H of 1024 pose records (192 B), good matches (49 x 16 B) and counts into pinned memory every step, overlapped with the next step"))
+        def leg_mispredict():
+            """the cost of a WRONG threshold prediction (the headline stream is the most coherent input there is: 0 pairs redone).  Three
+            batches of different content alternate -- S-752, the same frames at quarter contrast, uniform noise -- so every step starts
+            from thresholds predicted on other content; whatever (frame, level) the prediction was too high for is redone inside the step."""
+            ctx = vislam.Context(dev.index or 0, p)
+            try:
+                Bm = 512
+                st = Stream(ctx, dev, W, H, Bm, vdist.SINGLE_SEED)
+                low = (st.frames // 4 + 96).contiguous()
+                g = torch.Generator(device=dev); g.manual_seed(7)
+                noise = torch.randint(0, 256, (Bm, H, W), dtype=torch.uint8, device=dev, generator=g)
+                bufs = [st.frames, low, noise]
+                ctx.batch_plan(W, H, W, Bm)
+                redone, taus = [], []
+                def stepm(i):
+                    ctx.batch_run(bufs[i % 3].data_ptr(), Bm, vislam.STAGE_FRAME)
+                for i in range(3):
+                    stepm(i)
+                ctx.batch_sync()
+                for i in range(3, 9):                       # counted separately from the timing: the read-back syncs
+                    stepm(i); ctx.batch_sync()
+                    t_, r_ = ctx.batch_fast_thresholds()
+                    redone.append(int(r_)); taus.append([int(x) for x in t_])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                K = 12
+                for i in range(9, 9 + K):
+                    stepm(i)
+                ctx.batch_sync(); torch.cuda.synchronize()
+                dtm = (time.perf_counter() - t0) / K
+                fam_m, _ = family_times(ctx, stepm, 6)
+                return {"what": "headline step on alternating incoherent batches (S-752 / quarter contrast / uniform noise, 512 frames each): the "
+                                "speculative FAST thresholds are predicted on OTHER content; mispredicted (frame, level) pairs are redone at "
+                                "fast_threshold by k_fast_fix / k_select_fix inside the step; consecutive batches are not consecutive frames, so the "
+                                "matcher / pose stages see unrelated pairs (their cost is what it is)",
+                        "frames_per_step": Bm, "ms_per_step": dtm * 1e3, "frames_per_s": Bm / dtm, "frame_level_pairs_per_step": Bm * LEVELS,
+                        "frame_level_pairs_redone_per_step": redone, "tau_next_per_level_after_each_step": taus,
+                        "kernels_ms_per_step": {k: round(v, 4) for k, v in fam_m.items()}}
+            finally:
+                ctx.close()
+                torch.cuda.empty_cache()
+        guarded("s752_mispredicted_thresholds", leg_mispredict)
         q3 = vislam.default_params()
         q3.nfeatures, q3.nlevels, q3.w_size, q3.h_size = 4000, 4, 1920, 1080
         q3.fy = q3.fx
@@ -418,8 +489,10 @@ def main():
             r["matcher"] = {"pairs_per_distance_matrix": n5 * n5, "valu_lane_ops_per_matrix": 16 * n5 * n5,
                             "distance_matrices_per_s": 32 / (kn * 1e-3) if kn > 0 else None,
                             "equivalent_popcount_lane_ops_per_s": 16.0 * n5 * n5 * 32 / (kn * 1e-3) if kn > 0 else None,
-                            "note": "one matrix serves both knn directions (the reference computes it twice); computed on the FP4 matrix cores (e2m1 +-1, exact), "
-                                    "the lane-op figure is the xor+popcount work it replaces (SURVEY 8(d))"}
+                            "note": "the kernel computes TWO 8000 x 8000 matrices per pair (query->train and the transposed one, each reduced row-wise to its "
+                                    "top-2), as the reference's two knnMatch calls do; the RATE reported here counts one matrix per pair, the unit SURVEY 8(d) "
+                                    "prices (16 N1 N2 xor+popcount lane-ops); computed on the FP4 matrix cores (e2m1 +-1, exact)"}
+            r["matcher_roofline"] = matcher_roofline(kn, n5, 31)
             r["what"] = "BASELINE configs[4]: 3840x2160, 8 levels, 8000 kps/frame, 8000x8000 BF-Hamming all-pairs, filters, pose; 32 frames per step"
             return r
         guarded("config5_s2160", leg5)
@@ -507,6 +580,7 @@ def main():
                                           "what": "thresholds the next batch's k_fast starts from (min over the last batch's frames of the "
                                                   "retainBest(2*quota) cut per level, minus 4); 0 pairs redone = every prediction of the last step held"},
             "detect_kernels": detect_kernels,
+            "matcher_roofline": matcher_roofline(fam["ms_knn"], NFEAT, B),
             "pose_load": headline_pose,
             "aux_kernels": aux,
             "legs": legs,

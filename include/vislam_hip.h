@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VIS_ABI_VERSION 3
+#define VIS_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -141,9 +141,17 @@ int  vis_level_geometry(vis_ctx* ctx, int w, int h, int32_t* widths, int32_t* he
                         float* scales, int32_t* quotas);
 
 /* ---- single-frame API: one call per OpenCV(-CUDA) call site --------------- */
+/* Sizes of Camera::Update's levels (src/Camera.cpp:68-70: resize(prev, next, Size(), 0.5, 0.5)): cv::resize takes
+ * dsize = cvRound(size * 0.5) -- round half to EVEN: 135 -> 68, 137 -> 68 -- so a level can be one row / column larger than the
+ * reference's own bookkeeping `w_size[0] >> lvl` (src/Camera.cpp:42-47; 1080 -> 540, 270, 135, 68 against 67).  Both exist
+ * here as they do there: buffers, strides and the gradients follow these sizes; the patch builders and the alignment bound
+ * their coordinates by `>> lvl` like the reference.  For sizes that halve exactly four times (752x480) they coincide. */
+void vis_half_pyramid_dims(int w, int h, int32_t lw[5], int32_t lh[5]);
 /* Camera::Update, src/Camera.cpp:63-72: copy + 4x half-resolution levels.
- * out_levels[l] (l=1..4) receives (w>>l)*(h>>l) bytes, tightly packed; out_levels[0] may be NULL.
- * w and h must be multiples of 16 (all four levels halve exactly, as 752x480 does). */
+ * out_levels[l] (l=1..4) receives lw[l]*lh[l] bytes (vis_half_pyramid_dims), tightly packed; out_levels[0] may be NULL.
+ * With scale exactly 2 cv::resize(INTER_LINEAR) runs its area-fast path: (a+b+c+d+2)>>2 over every complete 2x2 block; where a
+ * level is one larger than half of an odd source size, the last column / row averages the pixels that exist
+ * (saturate_cast<uchar>((float)sum / count), round half to even).  w, h >= 16. */
 int  vis_camera_update(vis_ctx* ctx, const uint8_t* img, int w, int h, int stride,
                        uint8_t* const out_levels[5]);
 /* replaces frameGPU.upload + cuda::ORB::detectAndCompute + descriptorsGPU.download,
@@ -189,12 +197,12 @@ int  vis_f2f_ransac(vis_ctx* ctx, const vis_keypoint* pts1, const vis_keypoint* 
 
 /* ---- the step after matching in CameraGPU::addGPUKeyframe (src/CameraGPU.cpp:154-157) ---- */
 /* Camera::Update's half pyramid (src/Camera.cpp:63-72) + Camera::computeGradient (src/Camera.cpp:167-184) for n
- * frames resident in HBM.  Per frame and per level l = 0..4 of (w>>l) x (h>>l) pixels: Scharr dx and dy as
+ * frames resident in HBM.  Per frame and per level l = 0..4 of lw[l] x lh[l] pixels (vis_half_pyramid_dims): Scharr dx and dy as
  * CV_16S with OpenCV's `scale` argument (the reference call Scharr(img, g, CV_16S, 1, 0, 3, 0, BORDER_DEFAULT)
  * passes scale = 3, delta = 0), and gradient = addWeighted(|dx| sat u8, 0.5, |dy| sat u8, 0.5, 0).
  * All outputs are caller-owned DEVICE buffers of n * vis_gradient_frame_elems(w, h) elements: inside a frame the
- * levels are dense and back to back (level l starts at sum_{k<l} (w>>k)(h>>k)); d_gray receives levels 1..4 of
- * the half pyramid (its level-0 part is left untouched: level 0 is the frame itself).  w, h multiples of 16,
+ * levels are dense and back to back (level l starts at sum_{k<l} lw[k] lh[k]); d_gray receives levels 1..4 of
+ * the half pyramid (its level-0 part is left untouched: level 0 is the frame itself).  w, h >= 16,
  * stride % 4 == 0, 1 <= scale <= 8 (int16 cannot overflow), buffers 16-byte aligned. */
 size_t vis_gradient_frame_elems(int w, int h);
 int  vis_gradient_batch(vis_ctx* ctx, const uint8_t* d_frames, int w, int h, int stride, int n, int scale,
@@ -252,7 +260,7 @@ int  vis_estimate_pose_features(vis_ctx* ctx, const vis_align_params* ap, int w,
  * frames (d_gray levels 1..4, d_gx, d_gy).  Pair i = (frame i-1 -> frame i), i = 1..n-1; d_out[0] is zeroed.  The
  * candidate points of pair i are generated on the fly from d_pts: max_pts (x, y) floats per pair = the matched
  * keypoints of frame i-1 (Frame::nextGoodMatches, at most 200 are used like the reference), d_npts[i] of them valid.
- * d_init: n poses or NULL.  Asynchronous on the context's stream.  w, h multiples of 16. */
+ * d_init: n poses or NULL.  Asynchronous on the context's stream.  w, h >= 16. */
 int  vis_align_batch(vis_ctx* ctx, const vis_align_params* ap, const uint8_t* d_frames, int w, int h, int stride, int n,
                      const uint8_t* d_gray, const int16_t* d_gx, const int16_t* d_gy,
                      const float* d_pts, const int32_t* d_npts, int max_pts,
@@ -298,7 +306,8 @@ int  vis_batch_plan(vis_ctx* ctx, int w, int h, int stride, int max_frames);
 int  vis_batch_reset(vis_ctx* ctx);
 enum { VIS_STAGE_DETECT = 1, VIS_STAGE_MATCH = 2, VIS_STAGE_POSE = 4, VIS_STAGE_ALL = 7,
        /* Camera::Update (src/Camera.cpp:63-72) for every frame of the batch: the 4 half-resolution levels into a plan-owned
-        * buffer (vis_batch_half_pyramid), at the head of the detect chain.  Needs w, h multiples of 16. */
+        * buffer (vis_batch_half_pyramid), on a side stream that starts behind the pyramid launches of the detect chain and is joined
+        * by the detect stream at the end of its chain. */
        VIS_STAGE_UPDATE = 8, VIS_STAGE_FRAME = 15,
        /* Camera::computeGradient (src/Camera.cpp:167-184; inside addGPUKeyframe, src/CameraGPU.cpp:154) for every frame of the
         * batch: Scharr dx / dy (CV_16S, scale 3) and the blended magnitude on the 5 half-pyramid levels, into plan-owned buffers

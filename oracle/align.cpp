@@ -22,7 +22,7 @@
  *     the HIP kernel can reproduce it bit for bit.
  * SPEC decisions where the reference is undefined (SURVEY.md section 0.10 style):
  *   - image2.at<uchar>(round(y2), round(x2)) can index one past the last row/column when y2 > rows - 0.5
- *     (the guard is y2 < rows, :1280): the rounded index is clamped to rows-1 / cols-1;
+ *     (the guard is y2 < rows, :1280): the rounded index is clamped to the last row / column of the Mat;
  *   - zero valid residuals (Residuals.rows == 0 -> 1/0 and an empty gemm, :1331-1333): the level stops;
  *   - the A^T A / A^T r reductions use a FIXED summation order so that a parallel implementation can match:
  *     ALIGN_LANES = 256 partial sums (row i goes to partial i % 256, rows in ascending order); inside each group of
@@ -281,7 +281,11 @@ extern "C" int orc_estimate_pose_features(const vis_align_params* ap, int w, int
     std::memset(out, 0, sizeof(*out));
     float initial_error = 0.f;
     for (int lvl = ap->first_level; lvl >= ap->last_level; lvl--) {                       // :1182
+        // `cols`, `rows` = the reference's bookkeeping w_[lvl], h_[lvl] = size >> lvl (src/VISystem.cpp InitializePyramid); the Mats it
+        // indexes have Camera::Update's sizes (orc_half_pyramid_dims: up to one row / column more when a size does not halve exactly)
         const int cols = w >> lvl, rows = h >> lvl, N = n_cand[lvl];
+        int32_t alw[5], alh[5]; orc_half_pyramid_dims(w, h, alw, alh);
+        const int acols = alw[lvl], arows = alh[lvl];
         if (N < 0 || (N && (!gray1[lvl] || !gray2[lvl] || !gx1[lvl] || !gy1[lvl] || !cand1[lvl]))) return VIS_E_INVALID;
         const uint8_t* I1 = gray1[lvl]; const uint8_t* I2 = gray2[lvl];
         const float fx = K[lvl].fx, fy = K[lvl].fy, cx = K[lvl].cx, cy = K[lvl].cy, invfx = K[lvl].invfx, invfy = K[lvl].invfy;
@@ -322,12 +326,12 @@ extern "C" int orc_estimate_pose_features(const vis_align_params* ap, int w, int
                 const int ix1 = (int)x1, iy1 = (int)y1;                                      // at<uchar>(y1, x1): float -> int
                 if (ix1 < 0 || ix1 >= cols || iy1 < 0 || iy1 >= rows) continue;              // SPEC: the builders never emit such points
                 int rx = (int)std::round(x2), ry = (int)std::round(y2);                      // :1305
-                if (rx > cols - 1) rx = cols - 1;                                            // SPEC clamp (see header)
-                if (ry > rows - 1) ry = rows - 1;
-                const int intensity1 = I1[(size_t)iy1 * cols + ix1];
-                const int intensity2 = I2[(size_t)ry * cols + rx];
+                if (rx > acols - 1) rx = acols - 1;                                          // SPEC clamp (see header): to the Mat's own size
+                if (ry > arows - 1) ry = arows - 1;
+                const int intensity1 = I1[(size_t)iy1 * acols + ix1];
+                const int intensity2 = I2[(size_t)ry * acols + rx];
                 const float res = (float)(intensity2 - intensity1);
-                const float jl0 = (float)gx1[lvl][(size_t)iy1 * cols + ix1], jl1 = (float)gy1[lvl][(size_t)iy1 * cols + ix1];
+                const float jl0 = (float)gx1[lvl][(size_t)iy1 * acols + ix1], jl1 = (float)gy1[lvl][(size_t)iy1 * acols + ix1];
                 for (int c = 0; c < 6; c++) J.push_back((float)((double)jl0 * (double)Jw[0][c] + (double)jl1 * (double)Jw[1][c]));   // Jl * Jw (gemm)
                 r.push_back(res);
                 sumsq += (double)res * (double)res;

@@ -440,23 +440,41 @@ extern "C" int orc_resize_linear(const uint8_t* src, int sw, int sh, int sstride
     return VIS_OK;
 }
 
-// Camera::Update, src/Camera.cpp:68-70: resize(prev, next, Size(), 0.5, 0.5) -> INTER_LINEAR with an
-// exact 2x decimation takes OpenCV's area-fast path: (a+b+c+d+2)>>2.  SPEC: w and h must be multiples
-// of 16 so that all four levels halve exactly (752x480 -> 47x30); OpenCV's odd-size edge handling
-// (cvRound'ed dsize + partial boxes) is outside the reference's use and not restated.
+// Camera::Update, src/Camera.cpp:68-70: resize(prev, next, Size(), 0.5, 0.5).  What cv::resize (OpenCV 3.2 imgproc/imgwarp.cpp)
+// does with these arguments, restated from the published source (PARITY UNPINNED like everything OpenCV-owned here):
+//   dsize = Size(saturate_cast<int>(ssize.width * 0.5), saturate_cast<int>(ssize.height * 0.5))   -- cvRound: round half to EVEN
+//   scale_x = scale_y = 1 / 0.5 = 2 exactly (inv_scale stays the fx / fy given, because dsize was empty), so is_area_fast holds and
+//   "INTER_LINEAR && is_area_fast && iscale == 2" is rerouted to INTER_AREA -> resizeAreaFast_Invoker:
+//     destination pixels whose 2x2 source block is complete:  (a + b + c + d + 2) >> 2
+//     the others (last column when dsize.width * 2 > ssize.width, last row likewise):
+//         saturate_cast<uchar>((float)sum / count) over the source pixels of the block that exist  (round half to even)
+// For sizes that halve exactly (752x480 -> 47x30) only the first form occurs.  A size like 137 halves to 68 (68.5 -> even):
+// the last source column is then simply unused.
+static inline int half_dim(int n) { return (n >> 1) + ((n & 1) & ((n >> 1) & 1)); }
+extern "C" void orc_half_pyramid_dims(int w, int h, int32_t lw[5], int32_t lh[5]) {
+    lw[0] = w; lh[0] = h;
+    for (int l = 1; l < 5; l++) { lw[l] = half_dim(lw[l - 1]); lh[l] = half_dim(lh[l - 1]); }
+}
 extern "C" int orc_half_pyramid(const uint8_t* img, int w, int h, int stride, uint8_t* const out_levels[5]) {
-    if (!img || !out_levels || w < 16 || h < 16 || (w & 15) || (h & 15)) return VIS_E_INVALID;
+    if (!img || !out_levels || w < 16 || h < 16) return VIS_E_INVALID;
     std::vector<uint8_t> prev((size_t)w * h);
     for (int y = 0; y < h; y++) std::memcpy(&prev[(size_t)y * w], img + (size_t)y * stride, w);
     if (out_levels[0]) std::memcpy(out_levels[0], prev.data(), prev.size());
     int pw = w, ph = h;
     for (int l = 1; l < 5; l++) {
-        const int nw = pw / 2, nh = ph / 2;
+        const int nw = half_dim(pw), nh = half_dim(ph);
         std::vector<uint8_t> cur((size_t)nw * nh);
         for (int y = 0; y < nh; y++)
             for (int x = 0; x < nw; x++) {
-                const uint8_t* s = &prev[(size_t)(2 * y) * pw + 2 * x];
-                cur[(size_t)y * nw + x] = (uint8_t)((s[0] + s[1] + s[pw] + s[pw + 1] + 2) >> 2);
+                if (2 * x + 1 < pw && 2 * y + 1 < ph) {
+                    const uint8_t* s = &prev[(size_t)(2 * y) * pw + 2 * x];
+                    cur[(size_t)y * nw + x] = (uint8_t)((s[0] + s[1] + s[pw] + s[pw + 1] + 2) >> 2);
+                } else {
+                    int sum = 0, count = 0;
+                    for (int sy = 2 * y; sy < 2 * y + 2 && sy < ph; sy++)
+                        for (int sx = 2 * x; sx < 2 * x + 2 && sx < pw; sx++) { sum += prev[(size_t)sy * pw + sx]; count++; }
+                    cur[(size_t)y * nw + x] = (uint8_t)std::lrintf((float)sum / (float)count);      // count is 1 or 2: exact, <= 255
+                }
             }
         if (out_levels[l]) std::memcpy(out_levels[l], cur.data(), cur.size());
         prev.swap(cur); pw = nw; ph = nh;

@@ -35,7 +35,8 @@ int orc_level_geometry(const vis_params* p, int w, int h, int32_t* widths, int32
 /* cv::resize(..., INTER_LINEAR) 8-bit fixed-point path (Appendix A.1 item 2) */
 int orc_resize_linear(const uint8_t* src, int sw, int sh, int sstride,
                       uint8_t* dst, int dw, int dh, int dstride);
-/* Camera::Update half pyramid, src/Camera.cpp:68-70 (resize 0.5,0.5 == 2x2 box mean) */
+/* Camera::Update half pyramid, src/Camera.cpp:68-70 (resize 0.5,0.5 == 2x2 box mean); level sizes = cvRound(size * 0.5) */
+void orc_half_pyramid_dims(int w, int h, int32_t lw[5], int32_t lh[5]);
 int orc_half_pyramid(const uint8_t* img, int w, int h, int stride, uint8_t* const out_levels[5]);
 /* cv::FAST(img, thr, nonmax=true): keypoints in row-major order; also the raw score map
  * (0 for non-corners) when score_map != NULL (w*h bytes). returns count or <0 */

@@ -24,6 +24,8 @@ class FrameResult(C.Structure):
 lib.orc_level_geometry.argtypes = [C.POINTER(Params), ci, ci, vp, vp, vp, vp]
 lib.orc_resize_linear.argtypes = [vp, ci, ci, ci, vp, ci, ci, ci]
 lib.orc_half_pyramid.argtypes = [vp, ci, ci, ci, C.POINTER(vp)]
+lib.orc_half_pyramid_dims.argtypes = [ci, ci, vp, vp]
+lib.orc_half_pyramid_dims.restype = None
 lib.orc_fast_detect.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
 lib.orc_gaussian_blur7.argtypes = [vp, ci, ci, ci, vp, ci]
 lib.orc_orb_detect_compute.argtypes = [C.POINTER(Params), vp, ci, ci, ci, vp, vp, ci, ip]
@@ -60,10 +62,17 @@ def resize_linear(src, dw, dh):
     return dst
 
 
+def half_pyramid_dims(w, h):
+    lw = np.zeros(5, np.int32); lh = np.zeros(5, np.int32)
+    lib.orc_half_pyramid_dims(w, h, _p(lw), _p(lh))
+    return [int(x) for x in lw], [int(x) for x in lh]
+
+
 def half_pyramid(img):
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape
-    levels = [np.empty((h >> l, w >> l), np.uint8) for l in range(5)]
+    lw, lh = half_pyramid_dims(w, h)
+    levels = [np.empty((lh[l], lw[l]), np.uint8) for l in range(5)]
     arr = (vp * 5)(*[l.ctypes.data for l in levels])
     rc = lib.orc_half_pyramid(_p(img), w, h, img.strides[0], arr)
     assert rc == 0, rc

@@ -102,3 +102,11 @@ def test_synth_stream_is_bit_reproducible(vislam):
     g = np.load(os.path.join(ROOT, "tests", "golden", "synth_512_123.npz"))
     assert hashlib.sha256(cv.tobytes()).hexdigest() == str(g["canvas_sha256"])
     assert (f == g["frame5"]).all()
+
+
+def test_the_product_library_needs_no_profiler_component(vislam):
+    """roctx ranges are an opt-in diagnostic build (`make ROCTX=1`): the default library must load on a box without the profiler SDK"""
+    import subprocess
+    lib = os.path.join(ROOT, "vi-slam_amd", "lib", "libvislam_hip.so")
+    needed = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True, check=True).stdout
+    assert "roctx" not in needed and "rocprofiler" not in needed, needed

@@ -33,6 +33,23 @@ def test_single_pair_bit_exact(vislam, orc, ctx, canvas, dx, dy, div, n):
     _same(got, ref)
 
 
+@pytest.mark.parametrize("w,h", [(1080, 540), (600, 270), (270, 150)])
+def test_single_pair_on_sizes_that_do_not_halve_exactly(vislam, orc, ctx, canvas, w, h):
+    """levels one row / column larger than the reference's `size >> lvl` bookkeeping (270 -> 135 -> 68 against 67): coordinates are
+    bounded by the bookkeeping sizes, strides and the clamp of the rounded index follow the level's own size (oracle/align.cpp)"""
+    c = align_cases.case(vislam, orc, canvas, w=w, h=h, dx=3, dy=2, n=49, grad_div=8)
+    lw, lh = vislam.half_pyramid_dims(w, h)
+    assert [g.shape for g in c["gray1"]] == [(lh[l], lw[l]) for l in range(5)]
+    assert any(lh[l] != (h >> l) or lw[l] != (w >> l) for l in range(5))
+    ap = vislam.default_align_params(); oap = orc.default_align_params()
+    for q in (ap, oap):
+        q.fx, q.fy, q.cx, q.cy = 300.0, 300.0, w / 2.0, h / 2.0
+    got = ctx.estimate_pose_features(ap, w, h, c["gray1"], c["gray2"], c["gx"], c["gy"], c["cand"])
+    ref = orc.estimate_pose_features(oap, w, h, c["gray1"], c["gray2"], c["gx"], c["gy"], c["cand"])
+    _same(got, ref)
+    assert sum(ref.n_residuals) > 0
+
+
 def test_options_levels_and_initial_pose(vislam, orc, ctx, canvas):
     c = align_cases.case(vislam, orc, canvas, dx=4, dy=3, n=40, grad_div=8)
     for first, last, iters, init6 in [(3, 0, 10, None), (2, 1, 4, [0.002, -0.001, 0, 0, 0, 0.001]), (4, 4, 3, [0, 0, 0, 1e-4, 2e-4, 0]),

@@ -81,6 +81,56 @@ def test_camera_update_half_pyramid(vislam, orc, ctx, canvas):
         assert (got[l] == ref[l]).all(), l
 
 
+@pytest.mark.parametrize("w,h", [(1920, 1080), (137, 135), (150, 110), (61, 47), (19, 18)])
+def test_camera_update_sizes_that_do_not_halve_exactly(vislam, orc, ctx, w, h):
+    """cv::resize(Size(), 0.5, 0.5): level sizes cvRound(size * 0.5); partial 2x2 blocks average the pixels that exist (Camera.cpp:68-70)"""
+    img = np.random.default_rng(w * 7 + h).integers(0, 256, (h, w), dtype=np.uint8)
+    got, ref = ctx.camera_update(img), orc.half_pyramid(img)
+    assert vislam.half_pyramid_dims(w, h) == orc.half_pyramid_dims(w, h)
+    for l in range(5):
+        assert got[l].shape == ref[l].shape and (got[l] == ref[l]).all(), l
+
+
+def test_batch_update_and_gradient_stage_at_1080p(vislam, orc):
+    """VIS_STAGE_UPDATE / VIS_STAGE_GRADIENT on 1920x1080 frames (BASELINE configs[2]): 1080 -> 540 -> 270 -> 135 -> 68 rows"""
+    import torch
+    W, H, n = 1920, 1080, 3
+    p = vislam.default_params()
+    p.nfeatures, p.nlevels, p.w_size, p.h_size = 4000, 4, W, H
+    c = vislam.Context(0, p)
+    cv = vislam.synth_canvas(4096, 0xE0C00003)
+    frames = np.stack([vislam.synth_frame(cv, t, W, H, 0xE0C00003) for t in range(n)])
+    dev = torch.from_numpy(frames).cuda()
+    c.batch_plan(W, H, W, n)
+    c.batch_run(dev.data_ptr(), n, vislam.STAGE_DETECT | vislam.STAGE_GRADIENT)
+    c.batch_sync()
+    assert c.batch_status() == 0
+    lw, lh = vislam.half_pyramid_dims(W, H)
+    assert lh == [1080, 540, 270, 135, 68]
+    fe = vislam.gradient_frame_elems(W, H)
+    pg, px, py, pgg, pfe = c.batch_gradients()
+    assert pfe == fe
+
+    def view(ptr, typestr):
+        class _Dev:
+            __cuda_array_interface__ = {"data": (ptr, False), "shape": (n * fe,), "typestr": typestr, "version": 2}
+        return torch.as_tensor(_Dev(), device="cuda").cpu().numpy().reshape(n, fe)
+    half, gx, gy, g = view(pg, "|u1"), view(px, "<i2"), view(py, "<i2"), view(pgg, "|u1")
+    for t in range(n):
+        ref = orc.half_pyramid(frames[t])
+        off = 0
+        for l in range(5):
+            cnt = lw[l] * lh[l]
+            ox, oy, og = orc.scharr_gradient(ref[l], 3)
+            if l > 0:
+                assert np.array_equal(half[t, off:off + cnt].reshape(lh[l], lw[l]), ref[l]), (t, l)
+            assert np.array_equal(gx[t, off:off + cnt].reshape(lh[l], lw[l]), ox), (t, l)
+            assert np.array_equal(gy[t, off:off + cnt].reshape(lh[l], lw[l]), oy), (t, l)
+            assert np.array_equal(g[t, off:off + cnt].reshape(lh[l], lw[l]), og), (t, l)
+            off += cnt
+    c.close()
+
+
 def test_batch_update_stage_writes_the_half_pyramids(vislam, orc, canvas):
     """VIS_STAGE_UPDATE (Camera::Update inside the batched step): every frame's 4 half levels == the oracle's, and the detect
     results of the same call are unchanged by it"""

@@ -180,4 +180,4 @@ def test_invalid_arguments_are_rejected(vislam, ctx):
     with pytest.raises(vislam.VisError):
         ctx.orb_detect_compute(np.zeros((40, 40), np.uint8))        # smaller than twice the border
     with pytest.raises(vislam.VisError):
-        ctx.camera_update(np.zeros((100, 100), np.uint8))            # not a multiple of 16
+        ctx.camera_update(np.zeros((12, 100), np.uint8))             # smaller than 16 rows

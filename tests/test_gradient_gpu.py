@@ -22,7 +22,8 @@ def test_gradient_s752(vislam, orc, ctx, canvas):
     _check_levels(vislam, orc, ctx, vislam.synth_frame(canvas, 5, 752, 480))
 
 
-@pytest.mark.parametrize("w,h", [(64, 48), (96, 32), (160, 112), (1920, 1088), (3840, 2160)])
+@pytest.mark.parametrize("w,h", [(64, 48), (96, 32), (160, 112), (1920, 1088), (3840, 2160),
+                                 (1920, 1080), (137, 135), (150, 110), (333, 61)])       # sizes that do not halve exactly: 1080 -> .. 135 -> 68 rows
 def test_gradient_sizes(vislam, orc, ctx, canvas, w, h):
     # 64x48: level 4 is 4x3 (narrower than one thread's 8 pixels); 1920x1088: levels of every alignment class
     if w > 2048:        # the 4K configuration: textured random image (the 4096^2 fixture canvas is too small to crop it at t = 3)
@@ -57,7 +58,7 @@ def test_gradient_invalid_arguments(vislam, ctx):
     with pytest.raises(vislam.VisError):
         ctx.compute_gradient(img, scale=9)           # would overflow int16
     with pytest.raises(vislam.VisError):
-        ctx.compute_gradient(np.zeros((50, 64), np.uint8))   # h not a multiple of 16
+        ctx.compute_gradient(np.zeros((12, 64), np.uint8))   # fewer than 16 rows
 
 
 def test_gradient_batch_device_path(vislam, orc, ctx, canvas):

@@ -769,3 +769,26 @@ def test_ransac_loop_rederived(vislam, orc):
         assert (oninl, oiters) == (best_good, it), (trial, oninl, oiters, best_good, it)
         assert np.array_equal(omask, best_mask)
         assert np.abs(oE - bestE).max() == 0
+
+
+def test_half_pyramid_against_a_numpy_restatement_at_odd_sizes(orc):
+    """resizeAreaFast with scale 2 on sizes that do not halve exactly (1080p: 135 -> 68 rows), written out in numpy: complete blocks
+    (sum + 2) >> 2, partial blocks np.rint(sum / count) (numpy's rint is round-half-even like cvRound)"""
+    rng = np.random.default_rng(77)
+    def half_dim(n):
+        k = n >> 1
+        return k if n % 2 == 0 else (k if k % 2 == 0 else k + 1)
+    for h, w in ((135, 137), (1080 // 8, 1920 // 8), (33, 35), (61, 47), (270, 150)):
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        got = orc.half_pyramid(img)
+        prev = img.astype(np.int64)
+        for l in range(1, 5):
+            ph, pw = prev.shape
+            nh, nw = half_dim(ph), half_dim(pw)
+            pad = np.zeros((2 * nh, 2 * nw), np.int64); cnt = np.zeros((2 * nh, 2 * nw), np.int64)
+            pad[:min(ph, 2 * nh), :min(pw, 2 * nw)] = prev[:2 * nh, :2 * nw]; cnt[:min(ph, 2 * nh), :min(pw, 2 * nw)] = 1
+            ssum = pad.reshape(nh, 2, nw, 2).sum((1, 3)); c = cnt.reshape(nh, 2, nw, 2).sum((1, 3))
+            cur = np.where(c == 4, (ssum + 2) >> 2, np.rint(ssum / np.maximum(c, 1)).astype(np.int64))
+            assert got[l].shape == (nh, nw), (h, w, l)
+            assert np.array_equal(got[l], cur.astype(np.uint8)), (h, w, l)
+            prev = cur

@@ -326,3 +326,28 @@ def test_pipeline_stream_mt_equals_sequential(vislam, orc):
         sec, res = orc.pipeline_stream_mt(p, fr, th)
         assert sec > 0
         assert [(r.n_kp, r.n_sym, r.n_good, r.n_inliers, r.n_pose_good, r.iters_run, tuple(r.E)) for r in res] == ref
+
+
+def test_half_pyramid_sizes_follow_cv_resize(orc):
+    """Camera::Update, src/Camera.cpp:68-70: resize(prev, next, Size(), 0.5, 0.5) -> dsize = cvRound(size * 0.5), round half to even"""
+    lw, lh = orc.half_pyramid_dims(1920, 1080)
+    assert lw == [1920, 960, 480, 240, 120] and lh == [1080, 540, 270, 135, 68]      # 135 * 0.5 = 67.5 -> 68 (the reference's h_size >> 4 says 67)
+    assert orc.half_pyramid_dims(137, 133)[0][:2] == [137, 68] and orc.half_pyramid_dims(137, 133)[1][:2] == [133, 66]   # 68.5 -> 68, 66.5 -> 66
+    assert orc.half_pyramid_dims(752, 480) == ([752, 376, 188, 94, 47], [480, 240, 120, 60, 30])
+
+
+def test_half_pyramid_partial_blocks(orc):
+    """area-fast resize: complete 2x2 blocks -> (a+b+c+d+2)>>2; the last column / row of a level that is one larger than half of an odd
+    size averages the pixels that exist with saturate_cast<uchar>((float)sum / count) = round half to EVEN (hand-made example)"""
+    img = np.zeros((18, 19), np.uint8)              # 19 -> 10 (9.5 -> 10): last column from source column 18 alone; 18 -> 9 rows, all complete
+    img[:, 18] = np.arange(18) * 3
+    img[0, 0:2] = (1, 2); img[1, 0:2] = (2, 2)      # (1+2+2+2+2)>>2 = 2  (7/4 = 1.75 rounds up; 9 >> 2 = 2)
+    lv = orc.half_pyramid(img)
+    assert lv[1].shape == (9, 10) and lv[1][0, 0] == 2
+    # last column: rows 2y, 2y+1 of source column 18: (3*2y + 3*(2y+1)) / 2 = 6y + 1.5 -> round half to even: 6y + 2
+    assert [int(v) for v in lv[1][:, 9]] == [6 * y + 2 for y in range(9)]
+    # a level with an odd number of ROWS whose half rounds up: 22 rows -> 11 -> 6 (5.5 -> 6): last row of level 2 from one source row
+    img2 = np.tile(np.arange(22, dtype=np.uint8)[:, None] * 10, (1, 32))
+    lv2 = orc.half_pyramid(img2)
+    assert lv2[1].shape == (11, 16) and lv2[2].shape == (6, 8)
+    assert (lv2[2][5] == lv2[1][10, 0]).all()       # the mean of two equal pixels

@@ -33,7 +33,8 @@ struct AlignLevel {
     const int16_t* gx; const int16_t* gy;
     const float* cand;                             // explicit list (x, y, z, w) rows, or nullptr (generated)
     size_t img_fstride, grad_fstride;              // elements between consecutive frames
-    int rowstride, cols, rows, ncand;
+    int rowstride, cols, rows, ncand;              // cols, rows: the reference's bookkeeping w_[lvl], h_[lvl] = size >> lvl (bounds of the coordinates)
+    int acols, arows;                              // the level's own size (Camera::Update: cvRound(size * 0.5)): stride of the dense gradients, clamp of the rounded index
     float fx, fy, cx, cy, invfx, invfy;
 };
 struct AlignArgs {
@@ -331,9 +332,9 @@ __global__ __launch_bounds__(AL_THREADS) void k_align(AlignArgs G) {
                         v = v && !(ix1 < 0 || ix1 >= cols || iy1 < 0 || iy1 >= rows);
                         if (v) {
                             int rx = (int)roundf(x2), ry = (int)roundf(y2);
-                            if (rx > cols - 1) rx = cols - 1;
-                            if (ry > rows - 1) ry = rows - 1;
-                            o1 = (size_t)iy1 * V.rowstride + ix1; o2 = (size_t)ry * V.rowstride + rx; go = (size_t)iy1 * cols + ix1;   // gradients are dense
+                            if (rx > V.acols - 1) rx = V.acols - 1;
+                            if (ry > V.arows - 1) ry = V.arows - 1;
+                            o1 = (size_t)iy1 * V.rowstride + ix1; o2 = (size_t)ry * V.rowstride + rx; go = (size_t)iy1 * V.acols + ix1;   // gradients are dense
                         }
                         ok[u] = v; x2a[u] = x2; y2a[u] = y2; iza[u] = inv_z2;
                     }
@@ -492,11 +493,12 @@ extern "C" int vis_estimate_pose_features(vis_ctx* ctx, const vis_align_params* 
     if (rc) return rc;
     (void)hipSetDevice(ctx->device);
     size_t need = 4096;
+    int alw[5], alh[5]; vis_half_dims(w, h, alw, alh);
     for (int l = ap->last_level; l <= ap->first_level; l++) {
         const int N = n_cand[l];
         if (N < 0 || N > (1 << 24)) return VIS_E_INVALID;
         if (N && (!gray1[l] || !gray2[l] || !gx1[l] || !gy1[l] || !cand1[l])) return VIS_E_INVALID;
-        const size_t px = (size_t)(w >> l) * (h >> l);
+        const size_t px = (size_t)alw[l] * alh[l];
         need += 6 * px + (size_t)N * 16 + 6 * 256;
     }
     rc = vis_ensure_scratch(ctx, need + sizeof(vis_se3f) + sizeof(vis_align_result) + 1024);
@@ -508,9 +510,9 @@ extern "C" int vis_estimate_pose_features(vis_ctx* ctx, const vis_align_params* 
     for (int l = ap->last_level; l <= ap->first_level; l++) {
         const int N = n_cand[l];
         const int cols = w >> l, rows = h >> l;
-        const size_t px = (size_t)cols * rows;
+        const size_t px = (size_t)alw[l] * alh[l];
         AlignLevel& V = G.lv[l];
-        V.cols = cols; V.rows = rows; V.rowstride = cols; V.ncand = N; V.img_fstride = 0; V.grad_fstride = 0;
+        V.cols = cols; V.rows = rows; V.acols = alw[l]; V.arows = alh[l]; V.rowstride = alw[l]; V.ncand = N; V.img_fstride = 0; V.grad_fstride = 0;
         if (!N) continue;
         uint8_t* d1 = cv.take<uint8_t>(px); uint8_t* d2 = cv.take<uint8_t>(px);
         int16_t* dgx = cv.take<int16_t>(px); int16_t* dgy = cv.take<int16_t>(px);
@@ -540,7 +542,7 @@ extern "C" int vis_align_batch(vis_ctx* ctx, const vis_align_params* ap, const u
     if (!ctx || !d_frames || !d_gray || !d_gx || !d_gy || !d_pts || !d_npts || !d_out) return VIS_E_INVALID;
     int rc = check_align_params(ap, w, h);
     if (rc) return rc;
-    if ((w & 15) || (h & 15) || stride < w || n < 1 || max_pts < 1) { ctx->err = "vis_align_batch: w, h multiples of 16 (the half pyramid of vis_gradient_batch), stride >= w, n >= 1, max_pts >= 1"; return VIS_E_INVALID; }
+    if (stride < w || n < 1 || max_pts < 1) { ctx->err = "vis_align_batch: stride >= w, n >= 1, max_pts >= 1"; return VIS_E_INVALID; }
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemsetAsync(d_out, 0, sizeof(vis_align_result), st));            // frame 0 has no predecessor in this batch
@@ -548,14 +550,15 @@ extern "C" int vis_align_batch(vis_ctx* ctx, const vis_align_params* ap, const u
     AlignArgs G; std::memset(&G, 0, sizeof(G));
     fill_level_intrinsics(*ap, G);
     const size_t fe = vis_grad_frame_elems(w, h);
+    int alw[5], alh[5]; vis_half_dims(w, h, alw, alh);
     size_t off = 0;
     for (int l = 0; l < 5; l++) {
         AlignLevel& V = G.lv[l];
-        V.cols = w >> l; V.rows = h >> l; V.ncand = 0; V.cand = nullptr;
+        V.cols = w >> l; V.rows = h >> l; V.acols = alw[l]; V.arows = alh[l]; V.ncand = 0; V.cand = nullptr;
         if (l == 0) { V.i1 = d_frames; V.i2 = d_frames; V.rowstride = stride; V.img_fstride = (size_t)stride * h; }
-        else { V.i1 = d_gray + off; V.i2 = d_gray + off; V.rowstride = V.cols; V.img_fstride = fe; }
+        else { V.i1 = d_gray + off; V.i2 = d_gray + off; V.rowstride = V.acols; V.img_fstride = fe; }
         V.gx = d_gx + off; V.gy = d_gy + off; V.grad_fstride = fe;
-        off += (size_t)V.cols * V.rows;
+        off += (size_t)V.acols * V.arows;
     }
     G.pts = d_pts; G.npts = d_npts; G.max_pts = max_pts; G.init = d_init; G.out = d_out;
     G.f1_off = 0; G.f2_off = 1; G.out_off = 1;                                       // workgroup q = pair (frame q -> frame q+1), result slot q+1

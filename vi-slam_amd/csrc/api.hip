@@ -128,6 +128,7 @@ extern "C" void vis_destroy(vis_ctx* ctx) {
 
 static void sync_all(vis_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->update_stream) (void)hipStreamSynchronize(ctx->update_stream);      // (joined by the detect stream in vis_batch_run -- unless that call failed half way, or the caller swapped ctx->stream since)
     if (ctx->match_stream) (void)hipStreamSynchronize(ctx->match_stream);
     if (ctx->pose_stream) (void)hipStreamSynchronize(ctx->pose_stream);
     ctx->pose_pending = false; ctx->results_pending = false; ctx->align_pending = false;
@@ -407,11 +408,11 @@ static int check_flags(vis_ctx* ctx, Plan* pl) {
 // ------------------------------------------------------------------------------------------------ single-frame API
 extern "C" int vis_camera_update(vis_ctx* ctx, const uint8_t* img, int w, int h, int stride, uint8_t* const out_levels[5]) {
     if (!ctx || !img || !out_levels || w < 16 || h < 16 || stride < w) return VIS_E_INVALID;
-    if ((w & 15) || (h & 15)) { ctx->err = "Camera::Update: width and height must be multiples of 16 (four exact halvings; the reference's w_size >> lvl bookkeeping assumes the same)"; return VIS_E_INVALID; }
     (void)hipSetDevice(ctx->device);
+    int lw[5], lh[5]; vis_half_dims(w, h, lw, lh);
     size_t lvl_bytes[5]; size_t total = (size_t)w * h;
     lvl_bytes[0] = (size_t)w * h;
-    for (int l = 1; l < 5; l++) { lvl_bytes[l] = (size_t)(w >> l) * (h >> l); total += lvl_bytes[l] + 256; }
+    for (int l = 1; l < 5; l++) { lvl_bytes[l] = (size_t)lw[l] * lh[l]; total += lvl_bytes[l] + 256; }
     int rc = ensure_scratch(ctx, total + 1024);
     if (rc) return rc;
     Carver cv{(char*)ctx->d_scratch, 0};
@@ -427,12 +428,13 @@ extern "C" int vis_camera_update(vis_ctx* ctx, const uint8_t* img, int w, int h,
 }
 
 extern "C" size_t vis_gradient_frame_elems(int w, int h) { return (w < 16 || h < 16) ? 0 : vis_grad_frame_elems(w, h); }
+extern "C" void vis_half_pyramid_dims(int w, int h, int32_t lw[5], int32_t lh[5]) { if (lw && lh) vis_half_dims(w, h, lw, lh); }
 
 extern "C" int vis_gradient_batch(vis_ctx* ctx, const uint8_t* d_frames, int w, int h, int stride, int n, int scale,
                                   uint8_t* d_gray, int16_t* d_gx, int16_t* d_gy, uint8_t* d_g) {
     if (!ctx || !d_frames || !d_gray || !d_gx || !d_gy || !d_g) return VIS_E_INVALID;
-    if (w < 16 || h < 16 || (w & 15) || (h & 15) || stride < w || (stride & 3) || n < 1 || scale < 1 || scale > 8) {
-        ctx->err = "vis_gradient_batch: w, h multiples of 16, stride >= w and % 4 == 0, n >= 1, 1 <= scale <= 8"; return VIS_E_INVALID;
+    if (w < 16 || h < 16 || stride < w || (stride & 3) || n < 1 || scale < 1 || scale > 8) {
+        ctx->err = "vis_gradient_batch: w, h >= 16, stride >= w and % 4 == 0, n >= 1, 1 <= scale <= 8"; return VIS_E_INVALID;
     }
     if (((uintptr_t)d_gx | (uintptr_t)d_gy | (uintptr_t)d_g | (uintptr_t)d_gray) & 15) { ctx->err = "vis_gradient_batch: output buffers must be 16-byte aligned"; return VIS_E_INVALID; }
     (void)hipSetDevice(ctx->device);
@@ -446,22 +448,24 @@ extern "C" int vis_gradient_batch(vis_ctx* ctx, const uint8_t* d_frames, int w, 
 
 extern "C" int vis_compute_gradient(vis_ctx* ctx, const uint8_t* img, int w, int h, int stride, int scale,
                                     int16_t* const gx[5], int16_t* const gy[5], uint8_t* const g[5]) {
-    if (!ctx || !img || !gx || !gy || !g || w < 16 || h < 16 || (w & 15) || (h & 15) || stride < w || scale < 1 || scale > 8) return VIS_E_INVALID;
+    if (!ctx || !img || !gx || !gy || !g || w < 16 || h < 16 || stride < w || scale < 1 || scale > 8) return VIS_E_INVALID;
     (void)hipSetDevice(ctx->device);
     const size_t fe = vis_grad_frame_elems(w, h);
-    int rc = ensure_scratch(ctx, (size_t)w * h + fe * 6 + 4096);
+    const int ws = (w + 15) & ~15;                              // device row stride of the copy (the batched entry wants % 4 == 0)
+    int rc = ensure_scratch(ctx, (size_t)ws * h + fe * 6 + 4096);
     if (rc) return rc;
     Carver cv{(char*)ctx->d_scratch, 0};
-    uint8_t* d_img = cv.take<uint8_t>((size_t)w * h);
+    uint8_t* d_img = cv.take<uint8_t>((size_t)ws * h);
     uint8_t* d_gray = cv.take<uint8_t>(fe);
     int16_t* d_gx = cv.take<int16_t>(fe); int16_t* d_gy = cv.take<int16_t>(fe);
     uint8_t* d_g = cv.take<uint8_t>(fe);
-    HIPCHK(ctx, hipMemcpy2DAsync(d_img, w, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
-    rc = vis_gradient_batch(ctx, d_img, w, h, w, 1, scale, d_gray, d_gx, d_gy, d_g);
+    HIPCHK(ctx, hipMemcpy2DAsync(d_img, ws, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+    rc = vis_gradient_batch(ctx, d_img, w, h, ws, 1, scale, d_gray, d_gx, d_gy, d_g);
     if (rc) return rc;
+    int lw[5], lh[5]; vis_half_dims(w, h, lw, lh);
     size_t off = 0;
     for (int l = 0; l < 5; l++) {
-        const size_t cnt = (size_t)(w >> l) * (h >> l);
+        const size_t cnt = (size_t)lw[l] * lh[l];
         if (gx[l]) HIPCHK(ctx, hipMemcpyAsync(gx[l], d_gx + off, cnt * 2, hipMemcpyDeviceToHost, ctx->stream));
         if (gy[l]) HIPCHK(ctx, hipMemcpyAsync(gy[l], d_gy + off, cnt * 2, hipMemcpyDeviceToHost, ctx->stream));
         if (g[l]) HIPCHK(ctx, hipMemcpyAsync(g[l], d_g + off, cnt, hipMemcpyDeviceToHost, ctx->stream));
@@ -831,7 +835,6 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
     hipStream_t sA = ctx->stream, sM = ctx->match_stream, sP = ctx->pose_stream;
     ctx->tm.launches_total = 0;
     const bool detect = (stages & VIS_STAGE_DETECT) != 0;
-    if ((stages & (VIS_STAGE_UPDATE | VIS_STAGE_GRADIENT)) && ((pl->w & 15) || (pl->h & 15))) { ctx->err = "VIS_STAGE_UPDATE: w, h must be multiples of 16"; return VIS_E_INVALID; }
     const int cur = detect ? (pl->run_count & 1) : (pl->last_base / pl->rec_per_set);   // run_count is committed only when every launch succeeded
     const int base = cur * pl->rec_per_set;
     int rc = VIS_OK;
@@ -873,7 +876,12 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
             ctx->stream = sA;
             if (!rc) pl->grad_valid = true;
         }
-        if (rc) return rc;
+        if (rc) {
+            // whatever was queued on the side stream before the failure still reads d_frames / writes the plan's buffers: the detect
+            // stream joins it before this call returns, so "ctx->stream is done" keeps meaning "the batch's buffers are free"
+            if (hipEventRecord(ctx->ev_update_done, sU) == hipSuccess) (void)hipStreamWaitEvent(sA, ctx->ev_update_done, 0);
+            return rc;
+        }
         if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[11], sU);
         HIPCHK(ctx, hipEventRecord(ctx->ev_update_done, sU));
         update_queued = true;
@@ -926,6 +934,7 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
 extern "C" int vis_batch_sync(vis_ctx* ctx) {
     if (!ctx) return VIS_E_INVALID;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->update_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->update_stream));
     if (ctx->match_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->match_stream));
     const bool had_pose = ctx->pose_pending;
     if (ctx->pose_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->pose_stream));

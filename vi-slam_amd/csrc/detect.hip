@@ -435,7 +435,7 @@ __device__ __forceinline__ void fast_tile(const FastTile& V, const uint8_t* __re
         //     B  = D + (2K-3):  bit 7 CLEAR <=> r7 - c7 >= K-1 + (0 or 1)                                         ("bright")
         // A byte whose subtraction wraps (|difference| > 118) borrows 1 from / carries 1 into its left neighbour: the tests
         // use K-1 resp. 2K-3 instead of K and 2K-2, which absorbs exactly that unit, and the wrapped byte itself reads
-        // "pass".  tests/test_fast_pretest_model.py replays these formulas in numpy exhaustively over (c, r, t).
+        // "pass".  tests/test_independent_numpy.py replays these formulas in numpy exhaustively over (c, r, t).
         // The axis test itself is unchanged: both opposite pairs (N,S) and (E,W) must show a dark pixel, or both a bright one.
         const int q = tid & (FT_W / 4 - 1);
         const int gx0 = ox + 4 * q;                                      // image x of position sx = 4q+1
@@ -1119,13 +1119,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96), amdgpu_wav
 }
 
 // ------------------------------------------------------------------------------------------------
-// Camera::Update half pyramid (src/Camera.cpp:68-70): exact 2x2 box mean (a+b+c+d+2)>>2
-__global__ void k_half(const uint8_t* __restrict__ src, int sw, int sstride, uint8_t* __restrict__ dst, int dw, int dh) {
+// Camera::Update half pyramid (src/Camera.cpp:68-70), single-frame entry: cv::resize's area-fast path -- (a+b+c+d+2)>>2 over a complete
+// 2x2 block, the mean of the pixels that exist (round half to even) in the last column / row of a level that is one larger than half
+// of an odd source size (see gradient.hip k_half4 / oracle/orb.cpp orc_half_pyramid)
+__global__ void k_half(const uint8_t* __restrict__ src, int sw, int sh, int sstride, uint8_t* __restrict__ dst, int dw, int dh) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= dw || y >= dh) return;
     const uint8_t* s = src + (size_t)(2 * y) * sstride + 2 * x;
-    dst[(size_t)y * dw + x] = (uint8_t)((s[0] + s[1] + s[sstride] + s[sstride + 1] + 2) >> 2);
-    (void)sw;
+    const bool right = 2 * x + 1 < sw, below = 2 * y + 1 < sh;
+    if (right && below) dst[(size_t)y * dw + x] = (uint8_t)((s[0] + s[1] + s[sstride] + s[sstride + 1] + 2) >> 2);
+    else {
+        const int sum = s[0] + (right ? s[1] : 0) + (below ? s[sstride] : 0), count = 1 + (right ? 1 : 0) + (below ? 1 : 0);
+        dst[(size_t)y * dw + x] = (uint8_t)__float2int_rn((float)sum / (float)count);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1273,6 +1279,7 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
         }
         J.n = k;
         hipLaunchKernelGGL(k_small_ops, dim3((unsigned)std::min<uint32_t>(1024u, (e + 255u) / 256u)), dim3(256), 0, st, J);
+        HIPCHK(ctx, hipGetLastError());
     }
     DetLevels D; fill_det_levels(pl, d_frames, D);
     DescArgs G;
@@ -1333,12 +1340,13 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
         for (int l = 0; l < VIS_MAX_LEVELS; l++) { X.tile_base[l] = l < L ? pl->lv[l].tile_base : 0; X.ntiles[l] = l < L ? pl->lv[l].tiles_x * pl->lv[l].tiles_y : 0; }
         hipLaunchKernelGGL(k_fast_fix, dim3(2048), dim3(256), 0, st, (const FastTile*)pl->d_fast_tiles, d_frames, pl->total_tiles, t_base,
                            ctx->p.edge_threshold, pl->d_tile_cnt, X, (const int32_t*)pl->d_fix);
-        const int fix_grid = std::min(n * L, 65535);
+        const int fix_grid = n * L;                      // one workgroup per possible work-list entry (<= 4096 frames x 16 levels)
         if (big) hipLaunchKernelGGL(k_select_fix_1024, dim3(fix_grid), dim3(1024), sel_lds, st, D, pl->d_tile_cnt, pl->total_tiles,
                                     pl->d_seg_cnt, pl->d_flags, max_surv, n, tau, t_base, seg_cut, fix);
         else hipLaunchKernelGGL(k_select_fix, dim3(fix_grid), dim3(256), sel_lds, st, D, pl->d_tile_cnt, pl->total_tiles,
                                 pl->d_seg_cnt, pl->d_flags, max_surv, n, tau, t_base, seg_cut, fix);
         hipLaunchKernelGGL(k_tau_update, dim3(1), dim3(256), 0, st, (const int32_t*)pl->d_seg_cut, L, n, t_base, pl->d_tau);
+        HIPCHK(ctx, hipGetLastError());
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[3], st);
     // workgroups per frame: enough to fill the chip for small batches, a wave walks over many keypoints for large ones
@@ -1355,10 +1363,10 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
 int launch_half_pyramid(vis_ctx* ctx, const uint8_t* d_img, int w, int h, int stride, uint8_t* d_out[5]) {
     const uint8_t* src = d_img; int sw = w, sh = h, ss = stride;
     for (int l = 1; l < 5; l++) {
-        const int dw = sw >> 1, dh = sh >> 1;
+        const int dw = vis_half_dim(sw), dh = vis_half_dim(sh);
         if (dw < 1 || dh < 1) return VIS_E_INVALID;
         dim3 block(64, 4), grid((dw + 63) / 64, (dh + 3) / 4);
-        hipLaunchKernelGGL(k_half, grid, block, 0, ctx->stream, src, sw, ss, d_out[l], dw, dh);
+        hipLaunchKernelGGL(k_half, grid, block, 0, ctx->stream, src, sw, sh, ss, d_out[l], dw, dh);
         src = d_out[l]; sw = dw; sh = dh; ss = dw;
     }
     HIPCHK(ctx, hipGetLastError());

@@ -27,8 +27,10 @@ static __device__ __forceinline__ bool xcd_map(int b, int per_frame, int n, int&
     return frame < n;
 }
 
-// ---- Camera::Update: exact 2x2 box mean (a+b+c+d+2)>>2, 4 output pixels per thread --------------------------
-__global__ __launch_bounds__(256) void k_half4(const uint8_t* __restrict__ src, int sw, int sstride, size_t sframe,
+// ---- Camera::Update: cv::resize's area-fast path (scale exactly 2), 4 output pixels per thread: (a+b+c+d+2)>>2 over every complete
+// 2 x 2 source block; where the level is one larger than half of an odd source size, the last column / row averages the source
+// pixels that exist -- saturate_cast<uchar>((float)sum / count), count 1 or 2, round half to even (oracle/orb.cpp orc_half_pyramid)
+__global__ __launch_bounds__(256) void k_half4(const uint8_t* __restrict__ src, int sw, int sh, int sstride, size_t sframe,
                                                uint8_t* __restrict__ dst, int dw, int dh, size_t dframe, int nframes) {
     const int gx4 = (dw + 3) / 4;
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -38,7 +40,18 @@ __global__ __launch_bounds__(256) void k_half4(const uint8_t* __restrict__ src, 
     const uint8_t* s0 = src + (size_t)f * sframe + (size_t)(2 * y) * sstride + 2 * x4;
     const uint8_t* s1 = s0 + sstride;
     uint8_t* d = dst + (size_t)f * dframe + (size_t)y * dw + x4;
-    if (x4 + 4 <= dw) {
+    if (2 * y + 1 >= sh || 2 * (x4 + 3) + 1 >= sw) {                    // a partial block in this group of four (or in the whole last row)
+        for (int k = 0; k < 4 && x4 + k < dw; k++) {
+            const int sx = 2 * (x4 + k);
+            const bool right = sx + 1 < sw, below = 2 * y + 1 < sh;
+            if (right && below) d[k] = (uint8_t)((s0[2 * k] + s0[2 * k + 1] + s1[2 * k] + s1[2 * k + 1] + 2) >> 2);
+            else {
+                const int sum = s0[2 * k] + (right ? s0[2 * k + 1] : 0) + (below ? s1[2 * k] : 0);
+                const int count = 1 + (right ? 1 : 0) + (below ? 1 : 0);
+                d[k] = (uint8_t)__float2int_rn((float)sum / (float)count);
+            }
+        }
+    } else if (x4 + 4 <= dw) {
         typedef uint32_t __attribute__((aligned(1))) u32u;
         const uint2 a = make_uint2(*reinterpret_cast<const u32u*>(s0), *reinterpret_cast<const u32u*>(s0 + 4));
         const uint2 b = make_uint2(*reinterpret_cast<const u32u*>(s1), *reinterpret_cast<const u32u*>(s1 + 4));
@@ -56,7 +69,6 @@ __global__ __launch_bounds__(256) void k_half4(const uint8_t* __restrict__ src, 
         for (int k = 0; k < 4 && x4 + k < dw; k++)
             d[k] = (uint8_t)((s0[2 * k] + s0[2 * k + 1] + s1[2 * k] + s1[2 * k + 1] + 2) >> 2);
     }
-    (void)sw;
 }
 
 // ---- Camera::computeGradient ---------------------------------------------------------------------------------
@@ -235,7 +247,8 @@ __global__ __launch_bounds__(256) void k_debug_points(const vis_keypoint* __rest
 // ---- host side ----------------------------------------------------------------------------------------------
 size_t vis_grad_frame_elems(int w, int h) {
     size_t t = 0;
-    for (int l = 0; l < 5; l++) t += (size_t)(w >> l) * (h >> l);
+    int lw[5], lh[5]; vis_half_dims(w, h, lw, lh);
+    for (int l = 0; l < 5; l++) t += (size_t)lw[l] * lh[l];
     return (t + 63) & ~(size_t)63;                                   // frames start on 64-element boundaries
 }
 
@@ -320,15 +333,17 @@ int launch_half_pyramid_batch(vis_ctx* ctx, const uint8_t* d_frames, int w, int 
         HIPCHK(ctx, hipGetLastError());
         return VIS_OK;
     }
+    int lw[5], lh[5]; vis_half_dims(w, h, lw, lh);
     size_t off = 0;
     for (int l = 1; l < 5; l++) {
-        const int sw = w >> (l - 1), sh = h >> (l - 1), dw = sw >> 1, dh = sh >> 1;
+        const int sw = lw[l - 1], sh = lh[l - 1], dw = lw[l], dh = lh[l];
+        if (dw < 1 || dh < 1) return VIS_E_INVALID;
         const uint8_t* src = l == 1 ? d_frames : d_pyr + off;
         const int ss = l == 1 ? stride : sw;
         const size_t sf = l == 1 ? frame_bytes : fe;
         off += (size_t)sw * sh;
         const int items = ((dw + 3) / 4) * dh;
-        hipLaunchKernelGGL(k_half4, dim3((items + 255) / 256, n), dim3(256), 0, ctx->stream, src, sw, ss, sf, d_pyr + off, dw, dh, fe, n);
+        hipLaunchKernelGGL(k_half4, dim3((items + 255) / 256, n), dim3(256), 0, ctx->stream, src, sw, sh, ss, sf, d_pyr + off, dw, dh, fe, n);
     }
     HIPCHK(ctx, hipGetLastError());
     return VIS_OK;
@@ -338,10 +353,11 @@ int launch_gradient(vis_ctx* ctx, const uint8_t* d_frames, int w, int h, int str
                     const uint8_t* d_pyr, int scale, int16_t* d_gx, int16_t* d_gy, uint8_t* d_g) {
     GradArgs G;
     G.frame_elems = vis_grad_frame_elems(w, h);
+    int lw[5], lh[5]; vis_half_dims(w, h, lw, lh);
     size_t off = 0; int blocks = 0;
     for (int l = 0; l < 5; l++) {
         GradLevel& L = G.lv[l];
-        L.w = w >> l; L.h = h >> l; L.off = off;
+        L.w = lw[l]; L.h = lh[l]; L.off = off;
         if (L.w < 2 || L.h < 2) return VIS_E_INVALID;
         L.items_x = (L.w + 7) / 8;
         L.items = L.items_x * ((L.h + GR_ROWS - 1) / GR_ROWS);

@@ -132,8 +132,8 @@ struct vis_ctx {
     int32_t* d_sample_table = nullptr; int sample_max_m = 0; int sample_iters = 0; unsigned long long sample_seed = 0;
 };
 
-// roctx ranges around the stage families of a batched step (readable rocprofv3 --marker-trace timelines); compiled in when the
-// ROCm install has the roctx header (Makefile: -DVIS_HAVE_ROCTX -lrocprofiler-sdk-roctx), otherwise no-ops
+// roctx ranges around the stage families of a batched step (readable rocprofv3 --marker-trace timelines); compiled in only by
+// `make ROCTX=1` (-DVIS_HAVE_ROCTX -lrocprofiler-sdk-roctx: a diagnostic build), otherwise no-ops
 #ifdef VIS_HAVE_ROCTX
 #include <rocprofiler-sdk-roctx/roctx.h>
 struct VisRange { explicit VisRange(const char* n) { roctxRangePushA(n); } ~VisRange() { roctxRangePop(); } };
@@ -174,6 +174,12 @@ int launch_pose(vis_ctx* ctx, Plan* pl, int npairs);
 int launch_half_pyramid(vis_ctx* ctx, const uint8_t* d_img, int w, int h, int stride, uint8_t* d_out[5]);
 // gradient.hip: Camera::Update / computeGradient / patch builders, batched
 size_t vis_grad_frame_elems(int w, int h);
+// cvRound(n * 0.5), round half to even: the size cv::resize(src, dst, Size(), 0.5, 0.5) gives the next level (include/vislam_hip.h)
+static inline int vis_half_dim(int n) { return (n >> 1) + ((n & 1) & ((n >> 1) & 1)); }
+static inline void vis_half_dims(int w, int h, int lw[5], int lh[5]) {
+    lw[0] = w; lh[0] = h;
+    for (int l = 1; l < 5; l++) { lw[l] = vis_half_dim(lw[l - 1]); lh[l] = vis_half_dim(lh[l - 1]); }
+}
 int launch_half_pyramid_batch(vis_ctx* ctx, const uint8_t* d_frames, int w, int h, int stride, size_t frame_bytes, int n, uint8_t* d_pyr);
 int launch_gradient(vis_ctx* ctx, const uint8_t* d_frames, int w, int h, int stride, size_t frame_bytes, int n,
                     const uint8_t* d_pyr, int scale, int16_t* d_gx, int16_t* d_gy, uint8_t* d_g);

@@ -185,21 +185,24 @@ void Camera::Update(Mat _grayImage) {                                           
     currentFrame = new Frame();
     elapsed_computeGoodMatches = elapsed_descriptors = elapsed_detect = 0.0;
     _grayImage.copyTo(currentFrame->grayImage[0]);
-    if ((_grayImage.cols & 15) == 0 && (_grayImage.rows & 15) == 0) {
+    if (_grayImage.cols >= 16 && _grayImage.rows >= 16) {
+        // resize(prev, next, Size(), 0.5, 0.5): the level sizes are cv::resize's cvRound(size * 0.5) (vis_half_pyramid_dims)
+        int32_t lw[5], lh[5]; vis_half_pyramid_dims(_grayImage.cols, _grayImage.rows, lw, lh);
         uint8_t* lv[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-        for (int i = 1; i < 5; i++) { currentFrame->grayImage[i].create(_grayImage.rows >> i, _grayImage.cols >> i, CV_8U); lv[i] = currentFrame->grayImage[i].data; }
+        for (int i = 1; i < 5; i++) { currentFrame->grayImage[i].create(lh[i], lw[i], CV_8U); lv[i] = currentFrame->grayImage[i].data; }
         int rc = vis_camera_update(VisDevice::get(), _grayImage.data, _grayImage.cols, _grayImage.rows, (int)_grayImage.step, lv);
         if (rc) VisDevice::fail(rc, "Camera::Update");
     }
 }
 void Camera::computeGradient() {                                                  // src/Camera.cpp:167-184
     const Mat& img = currentFrame->grayImage[0];
-    if ((img.cols & 15) || (img.rows & 15)) return;                               // same restriction as Update's half pyramid
+    if (img.cols < 16 || img.rows < 16) return;
+    int32_t lw[5], lh[5]; vis_half_pyramid_dims(img.cols, img.rows, lw, lh);           // Scharr(grayImage[lvl]): the size of that Mat
     int16_t* gx[5]; int16_t* gy[5]; uint8_t* g[5];
     for (int lvl = 0; lvl < 5; lvl++) {
-        currentFrame->gradientX[lvl].create(img.rows >> lvl, img.cols >> lvl, CV_16S);
-        currentFrame->gradientY[lvl].create(img.rows >> lvl, img.cols >> lvl, CV_16S);
-        currentFrame->gradient[lvl].create(img.rows >> lvl, img.cols >> lvl, CV_8U);
+        currentFrame->gradientX[lvl].create(lh[lvl], lw[lvl], CV_16S);
+        currentFrame->gradientY[lvl].create(lh[lvl], lw[lvl], CV_16S);
+        currentFrame->gradient[lvl].create(lh[lvl], lw[lvl], CV_8U);
         gx[lvl] = reinterpret_cast<int16_t*>(currentFrame->gradientX[lvl].data);
         gy[lvl] = reinterpret_cast<int16_t*>(currentFrame->gradientY[lvl].data);
         g[lvl] = currentFrame->gradient[lvl].data;
@@ -545,13 +548,15 @@ void VISystem::EstimatePoseFeatures(Frame* _previous_frame, Frame* _current_fram
     const uint8_t* g1[5]; const uint8_t* g2[5]; const int16_t* gx[5]; const int16_t* gy[5]; const float* cd[5]; int32_t n[5];
     // With a rectifying calibration the system's (w, h) is the ROI of src/VISystem.cpp:162-205 while the frames keep their
     // size: the reference bounds-checks against w_[lvl], h_[lvl] and indexes the full-size Mats (:1267-1305).  The C ABI takes
-    // dense w_[lvl] x h_[lvl] levels, so the top-left w_[lvl] x h_[lvl] window of every level is what is handed over.
+    // dense levels of the sizes vis_half_pyramid_dims(w_[0], h_[0]) gives (w_[lvl] x h_[lvl], or one column / row more where a size
+    // does not halve exactly), so the top-left window of that size of every level is what is handed over.
+    int32_t aw[5], ah[5]; vis_half_pyramid_dims(w_[0], h_[0], aw, ah);
     Mat crop[4][5];
     auto window = [&](const Mat& m, int l, Mat& keep) -> const uint8_t* {
-        if (m.empty() || (m.cols == w_[l] && m.rows == h_[l] && m.step == (size_t)m.cols * m.elemSize())) return m.data;
-        if (m.cols < w_[l] || m.rows < h_[l]) return nullptr;
-        keep.create(h_[l], w_[l], m.depth);
-        for (int y = 0; y < h_[l]; y++) std::memcpy(keep.data + (size_t)y * keep.step, m.data + (size_t)y * m.step, keep.step);
+        if (m.empty() || (m.cols == aw[l] && m.rows == ah[l] && m.step == (size_t)m.cols * m.elemSize())) return m.data;
+        if (m.cols < aw[l] || m.rows < ah[l]) return nullptr;
+        keep.create(ah[l], aw[l], m.depth);
+        for (int y = 0; y < ah[l]; y++) std::memcpy(keep.data + (size_t)y * keep.step, m.data + (size_t)y * m.step, keep.step);
         return keep.data;
     };
     for (int l = 0; l < 5; l++) {
@@ -560,7 +565,7 @@ void VISystem::EstimatePoseFeatures(Frame* _previous_frame, Frame* _current_fram
         gy[l] = reinterpret_cast<const int16_t*>(window(_previous_frame->gradientY[l], l, crop[3][l]));
         cd[l] = reinterpret_cast<const float*>(_previous_frame->candidatePoints[l].data);
         n[l] = _previous_frame->candidatePoints[l].rows;
-        if (!g1[l] || !g2[l] || !gx[l] || !gy[l]) n[l] = 0;                            // Update() could not build the half pyramid (size not a multiple of 16)
+        if (!g1[l] || !g2[l] || !gx[l] || !gy[l]) n[l] = 0;                            // Update() could not build the half pyramid (frame smaller than 16 x 16)
     }
     const float sx = TranslationResidual.at<float>(0, 0), sy = TranslationResidual.at<float>(1, 0), sz = TranslationResidual.at<float>(2, 0);
     const SE3 current_pose(Matx33f::eye(), SE3::Point(-sx, -sy, -sz));                 // :1159

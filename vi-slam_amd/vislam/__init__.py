@@ -111,7 +111,7 @@ ABI_SYMBOLS = [
     "vis_recover_pose", "vis_f2f_ransac", "vis_batch_plan", "vis_batch_reset", "vis_batch_run",
     "vis_batch_sync", "vis_batch_get_keypoints", "vis_batch_get_knn", "vis_batch_get_matches",
     "vis_batch_get_pose", "vis_batch_status", "vis_synth_canvas", "vis_synth_frame",
-    "vis_gradient_frame_elems", "vis_gradient_batch", "vis_compute_gradient", "vis_patch_points",
+    "vis_gradient_frame_elems", "vis_half_pyramid_dims", "vis_gradient_batch", "vis_compute_gradient", "vis_patch_points",
     "vis_image_list", "vis_image_time", "vis_pgm_info", "vis_image_read",
     "vis_feeder_create", "vis_feeder_destroy", "vis_feeder_host_buffer", "vis_feeder_submit", "vis_feeder_release",
     "vis_default_align_params", "vis_estimate_pose_features", "vis_align_batch", "vis_batch_align",
@@ -164,6 +164,8 @@ def _load():
     lib.vis_synth_frame.argtypes = [vp, ci, C.c_uint64, ci, ci, ci, vp, ci]
     lib.vis_gradient_frame_elems.argtypes = [ci, ci]
     lib.vis_gradient_frame_elems.restype = C.c_size_t
+    lib.vis_half_pyramid_dims.argtypes = [ci, ci, C.c_void_p, C.c_void_p]
+    lib.vis_half_pyramid_dims.restype = None
     lib.vis_gradient_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp]
     lib.vis_compute_gradient.argtypes = [vp, vp, ci, ci, ci, ci, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     lib.vis_patch_points.argtypes = [vp, vp, ci, ci, C.POINTER(C.c_void_p), ip, C.POINTER(C.c_void_p), ip]
@@ -258,6 +260,13 @@ def se3_matrix(a):
 # ---- synthetic stream (host-side utility of the library; integer-only, bit-reproducible) ----------
 def gradient_frame_elems(w, h):
     return int(lib.vis_gradient_frame_elems(w, h))
+
+
+def half_pyramid_dims(w, h):
+    """(widths, heights) of Camera::Update's 5 levels: cvRound(size * 0.5) per step, round half to even (include/vislam_hip.h)"""
+    lw = np.zeros(5, np.int32); lh = np.zeros(5, np.int32)
+    lib.vis_half_pyramid_dims(w, h, _ptr(lw), _ptr(lh))
+    return [int(x) for x in lw], [int(x) for x in lh]
 
 
 # -- ImageReader (src/ImageReader.cpp): directory listing, timestamp stems, PGM / raw decode; no GPU involved --------
@@ -392,7 +401,8 @@ class Context:
     def camera_update(self, img):
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape
-        levels = [np.empty((h >> l, w >> l), np.uint8) for l in range(5)]
+        lw, lh = half_pyramid_dims(w, h)
+        levels = [np.empty((lh[l], lw[l]), np.uint8) for l in range(5)]
         arr = (C.c_void_p * 5)(*[l.ctypes.data for l in levels])
         self._chk(lib.vis_camera_update(self._h, _ptr(img), w, h, img.strides[0], arr), "vis_camera_update")
         return levels
@@ -402,9 +412,10 @@ class Context:
         """one host frame -> per level (gx int16, gy int16, gradient u8) of the 5 half-pyramid levels"""
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape
-        gx = [np.empty((h >> l, w >> l), np.int16) for l in range(5)]
-        gy = [np.empty((h >> l, w >> l), np.int16) for l in range(5)]
-        g = [np.empty((h >> l, w >> l), np.uint8) for l in range(5)]
+        lw, lh = half_pyramid_dims(w, h)
+        gx = [np.empty((lh[l], lw[l]), np.int16) for l in range(5)]
+        gy = [np.empty((lh[l], lw[l]), np.int16) for l in range(5)]
+        g = [np.empty((lh[l], lw[l]), np.uint8) for l in range(5)]
         ax = (C.c_void_p * 5)(*[a.ctypes.data for a in gx])
         ay = (C.c_void_p * 5)(*[a.ctypes.data for a in gy])
         ag = (C.c_void_p * 5)(*[a.ctypes.data for a in g])
