@@ -95,7 +95,11 @@ typedef struct vis_params {
      * matches (Frame::next/prevGoodMatches, src/VISystem.cpp:1673-1674); BASELINE config 3 asks for RANSAC on the
      * un-gridded symmetric matches (M up to N) */
     int32_t pose_input;       /* VIS_POSE_GOOD */
-    int32_t reserved_;
+    /* Device capacity for the keypoints of ONE frame; 0 = the default, sum over the levels of quota + quota/8 + 32.
+     * KeyPointsFilter::retainBest keeps EVERY keypoint tied at its cut, so an image of identical corners (a calibration
+     * checkerboard) yields more than nfeatures keypoints.  Beyond the capacity a call returns VIS_E_CAPACITY (never a silent cut);
+     * the single-frame entry vis_orb_detect_compute grows the capacity itself up to the `cap` its caller passes. <= 65535. */
+    int32_t keypoint_capacity;
 } vis_params;
 enum { VIS_POSE_GOOD = 0, VIS_POSE_SYM = 1 };
 

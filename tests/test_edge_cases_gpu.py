@@ -70,20 +70,46 @@ def test_heavy_ties_checkerboard(vislam, orc, ctx):
     assert len(k) == 384 and k.tobytes() == ok.tobytes() and (d == od).all()
 
 
-def test_ties_beyond_the_slack_are_reported(vislam, ctx):
-    """same image, quota 150: the 384 tied responses exceed keep_cap (200) -> VIS_E_CAPACITY, never a silent cut"""
+def test_ties_beyond_the_default_slack_are_all_returned(vislam, orc, ctx):
+    """same image, quota 150: 384 tied Harris responses against a default capacity of 200 per frame.  KeyPointsFilter::retainBest keeps
+    every tie (oracle/orb.cpp), so the single-frame entry grows the device capacity towards the caller's `cap` and returns all 384 --
+    bit-identical to the oracle; VIS_E_CAPACITY only when the CALLER's capacity is too small.  The slots detected before the growth
+    keep their records."""
     p = vislam.default_params()
     p.nlevels, p.nfeatures, p.w_size, p.h_size = 1, 150, 320, 240
     ctx.set_params(p)
-    with pytest.raises(vislam.VisError) as ei:
-        ctx.orb_detect_compute(_checkerboard(), slot=0, cap=20000)
+    other = np.random.default_rng(3).integers(0, 256, (240, 320), dtype=np.uint8)
+    k1, d1 = ctx.orb_detect_compute(other, slot=1)                      # a normal frame in another slot, before the growth
+    k, d = ctx.orb_detect_compute(_checkerboard(), slot=0, cap=20000)
+    ok, od = orc.orb_detect_compute(p, _checkerboard(), cap=20000)
+    assert len(k) == 384 and k.tobytes() == ok.tobytes() and (d == od).all()
+    g12, g21 = ctx.bf_knn2_hamming(1, 0, len(k1), len(k))               # slot 1 survived the re-planning
+    o12, o21 = orc.knn2_hamming(d1, d)
+    assert g12.tobytes() == o12.tobytes() and g21.tobytes() == o21.tobytes()
+    with pytest.raises(vislam.VisError) as ei:                          # the caller's own buffer is too small: reported, never cut
+        ctx.orb_detect_compute(_checkerboard(), slot=0, cap=300)
     assert ei.value.code == -4
-    # the flag is cleared by the failed call: the context keeps working
+    # an explicit capacity does the same for the batched path
+    import torch
     q = vislam.default_params()
-    q.nlevels, q.nfeatures, q.w_size, q.h_size = 1, 360, 320, 240
-    ctx.set_params(q)
-    k, _ = ctx.orb_detect_compute(_checkerboard(), slot=0, cap=20000)
-    assert len(k) == 384
+    q.nlevels, q.nfeatures, q.w_size, q.h_size, q.keypoint_capacity = 1, 150, 320, 240, 500
+    c2 = vislam.Context(0, q)
+    fr = np.stack([_checkerboard(), other])
+    dev = torch.from_numpy(fr).cuda()
+    c2.batch_plan(320, 240, 320, 2)
+    c2.batch_run(dev.data_ptr(), 2, vislam.STAGE_DETECT)
+    c2.batch_sync()
+    assert c2.batch_status() == 0
+    kb, db = c2.batch_keypoints(0, cap=500)
+    assert len(kb) == 384 and kb.tobytes() == ok.tobytes() and (db == od).all()
+    c2.close()
+    q.keypoint_capacity = 0                                             # default capacity: the batched path reports, never cuts
+    c3 = vislam.Context(0, q)
+    c3.batch_plan(320, 240, 320, 2)
+    c3.batch_run(dev.data_ptr(), 2, vislam.STAGE_DETECT)
+    c3.batch_sync()
+    assert c3.batch_status() != 0
+    c3.close()
 
 
 def _one_over_f(h, w, seed):

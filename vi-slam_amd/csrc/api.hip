@@ -55,6 +55,7 @@ static int validate_params(const vis_params& p) {
     if (!(p.ransac_prob > 0 && p.ransac_prob < 1) || !(p.fx > 0) || !(p.fy > 0)) return VIS_E_INVALID;
     if (p.f2f_iters < 0) return VIS_E_INVALID;
     if (p.pose_input != VIS_POSE_GOOD && p.pose_input != VIS_POSE_SYM) return VIS_E_INVALID;
+    if (p.keypoint_capacity < 0 || p.keypoint_capacity > 65535) return VIS_E_INVALID;
     return VIS_OK;
 }
 
@@ -140,7 +141,7 @@ extern "C" const char* vis_last_error(vis_ctx* ctx) { return ctx ? ctx->err.c_st
 // the fields that fix the per-record layout (keypoint capacity per level, descriptor pattern)
 static bool same_record_geometry(const vis_params& a, const vis_params& b) {
     return a.nfeatures == b.nfeatures && a.nlevels == b.nlevels && a.scale_factor == b.scale_factor &&
-           a.edge_threshold == b.edge_threshold && a.patch_size == b.patch_size;
+           a.edge_threshold == b.edge_threshold && a.patch_size == b.patch_size && a.keypoint_capacity == b.keypoint_capacity;
 }
 
 extern "C" int vis_set_params(vis_ctx* ctx, const vis_params* p) {
@@ -247,7 +248,8 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
     int rc = vis_compute_levels(ctx->p, w, h, stride, pl->lv);
     if (rc) { delete pl; return rc; }
     const int L = pl->L;
-    int kcap = 0; for (int l = 0; l < L; l++) kcap += pl->lv[l].keep_cap;
+    int kcap = 0; for (int l = 0; l < L; l++) kcap += pl->lv[l].quota + pl->lv[l].quota / 8 + 32;      // default: every level's own slack
+    kcap = std::max(kcap, ctx->p.keypoint_capacity);             // (the levels' keep_cap share whatever the caller asked for beyond it)
     if (kcap > 65535) { delete pl; return VIS_E_INVALID; }       // packed 16-bit indices in the matcher
     pl->kcap = kcap;
     std::vector<float> hf, wf; vis_grid_limits(ctx->p, &pl->root, hf, wf);
@@ -392,6 +394,32 @@ static int ensure_single(vis_ctx* ctx, int w, int h) {
     return plan_create(ctx, w, h, stride, 1, VIS_NSLOTS, 1, &ctx->single);
 }
 
+// re-create the single-frame plan with a larger per-frame keypoint capacity; the valid slots keep their records
+static int grow_single(vis_ctx* ctx, int capacity) {
+    Plan* old = ctx->single;
+    if (!old) return VIS_E_STATE;
+    sync_all(ctx);
+    ctx->p.keypoint_capacity = capacity;
+    Plan* np = nullptr;
+    int rc = plan_create(ctx, old->w, old->h, old->stride, 1, VIS_NSLOTS, 1, &np);
+    if (rc) return rc;
+    if (np->kcap < old->kcap || np->nrec != old->nrec) { plan_destroy(np); return VIS_E_STATE; }
+    std::vector<int32_t> nk((size_t)old->nrec);
+    HIPCHK(ctx, hipMemcpy(nk.data(), old->d_nkp, nk.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(np->d_nkp, nk.data(), nk.size() * 4, hipMemcpyHostToDevice));
+    for (int r = 0; r < old->nrec && r < VIS_NSLOTS; r++) {
+        const size_t n = (size_t)std::min(std::max(nk[r], 0), old->kcap);
+        if (!ctx->slot_valid[r] || !n) continue;
+        HIPCHK(ctx, hipMemcpy(np->d_kps + (size_t)r * np->kcap, old->d_kps + (size_t)r * old->kcap, n * sizeof(vis_keypoint), hipMemcpyDeviceToDevice));
+        HIPCHK(ctx, hipMemcpy(np->d_desc + (size_t)r * np->kcap * 32, old->d_desc + (size_t)r * old->kcap * 32, n * 32, hipMemcpyDeviceToDevice));
+        HIPCHK(ctx, hipMemcpy(np->d_descx + (size_t)r * np->kcap * 128, old->d_descx + (size_t)r * old->kcap * 128, n * 128, hipMemcpyDeviceToDevice));
+    }
+    plan_destroy(old);
+    ctx->single = np;
+    plan_destroy(ctx->batch); ctx->batch = nullptr;              // (its capacity belongs to the old parameters)
+    return VIS_OK;
+}
+
 static void key_to_dmatch(uint32_t key, int q, vis_dmatch* m) {
     m->queryIdx = q;
     if (key == 0xFFFFFFFFu) { m->trainIdx = -1; m->imgIdx = -1; m->distance = FLT_MAX; }
@@ -401,7 +429,11 @@ static void key_to_dmatch(uint32_t key, int q, vis_dmatch* m) {
 static int check_flags(vis_ctx* ctx, Plan* pl) {
     int32_t fl = 0;
     HIPCHK(ctx, hipMemcpy(&fl, pl->d_flags, 4, hipMemcpyDeviceToHost));
-    if (fl) { ctx->err = "device capacity flag set: " + std::to_string(fl); HIPCHK(ctx, hipMemset(pl->d_flags, 0, 4)); return VIS_E_CAPACITY; }
+    if (fl) {
+        ctx->err = "device capacity flag set: " + std::to_string(fl) + ((fl & 12) ? " (more tied keypoints than vis_params.keypoint_capacity holds: " +
+                   std::to_string(pl->kcap) + " per frame; raise it)" : "");
+        HIPCHK(ctx, hipMemset(pl->d_flags, 0, 4)); return VIS_E_CAPACITY;
+    }
     return VIS_OK;
 }
 
@@ -529,6 +561,19 @@ extern "C" int vis_orb_detect_compute(vis_ctx* ctx, const uint8_t* img, int w, i
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     collect_detect_timings(ctx);
     { float a = 0; if (ctx->ev_ok && hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[4]) == hipSuccess) ctx->tm.ms_total = a; }
+    {   // More tied keypoints than the plan's records hold (KeyPointsFilter::retainBest keeps every tie at its cut: a checkerboard)?  The
+        // caller's `cap` says how many it is prepared to take: grow the per-frame capacity towards it -- the other slots' records move
+        // into the re-created plan -- and detect again.  Only what exceeds `cap` (or 65535) is an error.
+        int32_t fl = 0;
+        HIPCHK(ctx, hipMemcpy(&fl, pl->d_flags, 4, hipMemcpyDeviceToHost));
+        if ((fl & 12) && !(fl & ~12) && cap > pl->kcap && pl->kcap < 65535) {
+            HIPCHK(ctx, hipMemset(pl->d_flags, 0, 4));
+            const int want = std::min(65535, std::max(cap, 2 * pl->kcap));
+            rc = grow_single(ctx, want);
+            if (rc) return rc;
+            return vis_orb_detect_compute(ctx, img, w, h, stride, frame_slot, kps_out, desc_out, cap, n_out);
+        }
+    }
     rc = check_flags(ctx, pl);
     if (rc) return rc;
     ctx->slot_valid[frame_slot] = 1;

@@ -41,15 +41,20 @@ int vis_compute_levels(const vis_params& p, int w, int h, int stride0, LevelInfo
         nd *= factor;
     }
     lv[p.nlevels - 1].quota = std::max(p.nfeatures - sum, 0);
+    // vis_params.keypoint_capacity beyond the default total is slack that ANY level may use (ties at the Harris cut sit on one level)
+    int def_total = 0;
+    for (int l = 0; l < p.nlevels; l++) def_total += lv[l].quota + lv[l].quota / 8 + 32;
+    const int extra = std::max(0, p.keypoint_capacity - def_total);
     for (int l = 0; l < p.nlevels; l++) {
         int q = lv[l].quota;
         // survivors of the FAST-score cut: 2*quota plus ties at the cut (FAST scores are small
-        // integers, ties are common); kept after the Harris cut: quota plus (rare) ties.
+        // integers, ties are common); kept after the Harris cut: quota plus ties.
         int sc = 2 * q + q / 2 + 256;
         int pw = 64; while (pw < sc) pw <<= 1;
         if (pw > 8192) return VIS_E_INVALID;             // LDS sort limit (64 KiB of keys)
+        while (pw < sc + extra && pw < 8192) pw <<= 1;    // a raised capacity also widens the one-round sort (k_select's LDS), up to that limit
         lv[l].surv_cap = pw;
-        lv[l].keep_cap = q + q / 8 + 32;
+        lv[l].keep_cap = std::min(q + q / 8 + 32 + extra, pw);
     }
     return VIS_OK;
 }

@@ -46,7 +46,7 @@ class Params(C.Structure):
         ("ransac_max_iters", C.c_int32), ("ransac_adaptive", C.c_int32), ("ransac_seed", C.c_uint64),
         ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
         ("f2f_iters", C.c_int32), ("f2f_threshold", C.c_double),
-        ("pose_input", C.c_int32), ("reserved_", C.c_int32),
+        ("pose_input", C.c_int32), ("keypoint_capacity", C.c_int32),
     ]
 
     def copy(self):
