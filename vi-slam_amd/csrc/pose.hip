@@ -20,6 +20,7 @@
 // Algorithm and operation order mirror oracle/pose.cpp; compared with a stated tolerance
 // (tests/test_pose_gpu.py), not bit-exactly.
 #include "vis_internal.h"
+#include <type_traits>
 #include <cfloat>
 #include <cstdlib>
 
@@ -890,21 +891,67 @@ __global__ __launch_bounds__(256) void k_hyp_models(PoseParams P, int h0, int h_
 // 256 threads then score every model of the sub-item against the pair's points (wave = model, lanes = points),
 // and thread hyp picks the first model with the largest count.  hbest[pair][h] = (best count << 4) | model, -1 = none.
 #define SC_CH 256                                                  // points staged in LDS per pass (512: 29 KB of LDS per workgroup and 1.30 instead of 0.98 ms per 1.02 M hypotheses)
+// The Sampson test `(float)(num / den) <= thr^2` of cv's five-point estimator, decided in SINGLE precision wherever single precision
+// can decide it, in double (the oracle's operation sequence, bit for bit) everywhere else.  FP64 issues at half the FP32 rate and
+// the double form has no fused multiply-adds (the oracle is compiled without contraction): 34 FP64 operations against 26 FP32 ones.
+//   s = x2^T E x1, den = (E x1)_0^2 + (E x1)_1^2 + (E^T x2)_0^2 + (E^T x2)_1^2, inlier <=> s^2 / den <= tmid (the double half way between
+//   thr^2 and the next float).  With u = 2^-24, ||E||_F = 1 (k_hyp_models normalises), R1 = max(|x1|, |y1|, 1), R2 likewise:
+//     every (E x1)_k, (E^T x2)_k evaluated from float-rounded inputs with two fmaf: error <= 4 u (|e0 x| + |e1 y| + |e2|) <= 8 u R
+//     s from those and the float-rounded x2: error <= 3 R2 (8 u R1) + 3 u (3 sqrt(3) R1 R2) < 40 u R1 R2        -> es = 64 u R1 R2
+//     den (four squares of values <= sqrt(3) R, each off by <= 8 u R, three additions): error < 160 u R^2           -> ed = 256 u max(R1, R2)^2
+//   (|s32| + es)^2 <= tlo (den32 - ed)  =>  certainly an inlier;   |s32| > es and (|s32| - es)^2 >= thi (den32 + ed)  =>  certainly not;
+//   tlo / thi = tmid (1 -/+ 2^-16) absorb the roundings of these two comparisons themselves.  Anything else -- a band of about
+//   +-0.2 % around the threshold at unit R (+-2 % at the image corners of config 3, R = 3.4), a NaN, a vanishing den -- takes the
+//   double path.  The decisions, hence masks, counts and
+//   iteration numbers, are the oracle's for every input (tests/test_pose_gpu.py, test_configs_gpu.py compare them exactly).
+struct ScorePt { float x1, y1, x2, y2, es, ed; };
+DEV int sampson_in_f64(const double* __restrict__ Em, double x1, double y1, double x2, double y2, double kLo, double kHi, float thr2) {
+    const double Ex0 = (Em[0] * x1 + Em[1] * y1) + Em[2];
+    const double Ex1 = (Em[3] * x1 + Em[4] * y1) + Em[5];
+    const double Ex2 = (Em[6] * x1 + Em[7] * y1) + Em[8];
+    const double Et0 = (Em[0] * x2 + Em[3] * y2) + Em[6];
+    const double Et1 = (Em[1] * x2 + Em[4] * y2) + Em[7];
+    const double x2tEx1 = (x2 * Ex0 + y2 * Ex1) + Ex2;
+    const double a = Ex0 * Ex0, b = Ex1 * Ex1, c = Et0 * Et0, d = Et1 * Et1;
+    const double num = x2tEx1 * x2tEx1, den = ((a + b) + c) + d;
+    // division-free classification of (float)(num/den) <= thr2: num <= kLo*den is certainly an inlier, num >= kHi*den certainly an
+    // outlier (margins 2^-40 >> the 2^-53 rounding of the products), anything in between takes the exact division
+    if (den > 0 && num <= kLo * den) return 1;
+    if (num >= kHi * den) return 0;
+    return (float)(num / den) <= thr2 ? 1 : 0;
+}
+// returns 1 / 0, or -1 = undecided in single precision
+DEV int sampson_in_f32(const float (&e)[9], const ScorePt& p, float tlo, float thi) {
+    const float ex0 = __fmaf_rn(e[0], p.x1, __fmaf_rn(e[1], p.y1, e[2]));
+    const float ex1 = __fmaf_rn(e[3], p.x1, __fmaf_rn(e[4], p.y1, e[5]));
+    const float ex2 = __fmaf_rn(e[6], p.x1, __fmaf_rn(e[7], p.y1, e[8]));
+    const float et0 = __fmaf_rn(e[0], p.x2, __fmaf_rn(e[3], p.y2, e[6]));
+    const float et1 = __fmaf_rn(e[1], p.x2, __fmaf_rn(e[4], p.y2, e[7]));
+    const float s = fabsf(__fmaf_rn(p.x2, ex0, __fmaf_rn(p.y2, ex1, ex2)));
+    const float den = __fmaf_rn(ex0, ex0, __fmaf_rn(ex1, ex1, __fmaf_rn(et0, et0, et1 * et1)));
+    const float hi = s + p.es, lo = s - p.es;
+    const bool in = hi * hi <= tlo * (den - p.ed);                 // (den - ed <= 0: the left side is > 0 >= the right side, es > 0)
+    const bool out = lo > 0.f && lo * lo >= thi * (den + p.ed);
+    return in ? 1 : (out ? 0 : -1);                                // selects, no branches (a NaN fails both comparisons: undecided)
+}
 // rstate is read (words 0, 6) AND written (word 8, the models-scored counter) here: a plain pointer, no const / __restrict__ promise
 __global__ __launch_bounds__(256) void k_hyp_score(PoseParams P, int h0, int h_end, int npairs, int32_t* rstate,
                                                    const double* __restrict__ n1, const double* __restrict__ n2,
                                                    const double* __restrict__ hyp, size_t S, const double* __restrict__ models,
                                                    int32_t* __restrict__ hbest, const int32_t* __restrict__ worklist, int chunks) {
-    __shared__ double sE[160][9];
-    __shared__ double sX1[SC_CH], sY1[SC_CH], sX2[SC_CH], sY2[SC_CH];
+    __shared__ __attribute__((aligned(16))) float sE[160][12];     // the sub-item's models, single precision, 48-byte rows (the double path re-reads `models`)
+    __shared__ ScorePt sP[SC_CH];
+    // (model, point) decisions that single precision left open, settled afterwards by ALL threads at once: inside the model loop a
+    // single undecided lane would hold its whole wave for a double-precision evaluation from global memory
+    constexpr int AMB_CAP = 2048;
+    __shared__ uint32_t sAmb[AMB_CAP];
+    __shared__ int32_t sNamb;
     __shared__ int32_t sBase[16], sCnt[16], sTag[160], sGood[160], sTotal;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float thr2 = (float)(P.thr * P.thr);
-    // division-free classification of (float)(num/den) <= thr2: mid = the double half way between thr2 and the next
-    // float; num <= kLo*den is certainly an inlier, num >= kHi*den certainly an outlier (margins 2^-40 >> the 2^-53
-    // rounding of the products), anything in between takes the exact division.  Same decisions as the oracle.
     const double tmid = 0.5 * ((double)thr2 + (double)__uint_as_float(__float_as_uint(thr2) + 1u));
     const double kLo = tmid * (1.0 - 0x1p-40), kHi = tmid * (1.0 + 0x1p-40);
+    const float tlo = __double2float_rd(tmid * (1.0 - 0x1p-16)), thi = __double2float_ru(tmid * (1.0 + 0x1p-16));
     for (int sub = blockIdx.x; ; sub += gridDim.x) {
         int pair, hbase;
         if (!sub_item(worklist, chunks, h0, npairs, sub, pair, hbase)) return;
@@ -921,28 +968,45 @@ __global__ __launch_bounds__(256) void k_hyp_score(PoseParams P, int h0, int h_e
             if (t) atomicAdd(rstate + (size_t)pair * RS + 8, t);   // point evaluations = models x M
         }
         __syncthreads();
+        const double* mbase = models + ((size_t)pair * P.max_iters + hbase) * 90;
         {
             const int hy = tid / 10, m = tid - hy * 10;            // thread = (hypothesis, model): the sub-item's model list in LDS
             if (tid < 160 && m < sCnt[hy]) {
                 const int t = sBase[hy] + m;
-                const double* mo = models + ((size_t)pair * P.max_iters + hbase + hy) * 90 + 9 * m;
+                const double* mo = mbase + (size_t)hy * 90 + 9 * m;
 #pragma unroll
-                for (int k = 0; k < 9; k++) sE[t][k] = mo[k];
+                for (int k = 0; k < 9; k++) sE[t][k] = (float)mo[k];
                 sTag[t] = (hy << 4) | m; sGood[t] = 0;
             }
         }
         const int T = sTotal;
         const double* pa = n1 + (size_t)pair * P.mcap * 2;
         const double* pb = n2 + (size_t)pair * P.mcap * 2;
-        for (int c0 = 0; c0 < (T > 0 ? M : 0); c0 += SC_CH) {
+        // one (model t, point c0 + i) decision: single precision first, the oracle's double sequence when that cannot tell
+        auto decide = [&](const float (&e)[9], const ScorePt& pt, int t, int c0, int i) -> int {
+            int in = sampson_in_f32(e, pt, tlo, thi);
+            if (in < 0) {
+                const int tag = sTag[t];
+                const double* mo = mbase + (size_t)(tag >> 4) * 90 + 9 * (tag & 15);
+                in = sampson_in_f64(mo, pa[2 * (c0 + i)], pa[2 * (c0 + i) + 1], pb[2 * (c0 + i)], pb[2 * (c0 + i) + 1], kLo, kHi, thr2);
+            }
+            return in;
+        };
+        auto make_pt = [&](int gi) -> ScorePt {                     // point gi of the pair in single precision + its error radii (see above)
+            const double x1 = pa[2 * gi], y1 = pa[2 * gi + 1], x2 = pb[2 * gi], y2 = pb[2 * gi + 1];
+            ScorePt q; q.x1 = (float)x1; q.y1 = (float)y1; q.x2 = (float)x2; q.y2 = (float)y2;
+            const float R1 = fmaxf(fmaxf(fabsf(q.x1), fabsf(q.y1)), 1.f) * 1.000001f, R2 = fmaxf(fmaxf(fabsf(q.x2), fabsf(q.y2)), 1.f) * 1.000001f;
+            const float Rm = fmaxf(R1, R2);
+            q.es = 64.f * 0x1p-24f * R1 * R2; q.ed = 256.f * 0x1p-24f * Rm * Rm;
+            return q;
+        };
+        if (M <= 256) {
+          for (int c0 = 0; c0 < (T > 0 ? M : 0); c0 += SC_CH) {
             const int mc = min(M - c0, SC_CH);
             __syncthreads();
-            for (int i = tid; i < mc; i += 256) {
-                sX1[i] = pa[2 * (c0 + i)]; sY1[i] = pa[2 * (c0 + i) + 1];
-                sX2[i] = pb[2 * (c0 + i)]; sY2[i] = pb[2 * (c0 + i) + 1];
-            }
+            for (int i = tid; i < mc; i += 256) sP[i] = make_pt(c0 + i);
             __syncthreads();
-            if (M <= 256) {
+            {
                 // Few correspondences (the reference pipeline: <= root^2 = 49 grid matches): LANE = (model, slice of the points).  A
                 // wave-per-model pass would leave a third of the lanes idle at M = 43 and pay a wave reduction per model; here the
                 // only reduction is one LDS add per lane.  The points are cut into K slices, K chosen per sub-item so that the
@@ -959,57 +1023,74 @@ __global__ __launch_bounds__(256) void k_hyp_score(PoseParams P, int h0, int h_e
                 for (int t0 = 0; t0 < T; t0 += per) {
                     const int t = t0 + tl;
                     const int tc = min(t, T - 1);
-                    double Em[9];
+                    float Em[9];
 #pragma unroll
                     for (int k = 0; k < 9; k++) Em[k] = sE[tc][k];
                     int good = 0;
-                    for (int i = q0; i < q1; i++) {
-                        const double x1 = sX1[i], y1 = sY1[i], x2 = sX2[i], y2 = sY2[i];
-                        const double Ex0 = (Em[0] * x1 + Em[1] * y1) + Em[2];
-                        const double Ex1 = (Em[3] * x1 + Em[4] * y1) + Em[5];
-                        const double Ex2 = (Em[6] * x1 + Em[7] * y1) + Em[8];
-                        const double Et0 = (Em[0] * x2 + Em[3] * y2) + Em[6];
-                        const double Et1 = (Em[1] * x2 + Em[4] * y2) + Em[7];
-                        const double x2tEx1 = (x2 * Ex0 + y2 * Ex1) + Ex2;
-                        const double a = Ex0 * Ex0, b = Ex1 * Ex1, c = Et0 * Et0, d = Et1 * Et1;
-                        const double num = x2tEx1 * x2tEx1, den = ((a + b) + c) + d;
-                        int in;
-                        if (den > 0 && num <= kLo * den) in = 1;
-                        else if (num >= kHi * den) in = 0;
-                        else in = (float)(num / den) <= thr2 ? 1 : 0;
-                        good += in;
-                    }
+                    for (int i = q0; i < q1; i++) good += decide(Em, sP[i], tc, c0, i);
                     if (t < T && good) atomicAdd(&sGood[t], good);
                 }
-            } else
-            for (int t = wv; t < T; t += 4) {
-                double Em[9];
+            }
+          }
+        } else if (T > 0) {
+            // Thousands of correspondences (BASELINE config 3: RANSAC on ~3100 symmetric matches): LANE = up to four points held in
+            // registers (straight from global memory: no staging, no barrier), every thread walks ALL models of the sub-item (three
+            // broadcast LDS reads per model); a model's count over the wave is one ballot + population count per point instead of a
+            // wave reduction per (model, chunk).  The ceil(M / 256) rows of 256 points are dealt evenly over ceil(rows / 4) rounds
+            // (M = 3100: 13 rows as 4 + 3 + 3 + 3, not 4 + 4 + 4 + 1).  What single precision cannot decide goes on a list
+            // (model << 16 | point) and counts as "out" in the loop; ALL threads settle the list in double precision afterwards.
+            if (tid == 0) sNamb = 0;
+            __syncthreads();
+            auto defer = [&](int t, int gi) {                      // rare: a list entry; with a full list (never seen) decided in place
+                const int slot = atomicAdd(&sNamb, 1);
+                if (slot < AMB_CAP) { sAmb[slot] = ((uint32_t)t << 16) | (uint32_t)gi; return; }
+                const int tag = sTag[t];
+                if (sampson_in_f64(mbase + (size_t)(tag >> 4) * 90 + 9 * (tag & 15), pa[2 * gi], pa[2 * gi + 1], pb[2 * gi], pb[2 * gi + 1], kLo, kHi, thr2))
+                    atomicAdd(&sGood[t], 1);
+            };
+            auto round_of = [&](auto ppl_tag, int g0, int mc) {    // PPL rows of 256 points starting at point g0, mc points in all
+                constexpr int PPL = decltype(ppl_tag)::value;
+                ScorePt Q[PPL]; unsigned long long mv[PPL]; bool vq[PPL];
 #pragma unroll
-                for (int k = 0; k < 9; k++) Em[k] = sE[t][k];
-                int good = 0;
-                for (int i = lane; i < mc; i += 64) {
-                    const double x1 = sX1[i], y1 = sY1[i], x2 = sX2[i], y2 = sY2[i];
-                    const double Ex0 = (Em[0] * x1 + Em[1] * y1) + Em[2];
-                    const double Ex1 = (Em[3] * x1 + Em[4] * y1) + Em[5];
-                    const double Ex2 = (Em[6] * x1 + Em[7] * y1) + Em[8];
-                    const double Et0 = (Em[0] * x2 + Em[3] * y2) + Em[6];
-                    const double Et1 = (Em[1] * x2 + Em[4] * y2) + Em[7];
-                    const double x2tEx1 = (x2 * Ex0 + y2 * Ex1) + Ex2;
-                    const double a = Ex0 * Ex0, b = Ex1 * Ex1, c = Et0 * Et0, d = Et1 * Et1;
-                    const double num = x2tEx1 * x2tEx1, den = ((a + b) + c) + d;
-                    int in;
-                    if (den > 0 && num <= kLo * den) in = 1;
-                    else if (num >= kHi * den) in = 0;
-                    else in = (float)(num / den) <= thr2 ? 1 : 0;
-                    good += in;
+                for (int k = 0; k < PPL; k++) {
+                    vq[k] = tid + 256 * k < mc;
+                    Q[k] = make_pt(g0 + (vq[k] ? tid + 256 * k : 0));
+                    mv[k] = __builtin_amdgcn_ballot_w64(vq[k]);
                 }
-                good += __builtin_amdgcn_update_dpp(0, good, 0xB1, 0xF, 0xF, false);
-                good += __builtin_amdgcn_update_dpp(0, good, 0x4E, 0xF, 0xF, false);
-                good += __builtin_amdgcn_update_dpp(0, good, 0x141, 0xF, 0xF, false);
-                good += __builtin_amdgcn_update_dpp(0, good, 0x140, 0xF, 0xF, false);
-                good = __builtin_amdgcn_readlane(good, 0) + __builtin_amdgcn_readlane(good, 16) +
-                       __builtin_amdgcn_readlane(good, 32) + __builtin_amdgcn_readlane(good, 48);
-                if (lane == 0) sGood[t] += good;
+                for (int t = 0; t < T; t++) {
+                    const float4 r0 = *reinterpret_cast<const float4*>(&sE[t][0]), r1 = *reinterpret_cast<const float4*>(&sE[t][4]);
+                    const float Em[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, sE[t][8]};
+                    int in[PPL]; unsigned long long und = 0; int cnt = 0;
+#pragma unroll
+                    for (int k = 0; k < PPL; k++) {                // branch-free; lanes without a point are masked out of the ballots
+                        in[k] = sampson_in_f32(Em, Q[k], tlo, thi);
+                        und |= __builtin_amdgcn_ballot_w64(in[k] < 0) & mv[k];
+                        cnt += __popcll(__builtin_amdgcn_ballot_w64(in[k] > 0) & mv[k]);
+                    }
+                    if (__builtin_expect(und != 0, 0)) {           // wave-uniform
+#pragma unroll
+                        for (int k = 0; k < PPL; k++) if (in[k] < 0 && vq[k]) defer(t, g0 + tid + 256 * k);
+                    }
+                    if (lane == 0 && cnt) atomicAdd(&sGood[t], cnt);
+                }
+            };
+            const int rows = (M + 255) >> 8, rounds = (rows + 3) >> 2, rbase = rows / rounds, rrem = rows - rbase * rounds;
+            int g0 = 0;
+            for (int r = 0; r < rounds; r++) {
+                const int nr = rbase + (r < rrem ? 1 : 0), mc = min(M - g0, nr * 256);
+                if (nr == 4) round_of(std::integral_constant<int, 4>{}, g0, mc);
+                else if (nr == 3) round_of(std::integral_constant<int, 3>{}, g0, mc);
+                else if (nr == 2) round_of(std::integral_constant<int, 2>{}, g0, mc);
+                else round_of(std::integral_constant<int, 1>{}, g0, mc);
+                g0 += nr * 256;
+            }
+            __syncthreads();
+            const int na = min(sNamb, AMB_CAP);
+            for (int a = tid; a < na; a += 256) {
+                const uint32_t code = sAmb[a];
+                const int t = (int)(code >> 16), gi = (int)(code & 0xFFFFu), tag = sTag[t];
+                if (sampson_in_f64(mbase + (size_t)(tag >> 4) * 90 + 9 * (tag & 15), pa[2 * gi], pa[2 * gi + 1], pb[2 * gi], pb[2 * gi + 1], kLo, kHi, thr2))
+                    atomicAdd(&sGood[t], 1);
             }
         }
         __syncthreads();
