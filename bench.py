@@ -533,14 +533,18 @@ def main():
                      "valu_frac_of_half_rate_ceiling": vi / t / peaks["half_rate_class"],
                      "valu_frac_of_full_rate_ceiling": vi / t / peaks["full_rate_class"],
                      "salu_wave_insts": (r.get("salu_wave_insts_per_launch") or 0) * scale * calls,
-                     "lds_bank_conflict_cycles": (r.get("lds_bank_conflict_cycles") or 0) * scale * calls}
+                     "lds_bank_conflict_cycles": (r.get("lds_bank_conflict_cycles") or 0) * scale * calls,
+                     # fraction of the launch during which a CU's LDS array is busy (SQ_LDS_IDX_ACTIVE / CU-cycles of the counter run)
+                     "lds_busy_frac": r.get("lds_busy_frac")}
                 if ab is not None:
                     d["algorithmic_bytes"] = ab * B
                     d["hbm_frac"] = ab * B / t / 1e9 / HBM_PEAK_GBS
                     d["traffic_over_algorithmic"] = hbm / (ab * B)
                 # what the counters say limits the kernel: the larger of (HBM traffic / peak) and (VALU issue / measured ceiling of
-                # the half-rate class, the class most of these kernels' instructions belong to)
+                # the half-rate class, the class most of these kernels' instructions belong to) -- or the LDS array, when that is busier
                 d["limited_by"] = "valu-issue" if d["valu_frac_of_half_rate_ceiling"] > d["hbm_traffic_frac"] else "hbm"
+                if (d["lds_busy_frac"] or 0) > max(d["valu_frac_of_half_rate_ceiling"], d["hbm_traffic_frac"]):
+                    d["limited_by"] = "lds"                        # round 4: k_describe's LDS array is busy 90+ % of the launch, 59 % of that bank conflicts of the sample gathers
                 detect_kernels[kn] = d
             dk = detect_kernels[kname]
             traffic = pj[kname]["hbm_bytes_per_launch"] * scale

@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-legs > $R/$OUT/bench_under_rocprof.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_legs -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/$OUT/bench_legs_under_rocprof.log 2>&1
 export VIS_PROFILE_BATCH=512 VIS_PROFILE_STEPS=3 VIS_PROFILE_WARM=2
-for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum SQ_INSTS_VALU_MFMA_MOPS_F6F4 SQ_VALU_MFMA_BUSY_CYCLES"; do
+for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum SQ_INSTS_VALU_MFMA_MOPS_F6F4 SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_I8"; do
   n=$(echo $c | cut -d' ' -f1)
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/pipe/pass_$n -- python3 $R/tools/profile_workload.py > $R/$OUT/pipe_$n.log 2>&1
 done

@@ -60,5 +60,10 @@ for k in ("k_fast", "k_resize", "k_describe", "k_knn2", "k_knn_mfma", "k_expand"
             res[k]["lds_bank_conflict_cycles"] = sq.get("SQ_LDS_BANK_CONFLICT", {}).get("mean")
             res[k]["salu_wave_insts_per_launch"] = sq.get("SQ_INSTS_SALU", {}).get("mean")
             res[k]["launches_counted"] = sq["SQ_INSTS_VALU"]["calls"]
+        if "SQ_LDS_IDX_ACTIVE" in sq and "SQ_BUSY_CYCLES" in sq:
+            # SQ_LDS_IDX_ACTIVE: LDS-array cycles summed over the 256 CUs; SQ_BUSY_CYCLES: kernel cycles summed over the 32 shader engines
+            # (8 CUs each) -> the fraction of the launch during which a CU's LDS array is busy
+            res[k]["lds_idx_active_cycles"] = sq["SQ_LDS_IDX_ACTIVE"]["mean"]
+            res[k]["lds_busy_frac"] = sq["SQ_LDS_IDX_ACTIVE"]["mean"] / (sq["SQ_BUSY_CYCLES"]["mean"] * 8.0)
 json.dump(res, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "raw"}, indent=1))
