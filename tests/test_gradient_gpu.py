@@ -23,7 +23,7 @@ def test_gradient_s752(vislam, orc, ctx, canvas):
 
 
 @pytest.mark.parametrize("w,h", [(64, 48), (96, 32), (160, 112), (1920, 1088), (3840, 2160),
-                                 (1920, 1080), (137, 135), (150, 110), (333, 61)])       # sizes that do not halve exactly: 1080 -> .. 135 -> 68 rows
+                                 (1920, 1080), (137, 135), (150, 110), (333, 61), (160, 118), (64, 50), (48, 34)])       # sizes that do not halve exactly: 1080 -> .. 135 -> 68 rows; width % 16 == 0 with any height: k_half_all + k_half4 for the rows below the last complete block row
 def test_gradient_sizes(vislam, orc, ctx, canvas, w, h):
     # 64x48: level 4 is 4x3 (narrower than one thread's 8 pixels); 1920x1088: levels of every alignment class
     if w > 2048:        # the 4K configuration: textured random image (the 4096^2 fixture canvas is too small to crop it at t = 3)

@@ -261,9 +261,12 @@ static __device__ __forceinline__ uint32_t box_rows(uint32_t a, uint32_t b) {   
     const uint32_t M = 0x00FF00FFu;
     return ((((a & M) + ((a >> 8) & M)) + ((b & M) + ((b >> 8) & M)) + 0x00020002u) >> 2) & M;
 }
-__global__ __launch_bounds__(256) void k_half_all(const uint8_t* __restrict__ src, int w, int h, int sstride, size_t sframe,
+// `h` only places the levels inside a frame record (their heights are vis_half_dims'); the rows worked on are the 16 * byn rows of
+// complete 16 x 16 blocks -- when h is not a multiple of 16 (1080 = 16 * 67 + 8) the launcher finishes the rest with k_half4.
+struct HalfLevels { size_t o1, o2, o3, o4; int byn; };
+__global__ __launch_bounds__(256) void k_half_all(const uint8_t* __restrict__ src, int w, HalfLevels HL, int sstride, size_t sframe,
                                                   uint8_t* __restrict__ dst, size_t dframe, int nframes) {
-    const int bxn = w >> 4, byn = h >> 4;
+    const int bxn = w >> 4, byn = HL.byn;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int f = blockIdx.y;
     if (f >= nframes || idx >= bxn * byn) return;
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(256) void k_half_all(const uint8_t* __restrict__ sr
         const uint4 b = *reinterpret_cast<const uint4*>(s0 + (size_t)(2 * r + 1) * sstride);
         L1[r][0] = box_rows(a.x, b.x); L1[r][1] = box_rows(a.y, b.y); L1[r][2] = box_rows(a.z, b.z); L1[r][3] = box_rows(a.w, b.w);
     }
-    const size_t o1 = (size_t)w * h, o2 = o1 + (size_t)(w >> 1) * (h >> 1), o3 = o2 + (size_t)(w >> 2) * (h >> 2), o4 = o3 + (size_t)(w >> 3) * (h >> 3);
+    const size_t o1 = HL.o1, o2 = HL.o2, o3 = HL.o3, o4 = HL.o4;
     {   // store level 1: 8 rows x 8 bytes (fields -> bytes: v_perm picks bytes 0 and 2 of two field dwords)
         const int w1 = w >> 1;
         uint8_t* p = d + o1 + (size_t)(8 * by) * w1 + 8 * bx;
@@ -327,24 +330,32 @@ __global__ __launch_bounds__(256) void k_half_all(const uint8_t* __restrict__ sr
 int launch_half_pyramid_batch(vis_ctx* ctx, const uint8_t* d_frames, int w, int h, int stride, size_t frame_bytes, int n,
                               uint8_t* d_pyr) {
     const size_t fe = vis_grad_frame_elems(w, h);
-    if (!(w & 15) && !(h & 15) && !(stride & 15) && !(frame_bytes & 15) && !((uintptr_t)d_frames & 15) && !((uintptr_t)d_pyr & 15) && !(fe & 15)) {
-        const int blocks = (w >> 4) * (h >> 4);
-        hipLaunchKernelGGL(k_half_all, dim3((blocks + 255) / 256, n), dim3(256), 0, ctx->stream, d_frames, w, h, stride, frame_bytes, d_pyr, fe, n);
-        HIPCHK(ctx, hipGetLastError());
-        return VIS_OK;
-    }
     int lw[5], lh[5]; vis_half_dims(w, h, lw, lh);
-    size_t off = 0;
-    for (int l = 1; l < 5; l++) {
-        const int sw = lw[l - 1], sh = lh[l - 1], dw = lw[l], dh = lh[l];
-        if (dw < 1 || dh < 1) return VIS_E_INVALID;
-        const uint8_t* src = l == 1 ? d_frames : d_pyr + off;
-        const int ss = l == 1 ? stride : sw;
-        const size_t sf = l == 1 ? frame_bytes : fe;
-        off += (size_t)sw * sh;
-        const int items = ((dw + 3) / 4) * dh;
-        hipLaunchKernelGGL(k_half4, dim3((items + 255) / 256, n), dim3(256), 0, ctx->stream, src, sw, sh, ss, sf, d_pyr + off, dw, dh, fe, n);
+    size_t loff[5]; loff[0] = 0;
+    for (int l = 1; l < 5; l++) loff[l] = loff[l - 1] + (size_t)lw[l - 1] * lh[l - 1];
+    // rows [0, 16 * byn): all four levels in one pass when the WIDTH halves exactly four times and everything is 16-byte aligned
+    // (1920 x 1080: 67 of 67.5 block rows); the rows below, or everything when that does not hold, level by level with partial blocks
+    int row0 = 0;
+    if (!(w & 15) && h >= 16 && !(stride & 15) && !(frame_bytes & 15) && !((uintptr_t)d_frames & 15) && !((uintptr_t)d_pyr & 15) && !(fe & 15) &&
+        !(loff[1] & 7) && !(loff[2] & 3) && !(loff[3] & 1)) {
+        HalfLevels HL; HL.o1 = loff[1]; HL.o2 = loff[2]; HL.o3 = loff[3]; HL.o4 = loff[4]; HL.byn = h >> 4;
+        const int blocks = (w >> 4) * HL.byn;
+        hipLaunchKernelGGL(k_half_all, dim3((blocks + 255) / 256, n), dim3(256), 0, ctx->stream, d_frames, w, HL, stride, frame_bytes, d_pyr, fe, n);
+        row0 = 16 * HL.byn;
     }
+    if (row0 < h)
+        for (int l = 1; l < 5; l++) {
+            const int sw = lw[l - 1], sh = lh[l - 1], dw = lw[l], dh = lh[l];
+            if (dw < 1 || dh < 1) return VIS_E_INVALID;
+            const int sr0 = row0 >> (l - 1), dr0 = row0 >> l;                // first source / destination row still to do (row0 is a multiple of 16)
+            if (dr0 >= dh) continue;
+            const uint8_t* src = (l == 1 ? d_frames : d_pyr + loff[l - 1]) + (size_t)sr0 * (l == 1 ? stride : sw);
+            const int ss = l == 1 ? stride : sw;
+            const size_t sf = l == 1 ? frame_bytes : fe;
+            const int items = ((dw + 3) / 4) * (dh - dr0);
+            hipLaunchKernelGGL(k_half4, dim3((items + 255) / 256, n), dim3(256), 0, ctx->stream, src, sw, sh - sr0, ss, sf,
+                               d_pyr + loff[l] + (size_t)dr0 * dw, dw, dh - dr0, fe, n);
+        }
     HIPCHK(ctx, hipGetLastError());
     return VIS_OK;
 }
