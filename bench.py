@@ -7,7 +7,8 @@ under torch.distributed.run, one rank per GPU.  One JSON line on rank 0.
 Headline workload (BASELINE.json configs[1]): synthetic 752x480 mono8 EuRoC-shaped stream ("S-752", integer-only
 generator, vi-slam_amd/csrc/synth_core.h), ORB 1000 keypoints x 8 levels, BF-Hamming k=2 both directions +
 ratio/symmetry/grid filter, essential RANSAC + recoverPose.  A "step" = one pass of the whole hot path over one batch of
-B consecutive frames that are already resident in HBM.
+4096 consecutive frames that are already resident in HBM, as 4 launches of 1024 frames (the plan's device buffers are sized
+for 1024; `kernels_ms_per_step`, `roofline` and the counter figures are PER LAUNCH of 1024 frames).
 Multi-GPU (configs[3]): rank r processes its own stream (seed + r); the only collective is one broadcast of the
 parameter/intrinsics struct from rank 0 (RCCL); scaling is weak.
 
@@ -78,9 +79,11 @@ class Stream:
         return self.frames[:n].cpu().numpy()
 
 
-def timed_steps(ctx, stream, B, R, stages, steps, warmup, dist=None, dev=None, after_step=None):
+def timed_steps(ctx, stream, B, R, stages, steps, warmup, dist=None, dev=None, after_step=None, q=1):
+    """a step = q consecutive launches of the pipeline over q * B consecutive frames of the stream (q = 1 for the legs)"""
     def step(i):
-        ctx.batch_run(stream.ptr((i % R) * B), B, stages)
+        for s_ in range(q):
+            ctx.batch_run(stream.ptr(((i % R) * q + s_) * B), B, stages)
         if after_step is not None:
             after_step(i)
     for i in range(warmup):
@@ -254,8 +257,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)   # 200 x 3.7 ms: a timed region long enough for an outside observer (rocm-smi) to see
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1024, help="frames per step (per GPU)")
-    ap.add_argument("--ring", type=int, default=2, help="distinct batches resident in HBM")
+    ap.add_argument("--batch", type=int, default=1024, help="frames per LAUNCH of the pipeline (the plan's device buffers are sized for it)")
+    ap.add_argument("--launches-per-step", type=int, default=4,
+                    help="a step = this many consecutive launches over consecutive frames of the stream (4 x 1024 = 4096 frames per step): the driver's "
+                         "--steps 20 is then 80 launches (0.2 s) instead of 20 (55 ms, 2-3 of which fill and drain the three-stage pipeline)")
+    ap.add_argument("--ring", type=int, default=2, help="distinct steps' worth of frames resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the side legs (profiling runs)")
     ap.add_argument("--stages", type=int, default=vislam.STAGE_FRAME, help="debug: bitmask of stages (1 detect, 2 match, 4 pose, 8 Camera::Update); the reported metric needs all 15")
@@ -283,13 +289,15 @@ def main():
     p = vdist.broadcast_params(p, dist, dev, rank)
 
     ctx = vislam.Context(local_rank if world > 1 else 0, p)
-    B, R = a.batch, a.ring
+    B, R, Q = a.batch, a.ring, max(1, a.launches_per_step)
     seed = vdist.stream_seed(rank, world)
-    stream = Stream(ctx, dev, W, H, B * R, seed)          # generated on the device: no host synthesis, no H2D
+    stream = Stream(ctx, dev, W, H, B * Q * R, seed)      # generated on the device: no host synthesis, no H2D
     ctx.batch_plan(W, H, W, B)
-    dt, step = timed_steps(ctx, stream, B, R, a.stages, a.steps, a.warmup, dist, dev)
+    dt, step_q = timed_steps(ctx, stream, B, R, a.stages, a.steps, a.warmup, dist, dev, q=Q)
     dt = vdist.max_over_ranks(dt, dist, dev)
 
+    def step(i):                                          # ONE launch (per-kernel timings, pose load: per launch of B frames)
+        ctx.batch_run(stream.ptr((i % (R * Q)) * B), B, a.stages)
     fam, launches_fast = family_times(ctx, step, 8)
     tau_next, redone = ctx.batch_fast_thresholds()       # the speculative FAST thresholds (exact by construction; see include/vislam_hip.h)
     headline_pose = None
@@ -558,7 +566,7 @@ def main():
                             "times from this run; a kernel made of both instruction classes sits between the two measured ceilings"}
         except Exception as e:                                  # loud: the record says what is missing
             valu = {"error": f"profiles/pmc_traffic.json unusable: {e!r}"}
-        fps = vdist.aggregate_fps(world, a.steps, B, dt)
+        fps = vdist.aggregate_fps(world, a.steps, B * Q, dt)
         out = {
             "metric": "frames/sec detect+match+pose, 752x480 mono8", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -572,7 +580,8 @@ def main():
                                    "FAST runs at a per-level threshold predicted from the previous batch's retainBest cuts (a corner below the cut "
                                    "is neither kept nor able to suppress a kept one), verified per (frame, level) on the device, mispredictions redone "
                                    "at fast_threshold inside the step: keypoints identical to FAST at 20 for every input (fast_threshold_prediction)",
-                       "frames_per_step_per_gpu": B, "parallelism": f"stream-per-gpu x{world}" if world > 1 else "single-gpu"},
+                       "frames_per_step_per_gpu": B * Q, "launches_per_step": Q, "frames_per_launch": B,
+                       "parallelism": f"stream-per-gpu x{world}" if world > 1 else "single-gpu"},
             # `bound` names the roofline `frac` is priced against (north_star asks for the HBM roofline of detect/describe);
             # `limited_by` is what the counters say actually limits this kernel (see valu_roofline / detect_kernels)
             "roofline": {"bound": "hbm", "limited_by": limited_by, "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -588,7 +597,8 @@ def main():
             "pose_load": headline_pose,
             "aux_kernels": aux,
             "legs": legs,
-            "kernels_ms_per_step": {k: round(v, 4) for k, v in fam.items()},
+            "kernels_ms_per_step": {k: round(v, 4) for k, v in fam.items()},       # per LAUNCH of frames_per_launch frames (one batch in flight)
+            "kernels_ms_per_launch": {k: round(v, 4) for k, v in fam.items()},
             "detect_describe_GBps": alg["total_detect_describe"] * B / ((fam["ms_pyramid"] + fam["ms_fast"] + fam["ms_select"] + fam["ms_describe"]) * 1e-3) / 1e9,
         }
         if host_frames is not None:
