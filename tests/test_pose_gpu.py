@@ -181,3 +181,26 @@ def test_recycled_device_memory_does_not_leak_into_results(vislam, orc, canvas):
         pose = c.batch_pose(t)
         assert pose["n_inliers"] == r.n_inliers and pose["iters_run"] == r.iters_run
     c.close()
+
+
+@pytest.mark.parametrize("m,thr,fx,noise,adaptive", [(300, 1.0, 458.654, 1.0, 1), (1000, 0.25, 458.654, 0.3, 1), (3000, 1.0, 150.0, 1.0, 1),
+                                                     (3000, 3.0, 458.654, 3.0, 0), (5000, 1.0, 458.654, 0.7, 1), (2049, 0.5, 90.0, 0.5, 0)])
+def test_many_correspondences_single_precision_scoring(vislam, orc, ctx, m, thr, fx, noise, adaptive):
+    """k_hyp_score's many-correspondences form decides the Sampson test in single precision where its error radii allow and in the oracle's
+    double sequence elsewhere (pose.hip).  Pixel noise of the size of the threshold puts thousands of residuals next to it; a short
+    focal length makes the normalised coordinates (and the radii) large; 2049 points exercise the row dealing (9 rows as 3 + 3 + 3).
+    Masks, counts and iteration numbers must be the oracle's, E within the stated tolerance."""
+    p = vislam.default_params()
+    p.fx = p.fy = fx
+    p.ransac_threshold, p.ransac_adaptive, p.ransac_max_iters = thr, adaptive, 400
+    ctx.set_params(p)
+    rng = np.random.default_rng(m + int(10 * thr))
+    x1, x2, R, t = two_view(m, 100 + m, 0.35, 0.0)
+    x2 = (x2 + rng.normal(0, noise, x2.shape)).astype(np.float32)
+    E, mask, ninl, iters = ctx.essential_ransac(x1, x2)
+    oE, omask, oninl, oiters = orc.essential_ransac(p, x1, x2)
+    assert (ninl, iters) == (oninl, oiters)
+    assert (mask == omask).all()
+    assert 100 < oninl < 0.95 * m                            # the threshold really cuts through the residual distribution (the short focal
+                                                             # lengths do not match the K the points were projected with: few inliers, large coordinates)
+    assert _cmpE(E, oE) <= TOL
