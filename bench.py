@@ -552,7 +552,11 @@ def main():
                 # the half-rate class, the class most of these kernels' instructions belong to) -- or the LDS array, when that is busier
                 d["limited_by"] = "valu-issue" if d["valu_frac_of_half_rate_ceiling"] > d["hbm_traffic_frac"] else "hbm"
                 if (d["lds_busy_frac"] or 0) > max(d["valu_frac_of_half_rate_ceiling"], d["hbm_traffic_frac"]):
-                    d["limited_by"] = "lds"                        # round 4: k_describe's LDS array is busy 90+ % of the launch, 59 % of that bank conflicts of the sample gathers
+                    d["limited_by"] = "lds"
+                elif (d["lds_busy_frac"] or 0) >= 0.85 and d["limited_by"] == "valu-issue":
+                    # round 4: k_describe's LDS array is busy ~90 % of the launch (57 % of that bank conflicts of the sample gathers) while vector
+                    # issue sits at its half-rate ceiling: removing a fifth of its vector instructions moved it by 2 %
+                    d["limited_by"] = "lds + valu-issue"
                 detect_kernels[kn] = d
             dk = detect_kernels[kname]
             traffic = pj[kname]["hbm_bytes_per_launch"] * scale
