@@ -792,3 +792,49 @@ def test_half_pyramid_against_a_numpy_restatement_at_odd_sizes(orc):
             assert got[l].shape == (nh, nw), (h, w, l)
             assert np.array_equal(got[l], cur.astype(np.uint8)), (h, w, l)
             prev = cur
+
+
+def test_single_precision_sampson_error_radii_hold():
+    """vi-slam_amd/csrc/pose.hip decides the Sampson test in single precision inside rigorous error radii (|s32 - s| < 40 u R1 R2,
+    |den32 - den| < 160 u R^2 for ||E||_F = 1, u = 2^-24, R = max(|x|, |y|, 1); the kernel uses 64 u and 256 u) and in the oracle's double
+    sequence otherwise.  This replays the kernel's operation order in numpy float32 (each fmaf as an exactly-rounded a*b + c: the product
+    of two floats is exact in float64, the double rounding is at most one float ulp of slack inside a 1.6x margin) on two million random
+    (model, point) pairs -- unit-norm E, coordinates up to |4| like the image corners of a short focal length -- against float64, and
+    checks that no pair ever leaves the radii the kernel assumes, and that the "certainly in / certainly out" decisions never contradict
+    the double-precision rule."""
+    rng = np.random.default_rng(2024)
+    n = 2_000_000
+    E = rng.normal(0, 1, (n, 9)); E /= np.linalg.norm(E, axis=1, keepdims=True)
+    scale = rng.choice([0.3, 1.0, 4.0], n)[:, None]
+    P = rng.uniform(-1, 1, (n, 4)) * scale                       # x1 y1 x2 y2 (double, as k_pose_prep leaves them)
+    # make a good share of the pairs near-inliers so that s is small against its terms (the cancellation the radii must cover)
+    f32 = np.float32
+    def fma(a, b, c):
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(f32)
+    e = [E[:, k].astype(f32) for k in range(9)]
+    x1, y1, x2, y2 = (P[:, k].astype(f32) for k in range(4))
+    ex0 = fma(e[0], x1, fma(e[1], y1, e[2])); ex1 = fma(e[3], x1, fma(e[4], y1, e[5])); ex2 = fma(e[6], x1, fma(e[7], y1, e[8]))
+    et0 = fma(e[0], x2, fma(e[3], y2, e[6])); et1 = fma(e[1], x2, fma(e[4], y2, e[7]))
+    s32 = np.abs(fma(x2, ex0, fma(y2, ex1, ex2)))
+    den32 = fma(ex0, ex0, fma(ex1, ex1, fma(et0, et0, (et1.astype(np.float64) * et1.astype(np.float64)).astype(f32))))
+    X1, Y1, X2, Y2 = P[:, 0], P[:, 1], P[:, 2], P[:, 3]
+    Ex0 = E[:, 0] * X1 + E[:, 1] * Y1 + E[:, 2]; Ex1 = E[:, 3] * X1 + E[:, 4] * Y1 + E[:, 5]; Ex2 = E[:, 6] * X1 + E[:, 7] * Y1 + E[:, 8]
+    Et0 = E[:, 0] * X2 + E[:, 3] * Y2 + E[:, 6]; Et1 = E[:, 1] * X2 + E[:, 4] * Y2 + E[:, 7]
+    s = np.abs(X2 * Ex0 + Y2 * Ex1 + Ex2); den = Ex0 ** 2 + Ex1 ** 2 + Et0 ** 2 + Et1 ** 2
+    u = 2.0 ** -24
+    R1 = np.maximum(np.maximum(np.abs(X1), np.abs(Y1)), 1.0); R2 = np.maximum(np.maximum(np.abs(X2), np.abs(Y2)), 1.0)
+    Rm = np.maximum(R1, R2)
+    rs = np.abs(s32.astype(np.float64) - s) / (u * R1 * R2); rd = np.abs(den32.astype(np.float64) - den) / (u * Rm * Rm)
+    assert rs.max() < 40 and rd.max() < 160, (rs.max(), rd.max())   # the derived bounds (the kernel's radii are 64 and 256)
+    # decisions with the kernel's radii and margins against the double rule num / den <= tmid
+    for thr in (1.0 / 458.654, 0.25 / 458.654, 3.0 / 150.0):
+        thr2 = f32(thr * thr)
+        tmid = 0.5 * (float(thr2) + float(np.nextafter(thr2, f32(np.inf))))
+        tlo, thi = f32(tmid * (1 - 2.0 ** -16)), f32(tmid * (1 + 2.0 ** -16))
+        es = (64 * u * R1 * R2 * 1.000002).astype(f32); ed = (256 * u * Rm * Rm * 1.000002).astype(f32)
+        hi, lo = s32 + es, s32 - es
+        sure_in = hi * hi <= tlo * (den32 - ed)
+        sure_out = (lo > 0) & (lo * lo >= thi * (den32 + ed))
+        truth = (s * s) <= tmid * den
+        assert not (sure_in & ~truth).any() and not (sure_out & truth).any(), thr
+        assert (sure_in | sure_out).mean() > 0.97                     # and single precision does decide nearly everything

@@ -399,11 +399,12 @@ static int grow_single(vis_ctx* ctx, int capacity) {
     Plan* old = ctx->single;
     if (!old) return VIS_E_STATE;
     sync_all(ctx);
+    const int cap_before = ctx->p.keypoint_capacity;
     ctx->p.keypoint_capacity = capacity;
     Plan* np = nullptr;
     int rc = plan_create(ctx, old->w, old->h, old->stride, 1, VIS_NSLOTS, 1, &np);
-    if (rc) return rc;
-    if (np->kcap < old->kcap || np->nrec != old->nrec) { plan_destroy(np); return VIS_E_STATE; }
+    if (rc == VIS_OK && (np->kcap < old->kcap || np->nrec != old->nrec)) { plan_destroy(np); rc = VIS_E_STATE; }
+    if (rc) { ctx->p.keypoint_capacity = cap_before; return rc; }       // (the old plan and its slots stay as they were)
     std::vector<int32_t> nk((size_t)old->nrec);
     HIPCHK(ctx, hipMemcpy(nk.data(), old->d_nkp, nk.size() * 4, hipMemcpyDeviceToHost));
     HIPCHK(ctx, hipMemcpy(np->d_nkp, nk.data(), nk.size() * 4, hipMemcpyHostToDevice));
