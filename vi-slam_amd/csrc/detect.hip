@@ -13,10 +13,12 @@
 //   k_select   (1 launch)        block per (frame,level): 256-bin score histogram = retainBest(2*quota) cut,
 //                                Harris on survivors, LDS bitonic sort by (response desc, y, x) = canonical order,
 //                                retainBest(quota)
-//   k_describe (1 launch)        wave per keypoint: 43x43 raw patch -> LDS, IC angle, 7-tap fixed-point blur
-//                                evaluated only where rBRIEF samples, 256 tests packed with wave ballots
+//   k_describe (1 launch)        a wave walks over keypoints (software pipeline: the next keypoint's record and patch are in flight):
+//                                43x43 raw patch -> LDS, IC angle, 7-tap blur rows on the matrix pipe (v_mfma_i32_16x16x64_i8, exact),
+//                                blur columns only where rBRIEF samples, 256 tests packed with wave ballots
 // HBM traffic model: every pyramid pixel is read once by k_fast and once as the
-// next level's resize source; candidates/keypoints are O(N) and tiny.  All kernels are bound by vector-ALU issue.
+// next level's resize source; candidates/keypoints are O(N) and tiny.  k_resize streams at 84 % of the copy ceiling; k_fast is a chain of
+// latency-bound phases with vector + scalar issue saturated; k_describe is bound by the LDS array with vector issue right behind it.
 #include "vis_internal.h"
 #include <cfloat>
 #include <cmath>
