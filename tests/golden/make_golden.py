@@ -85,7 +85,19 @@ def main():
         d[f"cand_{l}"] = c["cand"][l]
     np.savez_compressed(os.path.join(HERE, "align_320x240.npz"), iterations=np.array(list(r.iterations)), n_residuals=np.array(list(r.n_residuals)),
                         error=np.array(r.error, np.float32), pose=r.pose.as_array(), matrix=np.array(r.matrix, np.float32), **d)
+    half_odd(cv)
     print("golden fixtures written:", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
+
+
+def half_odd(cv):
+    """Camera::Update + Camera::computeGradient on a size that does not halve exactly (150 x 110 -> 75 x 55 -> 38 x 28 -> 19 x 14 -> 10 x 7:
+    75 -> 37.5 -> 38 and 19 -> 9.5 -> 10 round half to even upwards, 55 -> 27.5 -> 28): level sizes, the levels, the level-4 gradients"""
+    f = np.ascontiguousarray(vislam.synth_frame(cv, 9, 160, 120, 123)[:110, :150])
+    lw, lh = orc.half_pyramid_dims(150, 110)
+    lv = orc.half_pyramid(f)
+    gx4, gy4, g4 = orc.scharr_gradient(lv[4], 3)
+    np.savez_compressed(os.path.join(HERE, "half_150x110.npz"), img=f, lw=np.array(lw), lh=np.array(lh),
+                        levels=np.concatenate([l.ravel() for l in lv[1:]]), gx4=gx4, gy4=gy4, g4=g4)
 
 
 if __name__ == "__main__":
