@@ -11,8 +11,10 @@
 // everything expensive (minimal solver, M Sampson errors per model) is independent per hypothesis:
 //   k_pose_prep    block/pair : normalise points, copy (or replay) the cv::RNG sample table
 //   k_ransac_hyp   lane/hypothesis : minimal solver up to the degree-10 polynomial -> hypothesis record
-//   k_hyp_roots    16 lanes/hypothesis : real roots, one bisection interval per lane
-//   k_hyp_score    256 threads/16 hypotheses : back-substitution (<=10 E each) + inlier counts of every E
+//   k_hyp_roots    16 lanes/hypothesis : real roots, one bisection interval per lane (a handful of pairs: latency)
+//   k_hyp_roots_packed  wave/64 hypotheses : the same, the intervals of a level packed over the lanes (batches: throughput)
+//   k_hyp_models   lane/hypothesis : back-substitution, <= 10 candidate E per hypothesis
+//   k_hyp_score    256 threads/16 hypotheses : inlier counts of every E (single precision inside error radii, double otherwise)
 //   k_ransac_scan  wave/pair : replays RANSACPointSetRegistrator::run's accept/update rule in order
 //   k_pose_final   block/pair : inlier mask of the winner, SVD, 4x M DLT triangulations, cheirality vote
 // The first 16 hypotheses of every pair are evaluated and scanned first; later chunks run only for the pairs whose
@@ -719,75 +721,142 @@ __global__ __launch_bounds__(256) void k_hyp_roots(PoseParams P, int h0, int h_e
     }
 }
 
-// ---- the same root finder with ONE HYPOTHESIS PER LANE, for the work-list chunks (hundreds of hypotheses per pair: throughput
-// matters, not latency).  With 16 lanes per polynomial every level costs its 40 bisection steps whatever the number of
-// sign-change intervals, and most of the 16 lanes idle; here a wave walks the intervals j = 0, 1, .. of a level for 64
-// polynomials at once and skips an interval no lane needs.  Same arithmetic per interval (oracle/pose.cpp real_roots).  The
-// previous level's roots live in LDS ([root][lane]); interval j reads root j before anything of this level can overwrite it
-// (at most j roots have been stored by then), so one buffer serves both levels.
-template <int D>
-DEV void roots_level_lane(const double (&c)[11], double B, double (*prev)[64], int lane, int& nprev) {
-    constexpr int K = 10 - D;
-    double q[D + 1];
+// ---- the same root finder with ONE HYPOTHESIS PER LANE for the owner's part and the sign-change intervals of a level PACKED over
+// the lanes, for batches (hundreds of hypotheses per pair, or 16 of each of four pairs in the first chunk: throughput matters, not
+// latency).  With 16 lanes per polynomial every level costs its 40 bisection steps whatever the number of sign-change intervals,
+// and most of the 16 lanes idle.  A wave that walks "interval j of my polynomial" for 64 polynomials runs max-over-lanes(number of
+// intervals) rounds per level: measured on the fixed-1000 leg 88 % of the lane-rounds hold an interval at level 2, 52 % at levels
+// 7-9, 66 % at the last one (62 % weighted by the work per round).  Here the owners list their intervals (owner lane, interval,
+// root slot, sign at the left end, "right end is +B"), any lane bisects any interval with the owner's coefficients (LDS, read once
+// per interval) and writes the root where the owner expects it (the other one of two root buffers: every interval of a level reads
+// its end points from the previous level's).  A lane takes up to FOUR intervals per round (independent Horner chains issued
+// side by side; 0.2 ms faster than two on the fixed-1000 leg).  The arithmetic per interval is the sequential algorithm's
+// (oracle/pose.cpp real_roots): same coefficients, same end points, same Horner chain, same number of steps.
+struct RootsLds {
+    double cb[12][64];                                             // c[0..10] and the root bound B of every hypothesis of the wave
+    double prev[2][10][64];                                        // roots of the previous / this level ([root][owner lane])
+    uint16_t items[640];                                           // owner | interval << 6 | root slot << 10 | left sign << 14 | right end is +B << 15
+};
+// exact IEEE double multiply / add as instructions the compiler may not reorder: the C chains of a lane are issued as C multiplies, then
+// C adds, so that a dependent pair is C - 1 instructions apart (the compiler's own order, mul a, add a, mul b, add b, stalls on
+// every second instruction; in-order issue cannot hide that with two waves per SIMD)
+DEV double mul_f64_ordered(double a, double b) { double r; asm volatile("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+DEV double add_f64_ordered(double a, double b) { double r; asm volatile("v_add_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+template <int D, int C>
+DEV void roots_bisect_packed(RootsLds& L, int k0, int N, int lane) {
+    constexpr int K = 10 - D, NIT = (D == 10) ? BISECT_FINAL : BISECT_INNER;
+    const double (*prev)[64] = L.prev[(D - 1) & 1];
+    double (*next)[64] = L.prev[D & 1];
+    bool v[C]; uint32_t d[C]; int h[C];
+    double q[C][D + 1], lo[C], hi[C];
+    unsigned long long nm[C];
 #pragma unroll
-    for (int i = 0; i <= D; i++) {
-        double f = 1.0;
+    for (int c = 0; c < C; c++) {
+        const int k = k0 + 64 * c + lane;
+        v[c] = k < N;
+        d[c] = L.items[v[c] ? k : k0];
+        h[c] = d[c] & 63;
+        const int j = (d[c] >> 6) & 15;
+        const double B = L.cb[11][h[c]];
+        lo[c] = j == 0 ? -B : prev[j > 0 ? j - 1 : 0][h[c]];
+        hi[c] = (d[c] >> 15) ? B : prev[min(j, 9)][h[c]];
+        nm[c] = ~__builtin_amdgcn_ballot_w64((d[c] >> 14) & 1u);    // left = (fm < 0) == neg
 #pragma unroll
-        for (int jj = 0; jj < K; jj++) f *= (double)(i + K - jj);
-        q[i] = c[i + K] * f;
-    }
-    constexpr int NIT = (D == 10) ? BISECT_FINAL : BISECT_INNER;
-    // signs at the interval end points -B, root 0 .. root nprev-1 of the previous level, +B (each value is the Horner chain the
-    // sequential algorithm evaluates at that end point; it evaluates the inner ones twice, as hi of one interval and lo of the next)
-    uint32_t sneg = 0;
+        for (int i = 0; i <= D; i++) {
+            double f = 1.0;
 #pragma unroll
-    for (int j = 0; j <= D; j++) {
-        const double x = j == 0 ? -B : ((D > 1 && j <= D - 1 && j <= nprev) ? prev[j - 1][lane] : B);
-        double fx = q[D];
-#pragma unroll
-        for (int i = D - 1; i >= 0; i--) fx = fx * x + q[i];
-        sneg |= (fx < 0 ? 1u : 0u) << j;
-    }
-    // interval j = (end point j, end point j + 1), j = 0 .. nprev, holds a root iff the signs differ.  A lane walks over ITS
-    // sign-change intervals only (ascending), so the wave needs max-over-lanes(number of roots) rounds instead of D.
-    const int last = min(nprev, D - 1);                            // index of the interval that ends at +B
-    uint32_t todo = (sneg ^ (sneg >> 1)) & ((2u << last) - 1u);
-    int ncur = 0;
-    int j = todo ? __builtin_ctz(todo) : 0;
-    double lo = (j == 0) ? -B : prev[j - 1][lane];
-    double hi = (j >= last) ? B : prev[j][lane];
-    while (__any(todo != 0)) {
-        const bool act = todo != 0;
-        const unsigned long long negmask = ~__builtin_amdgcn_ballot_w64((sneg >> j) & 1u);       // left = (fm < 0) == neg
-        for (int it = 0; it < NIT; it++) {
-            const double m = 0.5 * (lo + hi);
-            double fm = q[D];
-#pragma unroll
-            for (int i = D - 1; i >= 0; i--) fm = fm * m + q[i];
-            BISECT_STEP(act)
+            for (int jj = 0; jj < K; jj++) f *= (double)(i + K - jj);
+            q[c][i] = L.cb[i + K][h[c]] * f;
         }
-        const double r = 0.5 * (lo + hi);
-        // the next interval's end points are read BEFORE this root is stored: root k lands at index k <= j, the next interval
-        // j' > j reads indices j' - 1 and j' >= k, and everything after it reads indices > k
-        todo &= todo - 1u;
-        j = todo ? __builtin_ctz(todo) : 0;
-        lo = (j == 0) ? -B : prev[j - 1][lane];
-        hi = (j >= last) ? B : prev[min(j, 9)][lane];
-        if (act) { prev[ncur][lane] = r; ncur++; }                 // (a lane only ever touches its own column of prev)
     }
-    nprev = ncur;
+    for (int it = 0; it < NIT; it++) {
+        double m[C], f[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) { m[c] = 0.5 * (lo[c] + hi[c]); f[c] = q[c][D]; }
+#pragma unroll
+        for (int i = D - 1; i >= 0; i--) {
+#pragma unroll
+            for (int c = 0; c < C; c++) f[c] = mul_f64_ordered(f[c], m[c]);
+#pragma unroll
+            for (int c = 0; c < C; c++) f[c] = add_f64_ordered(f[c], q[c][i]);
+        }
+        // (see BISECT_STEP: a collapsed interval's step is a no-op, looked at every eighth step)
+        if ((it & 7) == 7) {
+            bool open = false;
+#pragma unroll
+            for (int c = 0; c < C; c++) open |= v[c] && m[c] > lo[c] && m[c] < hi[c];
+            if (!__any(open)) break;
+        }
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const unsigned long long l_ = __builtin_amdgcn_ballot_w64(f[c] < 0) ^ nm[c];
+            lo[c] = sel_f64(l_, m[c], lo[c]); hi[c] = sel_f64(l_, hi[c], m[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; c++) if (v[c]) next[(d[c] >> 10) & 15][h[c]] = 0.5 * (lo[c] + hi[c]);
+}
+template <int D>
+DEV void roots_level_packed(const double (&c)[11], double B, RootsLds& L, int lane, bool flagged, int& nprev) {
+    constexpr int K = 10 - D;
+    const double (*prev)[64] = L.prev[(D - 1) & 1];
+    // the owner's part: signs at the interval end points -B, root 0 .. root nprev-1 of the previous level, +B (as roots_level_lane)
+    uint32_t sneg = 0;
+    {
+        double q[D + 1];
+#pragma unroll
+        for (int i = 0; i <= D; i++) {
+            double f = 1.0;
+#pragma unroll
+            for (int jj = 0; jj < K; jj++) f *= (double)(i + K - jj);
+            q[i] = c[i + K] * f;
+        }
+#pragma unroll
+        for (int j = 0; j <= D; j++) {
+            const double x = j == 0 ? -B : ((D > 1 && j <= D - 1 && j <= nprev) ? prev[j - 1][lane] : B);
+            double fx = q[D];
+#pragma unroll
+            for (int i = D - 1; i >= 0; i--) fx = fx * x + q[i];
+            sneg |= (fx < 0 ? 1u : 0u) << j;
+        }
+    }
+    const int last = min(nprev, D - 1);                            // index of the interval that ends at +B
+    uint32_t todo = flagged ? (sneg ^ (sneg >> 1)) & ((2u << last) - 1u) : 0u;
+    const int n = __popc(todo);
+    int incl = n;                                                  // inclusive prefix sum over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+    const int N = __builtin_amdgcn_readlane(incl, 63);
+    {
+        int slot = incl - n, i = 0;
+        while (todo) {
+            const int j = __builtin_ctz(todo);
+            todo &= todo - 1u;
+            L.items[slot + i] = (uint16_t)(lane | (j << 6) | (i << 10) | (((sneg >> j) & 1u) << 14) | ((j >= last ? 1u : 0u) << 15));
+            i++;
+        }
+    }
+    HYP_SYNC();
+    for (int k0 = 0; k0 < N; ) {                                    // up to four intervals per lane and round
+        const int left = N - k0;
+        if (left > 192) { roots_bisect_packed<D, 4>(L, k0, N, lane); k0 += 256; }
+        else if (left > 128) { roots_bisect_packed<D, 3>(L, k0, N, lane); k0 += 192; }
+        else if (left > 64) { roots_bisect_packed<D, 2>(L, k0, N, lane); k0 += 128; }
+        else { roots_bisect_packed<D, 1>(L, k0, N, lane); k0 += 64; }
+    }
+    HYP_SYNC();
+    nprev = n;
 }
 
-__global__ __launch_bounds__(256) void k_hyp_roots_lane(PoseParams P, int h0, int h_end, int npairs, const int32_t* __restrict__ rstate,
-                                                        double* __restrict__ hyp, size_t S, const int32_t* __restrict__ worklist, int chunks) {
-    __shared__ double sh_prev[4][10][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    double (*prev)[64] = sh_prev[wv];
+__global__ __launch_bounds__(64) void k_hyp_roots_packed(PoseParams P, int h0, int h_end, int npairs, const int32_t* __restrict__ rstate,
+                                                         double* __restrict__ hyp, size_t S, const int32_t* __restrict__ worklist, int chunks) {
+    __shared__ RootsLds L;
+    const int lane = threadIdx.x;
     // items: 64 consecutive hypotheses of one work-list pair, or (first chunk, worklist == nullptr) 16 of each of four pairs
     const int total = worklist ? worklist[0] * chunks : (npairs + 3) / 4;
     int32_t* flags = reinterpret_cast<int32_t*>(hyp + (size_t)HR_DOUBLES * S);
     int32_t* nrs = flags + S;
-    for (int item = blockIdx.x * 4 + wv; item < total; item += gridDim.x * 4) {
+    for (int item = blockIdx.x; item < total; item += gridDim.x) {
         const int pair_raw = worklist ? worklist[1 + item / chunks] : item * 4 + (lane >> 4);
         const int pair = min(pair_raw, npairs - 1);
         const int h = worklist ? h0 + (item % chunks) * 64 + lane : h0 + (lane & 15);
@@ -800,14 +869,19 @@ __global__ __launch_bounds__(256) void k_hyp_roots_lane(PoseParams P, int h0, in
         int np = 0;
         if (__any(flag != 0)) {
             const double B = poly_prepare(c, flag);
-            roots_level_lane<1>(c, B, prev, lane, np); roots_level_lane<2>(c, B, prev, lane, np);
-            roots_level_lane<3>(c, B, prev, lane, np); roots_level_lane<4>(c, B, prev, lane, np);
-            roots_level_lane<5>(c, B, prev, lane, np); roots_level_lane<6>(c, B, prev, lane, np);
-            roots_level_lane<7>(c, B, prev, lane, np); roots_level_lane<8>(c, B, prev, lane, np);
-            roots_level_lane<9>(c, B, prev, lane, np); roots_level_lane<10>(c, B, prev, lane, np);
+            HYP_SYNC();                                            // the previous item's roots have been read
+#pragma unroll
+            for (int i = 0; i <= 10; i++) L.cb[i][lane] = c[i];
+            L.cb[11][lane] = B;
+            const bool fl = flag != 0;
+            roots_level_packed<1>(c, B, L, lane, fl, np); roots_level_packed<2>(c, B, L, lane, fl, np);
+            roots_level_packed<3>(c, B, L, lane, fl, np); roots_level_packed<4>(c, B, L, lane, fl, np);
+            roots_level_packed<5>(c, B, L, lane, fl, np); roots_level_packed<6>(c, B, L, lane, fl, np);
+            roots_level_packed<7>(c, B, L, lane, fl, np); roots_level_packed<8>(c, B, L, lane, fl, np);
+            roots_level_packed<9>(c, B, L, lane, fl, np); roots_level_packed<10>(c, B, L, lane, fl, np);
         }
         if (flag) {
-            for (int j = 0; j < np; j++) hyp[slot + (size_t)(HR_ROOTS + j) * S] = prev[j][lane];
+            for (int j = 0; j < np; j++) hyp[slot + (size_t)(HR_ROOTS + j) * S] = L.prev[0][j][lane];      // level 10 writes buffer 10 & 1 = 0
             nrs[slot] = np;
         } else if (active) nrs[slot] = 0;
     }
@@ -1494,7 +1568,7 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
             // 16 lanes per polynomial for a handful of pairs (a single call's latency), one polynomial per lane for a batch: a
             // third of the vector instructions, and the longer chain of the pose stream is hidden behind the detect chain (+0.5 %)
             if (npairs >= 64)
-                hipLaunchKernelGGL(k_hyp_roots_lane, dim3((npairs + 15) / 16), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_hyp, S, (const int32_t*)nullptr, 0);
+                hipLaunchKernelGGL(k_hyp_roots_packed, dim3((npairs + 3) / 4), dim3(64), 0, st, P, 0, first, npairs, d_rstate, d_hyp, S, (const int32_t*)nullptr, 0);
             else
                 hipLaunchKernelGGL(k_hyp_roots, dim3(npairs), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_hyp, S, (const int32_t*)nullptr, 0);
             hipLaunchKernelGGL(k_hyp_models, dim3((npairs + 15) / 16), dim3(256), 0, st, P, 0, first, npairs, d_rstate, d_hyp, S, d_models, (const int32_t*)nullptr, 0);
@@ -1512,7 +1586,9 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
                 hipLaunchKernelGGL(k_hyp_roots, dim3(nsub), dim3(256), 0, st, P, first, max_iters, npairs, d_rstate, d_hyp, S,
                                    (const int32_t*)d_worklist, chunks);
             else           // one hypothesis per lane
-                hipLaunchKernelGGL(k_hyp_roots_lane, dim3(std::min(2048, (npairs * chunks + 3) / 4)), dim3(256), 0, st, P, first, max_iters, npairs, d_rstate,
+                // one workgroup (wave) per 64-hypothesis item: the items differ in their numbers of real roots, a fixed grid walking
+                // them in strides left a quarter of the chip idle at the end (2.0 -> 1.5 ms per 1.02 M polynomials)
+                hipLaunchKernelGGL(k_hyp_roots_packed, dim3(std::min(1 << 20, npairs * chunks)), dim3(64), 0, st, P, first, max_iters, npairs, d_rstate,
                                    d_hyp, S, (const int32_t*)d_worklist, chunks);
             hipLaunchKernelGGL(k_hyp_models, dim3(std::min(4096, (npairs * chunks + 3) / 4)), dim3(256), 0, st, P, first, max_iters, npairs, d_rstate,
                                d_hyp, S, d_models, (const int32_t*)d_worklist, chunks);
