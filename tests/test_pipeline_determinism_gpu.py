@@ -87,3 +87,30 @@ def test_alignment_in_the_pipeline_is_repeatable(vislam, canvas):
     nres = np.frombuffer(res[:, 136:156].tobytes(), np.int32).reshape(n_total, 5)
     assert (nres[[0, 24]] == 0).all()                          # first frame of each batch: no predecessor inside the batch
     assert (nres[1:24, 0] > 1000).all() and (nres[25:, 0] > 1000).all()
+
+
+def test_sync_and_timings_before_the_first_run_leave_no_error_behind(vislam, canvas):
+    """vis_batch_sync / vis_timings query the stage events; before the first run (or after a run that left stages out) some of
+    them were never recorded and the query fails -- that failure must not survive as the thread's HIP "last error", where the
+    launch checks of the next, valid, call would pick it up (seen as `vis_batch_run: hipGetLastError(): invalid resource handle`
+    from a bench leg with zero warm-up steps)."""
+    import torch
+    n = 8
+    frames = np.stack([vislam.synth_frame(canvas, t, W, H) for t in range(n)])
+    dev = torch.from_numpy(frames).cuda()
+    p = vislam.default_params(); p.fy = p.fx
+    ref = vislam.Context(0, p); ref.batch_plan(W, H, W, n)
+    ref.batch_run(dev.data_ptr(), n); ref.batch_sync()
+    want = ref.batch_results(n)[0].tobytes()
+    ref.close()
+    c = vislam.Context(0, p)
+    c.batch_plan(W, H, W, n)
+    c.batch_sync()                                              # nothing has run: every event query fails
+    assert c.batch_status() == 0
+    c.timings()
+    c.batch_run(dev.data_ptr(), n, vislam.STAGE_DETECT)         # the match / pose events stay unrecorded
+    c.batch_sync(); c.timings()
+    c2 = vislam.Context(0, p); c2.batch_plan(W, H, W, n)        # a fresh context on the same thread: same stream of "last errors"
+    c2.batch_run(dev.data_ptr(), n); c2.batch_sync()
+    assert c2.batch_results(n)[0].tobytes() == want
+    c.close(); c2.close()

@@ -537,13 +537,22 @@ extern "C" int vis_patch_points(vis_ctx* ctx, const vis_keypoint* good, int n, i
     return over ? VIS_E_CAPACITY : VIS_OK;
 }
 
+// elapsed time between two events, false when either was never recorded (a stage that did not run, a sync before the first run).
+// The failed query must not stay behind as the thread's "last error": the launch checks (hipGetLastError after a kernel launch)
+// would report it for the next, valid, call.
+static bool ev_elapsed(float* ms, hipEvent_t a, hipEvent_t b) {
+    if (hipEventElapsedTime(ms, a, b) == hipSuccess) return true;
+    (void)hipGetLastError();
+    return false;
+}
+
 static void collect_detect_timings(vis_ctx* ctx) {
     if (!ctx->ev_ok) return;
     float a = 0;
-    if (hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->tm.ms_pyramid = a;
-    if (hipEventElapsedTime(&a, ctx->ev[1], ctx->ev[2]) == hipSuccess) ctx->tm.ms_fast = a;
-    if (hipEventElapsedTime(&a, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->tm.ms_select = a;
-    if (hipEventElapsedTime(&a, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->tm.ms_describe = a;
+    if (ev_elapsed(&a, ctx->ev[0], ctx->ev[1])) ctx->tm.ms_pyramid = a;
+    if (ev_elapsed(&a, ctx->ev[1], ctx->ev[2])) ctx->tm.ms_fast = a;
+    if (ev_elapsed(&a, ctx->ev[2], ctx->ev[3])) ctx->tm.ms_select = a;
+    if (ev_elapsed(&a, ctx->ev[3], ctx->ev[4])) ctx->tm.ms_describe = a;
 }
 
 extern "C" int vis_orb_detect_compute(vis_ctx* ctx, const uint8_t* img, int w, int h, int stride, int frame_slot,
@@ -561,7 +570,7 @@ extern "C" int vis_orb_detect_compute(vis_ctx* ctx, const uint8_t* img, int w, i
     HIPCHK(ctx, hipMemcpyAsync(&n, pl->d_nkp + frame_slot, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     collect_detect_timings(ctx);
-    { float a = 0; if (ctx->ev_ok && hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[4]) == hipSuccess) ctx->tm.ms_total = a; }
+    { float a = 0; if (ctx->ev_ok && ev_elapsed(&a, ctx->ev[0], ctx->ev[4])) ctx->tm.ms_total = a; }
     {   // More tied keypoints than the plan's records hold (KeyPointsFilter::retainBest keeps every tie at its cut: a checkerboard)?  The
         // caller's `cap` says how many it is prepared to take: grow the per-frame capacity towards it -- the other slots' records move
         // into the re-created plan -- and detect again.  Only what exceeds `cap` (or 65535) is an error.
@@ -617,7 +626,7 @@ extern "C" int vis_bf_knn2_hamming(vis_ctx* ctx, int slot_q, int slot_t, vis_dma
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[5], ctx->stream);
     int32_t nq = 0, nt = 0;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    { float a = 0; if (ctx->ev_ok && hipEventElapsedTime(&a, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->tm.ms_knn = a; }
+    { float a = 0; if (ctx->ev_ok && ev_elapsed(&a, ctx->ev[4], ctx->ev[5])) ctx->tm.ms_knn = a; }
     HIPCHK(ctx, hipMemcpy(&nq, pl->d_nkp + slot_q, 4, hipMemcpyDeviceToHost));
     HIPCHK(ctx, hipMemcpy(&nt, pl->d_nkp + slot_t, 4, hipMemcpyDeviceToHost));
     rc = download_knn(ctx, pl->d_knn12, nq, out12);
@@ -652,7 +661,7 @@ extern "C" int vis_bf_knn2_hamming_host(vis_ctx* ctx, const uint8_t* desc_q, int
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[5], ctx->stream);
     if (rc) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    { float a = 0; if (ctx->ev_ok && hipEventElapsedTime(&a, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->tm.ms_knn = a; }
+    { float a = 0; if (ctx->ev_ok && ev_elapsed(&a, ctx->ev[4], ctx->ev[5])) ctx->tm.ms_knn = a; }
     rc = download_knn(ctx, tp.d_knn12, n_q, out12);
     if (rc) return rc;
     rc = download_knn(ctx, tp.d_knn21, n_t, out21);
@@ -696,8 +705,8 @@ extern "C" int vis_good_matches(vis_ctx* ctx, int slot_prev, int slot_cur, vis_d
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[6], ctx->stream);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     { float a = 0;
-      if (ctx->ev_ok && hipEventElapsedTime(&a, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->tm.ms_knn = a;
-      if (ctx->ev_ok && hipEventElapsedTime(&a, ctx->ev[5], ctx->ev[6]) == hipSuccess) ctx->tm.ms_filter = a; }
+      if (ctx->ev_ok && ev_elapsed(&a, ctx->ev[4], ctx->ev[5])) ctx->tm.ms_knn = a;
+      if (ctx->ev_ok && ev_elapsed(&a, ctx->ev[5], ctx->ev[6])) ctx->tm.ms_filter = a; }
     return download_matches(ctx, pl, 0, good, cap, n_good, sym_out, sym_cap, n_sym);
 }
 
@@ -787,7 +796,7 @@ static int pose_host(vis_ctx* ctx, const float* p1xy, const float* p2xy, int m, 
     if (rc) return rc;
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[7], ctx->stream);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    { float a = 0; if (ctx->ev_ok && hipEventElapsedTime(&a, ctx->ev[6], ctx->ev[7]) == hipSuccess) ctx->tm.ms_pose = a; }
+    { float a = 0; if (ctx->ev_ok && ev_elapsed(&a, ctx->ev[6], ctx->ev[7])) ctx->tm.ms_pose = a; }
     HIPCHK(ctx, hipMemcpy(out, d_pose, sizeof(PoseOut), hipMemcpyDeviceToHost));
     if (mask && m) HIPCHK(ctx, hipMemcpy(mask, d_mask, (size_t)m, hipMemcpyDeviceToHost));
     return VIS_OK;
@@ -989,17 +998,17 @@ extern "C" int vis_batch_sync(vis_ctx* ctx) {
     if (ctx->ev_ok) {
         collect_detect_timings(ctx);
         float a = 0;
-        if (hipEventElapsedTime(&a, ctx->ev_match_start, ctx->ev[5]) == hipSuccess) ctx->tm.ms_knn = a;
-        if (hipEventElapsedTime(&a, ctx->ev[5], ctx->ev[6]) == hipSuccess) ctx->tm.ms_filter = a;
+        if (ev_elapsed(&a, ctx->ev_match_start, ctx->ev[5])) ctx->tm.ms_knn = a;
+        if (ev_elapsed(&a, ctx->ev[5], ctx->ev[6])) ctx->tm.ms_filter = a;
         ctx->tm.ms_pose = 0;
-        if (had_pose && hipEventElapsedTime(&a, ctx->ev_pose_start, ctx->ev_pose_done) == hipSuccess) ctx->tm.ms_pose = a;
+        if (had_pose && ev_elapsed(&a, ctx->ev_pose_start, ctx->ev_pose_done)) ctx->tm.ms_pose = a;
         ctx->tm.ms_update = 0;
         const bool upd = ctx->batch && ctx->batch->half_valid;
-        if (upd && hipEventElapsedTime(&a, ctx->ev[10], ctx->ev[11]) == hipSuccess) ctx->tm.ms_update = a;
+        if (upd && ev_elapsed(&a, ctx->ev[10], ctx->ev[11])) ctx->tm.ms_update = a;
         hipEvent_t e0 = ctx->ev[0];
-        if (hipEventElapsedTime(&a, e0, ctx->ev[8]) == hipSuccess) ctx->tm.ms_total = a;
-        if (hipEventElapsedTime(&a, e0, ctx->ev[6]) == hipSuccess && a > ctx->tm.ms_total) ctx->tm.ms_total = a;
-        if (had_pose && hipEventElapsedTime(&a, e0, ctx->ev_pose_done) == hipSuccess && a > ctx->tm.ms_total) ctx->tm.ms_total = a;
+        if (ev_elapsed(&a, e0, ctx->ev[8])) ctx->tm.ms_total = a;
+        if (ev_elapsed(&a, e0, ctx->ev[6]) && a > ctx->tm.ms_total) ctx->tm.ms_total = a;
+        if (had_pose && ev_elapsed(&a, e0, ctx->ev_pose_done) && a > ctx->tm.ms_total) ctx->tm.ms_total = a;
     }
     return VIS_OK;
 }
