@@ -1579,7 +1579,7 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
         if (max_iters > first) {
             const int chunks = (max_iters - first + 63) / 64;
             const int nb = (int)std::min<long long>(256 * 16, (long long)npairs * chunks * (64 / QH));    // eight waves per CU (two per SIMD: 256 VGPRs), two rounds
-            const int nsub = (int)std::min<long long>(2048, (long long)npairs * chunks * 4);
+            const int nsub = (int)std::min<long long>(1 << 20, (long long)npairs * chunks * 4);   // one workgroup per sub-item (a fixed grid of 2048 walking them: config 3 + 0.17 ms)
             hipLaunchKernelGGL(k_ransac_hyp_list, dim3(nb), dim3(64), HYP_LDS_BYTES, st, P, first, max_iters,
                                npairs, d_n1, d_n2, d_samples, d_rstate, d_hyp, S, (const int32_t*)d_worklist, chunks);
             if (roots16)
