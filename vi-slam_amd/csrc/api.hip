@@ -311,14 +311,14 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
     DALLOC(pl->d_counts, (size_t)npairs * pl->max_iters * 10);
     DALLOC(pl->d_rstate, (size_t)npairs * VIS_RSTATE_WORDS);
     DALLOC(pl->d_pose, npairs);
-    DALLOC(pl->d_worklist, (size_t)npairs + 1);
+    DALLOC(pl->d_worklist, (size_t)npairs + 2);        // count, pairs, k_hyp_roots_packed item counter
     DALLOC(pl->d_hyp, (size_t)npairs * pl->max_iters * VIS_HYP_DOUBLES);
     // defence in depth: nothing should read these before writing them, but a recycled allocation must never
     // turn a missed guard into an out-of-bounds index (see the inactive-lane fix in k_ransac_hyp)
     HIPCHK(ctx, hipMemset(pl->d_samples, 0, (size_t)npairs * pl->max_iters * 5 * sizeof(int32_t)));
     HIPCHK(ctx, hipMemset(pl->d_counts, 0xFF, (size_t)npairs * pl->max_iters * 10 * sizeof(int32_t)));
     HIPCHK(ctx, hipMemset(pl->d_rstate, 0, (size_t)npairs * VIS_RSTATE_WORDS * sizeof(int32_t)));
-    HIPCHK(ctx, hipMemset(pl->d_worklist, 0, ((size_t)npairs + 1) * sizeof(int32_t)));
+    HIPCHK(ctx, hipMemset(pl->d_worklist, 0, ((size_t)npairs + 2) * sizeof(int32_t)));
     HIPCHK(ctx, hipMemset(pl->d_knn12, 0xFF, (size_t)npairs * kcap * 2 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMemset(pl->d_knn21, 0xFF, (size_t)npairs * kcap * 2 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMemset(pl->d_p1, 0, (size_t)npairs * mcap * 2 * sizeof(float)));
@@ -779,7 +779,7 @@ static int pose_host(vis_ctx* ctx, const float* p1xy, const float* p2xy, int m, 
     double* d_E = cv.take<double>(9);
     uint8_t* d_mask = cv.take<uint8_t>(mcap);
     PoseOut* d_pose = cv.take<PoseOut>(1);
-    int32_t* d_worklist = cv.take<int32_t>(2);
+    int32_t* d_worklist = cv.take<int32_t>(3);
     double* d_hyp = cv.take<double>((size_t)iters * VIS_HYP_DOUBLES);
     if (m) {
         HIPCHK(ctx, hipMemcpy(d_p1, p1xy, (size_t)m * 8, hipMemcpyHostToDevice));

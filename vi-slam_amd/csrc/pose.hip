@@ -856,7 +856,18 @@ __global__ __launch_bounds__(64) void k_hyp_roots_packed(PoseParams P, int h0, i
     const int total = worklist ? worklist[0] * chunks : (npairs + 3) / 4;
     int32_t* flags = reinterpret_cast<int32_t*>(hyp + (size_t)HR_DOUBLES * S);
     int32_t* nrs = flags + S;
-    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    // Work-list items differ in their numbers of real roots: a workgroup CLAIMS its next item (counter behind the list, zeroed by
+    // the scan that built the list) instead of walking a stride -- a grid of what fits on the chip stays busy to the end, and an
+    // almost empty list (the adaptive headline) costs that many empty workgroups, not one per possible item.
+    // (The first item is the workgroup's own index: with an almost empty list 2048 atomics on one address would cost 35 us.)
+    int32_t* claim = worklist ? const_cast<int32_t*>(worklist) + 1 + npairs : nullptr;
+    auto next_item = [&](int prev) -> int {
+        if (!claim || prev < 0) return prev < 0 ? (int)blockIdx.x : prev + (int)gridDim.x;
+        int it = 0;
+        if (lane == 0) it = atomicAdd(claim, 1);
+        return (int)gridDim.x + __builtin_amdgcn_readfirstlane(it);
+    };
+    for (int item = next_item(-1); item < total; item = next_item(item)) {
         const int pair_raw = worklist ? worklist[1 + item / chunks] : item * 4 + (lane >> 4);
         const int pair = min(pair_raw, npairs - 1);
         const int h = worklist ? h0 + (item % chunks) * 64 + lane : h0 + (lane & 15);
@@ -1279,6 +1290,7 @@ __global__ __launch_bounds__(64) void k_ransac_scan(PoseParams P, int hi, const 
     if (lane == 0) {
         rs[0] = niters; rs[1] = maxGood; rs[2] = bi; rs[3] = bm; rs[4] = iter; rs[7] = iter;
         if (worklist && niters > hi && hi < P.max_iters) worklist[1 + atomicAdd(&worklist[0], 1)] = pair;   // needs more hypotheses
+        if (worklist && pair == 0) worklist[1 + gridDim.x] = 0;   // k_hyp_roots_packed's item counter (this scan runs once, before the work-list kernels)
     }
 }
 
@@ -1533,6 +1545,23 @@ static PoseParams make_pose_params(const vis_ctx* ctx, int max_iters, int mcap) 
     return P;
 }
 
+struct PoseGrids { int hyp_list, roots, models, score; };
+static PoseGrids pose_grids(int device) {
+    hipDeviceProp_t pr; int cus = 256;
+    if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+    auto occ = [&](const void* k, int block, size_t lds, int fallback) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, block, lds) != hipSuccess || n < 1) { (void)hipGetLastError(); n = fallback; }
+        return n * cus;
+    };
+    PoseGrids g;
+    g.hyp_list = occ((const void*)k_ransac_hyp_list, 64, HYP_LDS_BYTES, 8) * 2;     // equal items: two rounds
+    g.roots = occ((const void*)k_hyp_roots_packed, 64, 0, 8);
+    g.models = occ((const void*)k_hyp_models, 256, 0, 4) * 4;
+    g.score = occ((const void*)k_hyp_score, 256, 0, 4);
+    return g;
+}
+
 // generic driver used by the batch path and the host-pointer entry points.
 // d_p1/d_p2: npairs x mcap x 2 floats; d_npts: npairs
 int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p1, const float* d_p2, const int32_t* d_npts,
@@ -1578,8 +1607,15 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
         hipLaunchKernelGGL(k_ransac_scan, dim3(npairs), dim3(64), 0, st, P, first, d_counts, d_rstate, d_worklist);
         if (max_iters > first) {
             const int chunks = (max_iters - first + 63) / 64;
-            const int nb = (int)std::min<long long>(256 * 16, (long long)npairs * chunks * (64 / QH));    // eight waves per CU (two per SIMD: 256 VGPRs), two rounds
-            const int nsub = (int)std::min<long long>(1 << 20, (long long)npairs * chunks * 4);   // one workgroup per sub-item (a fixed grid of 2048 walking them: config 3 + 0.17 ms)
+            // grids = what is resident on the chip at once (occupancy x CUs), walked in strides / by claiming: one workgroup per possible
+            // item floods the adaptive headline, whose list is almost empty, with empty workgroups (65 k of them: - 5 % frames/s)
+            static const PoseGrids G = pose_grids(ctx->device);
+            const int nb = (int)std::min<long long>(G.hyp_list, (long long)npairs * chunks * (64 / QH));
+            // k_hyp_score: a workgroup per sub-item when every pair is on the list (adaptive stop off: known on the host) -- workgroups that
+            // walk equal items in strides stay in lockstep, their load phases (models, four rows of points per round) coincide on a CU
+            // and nothing computes meanwhile: config 3 ms_pose 2.92 / 2.83 / 2.76 / 2.70 / 2.68 at 1024 / 2048 / 4096 / 8192 / 16384
+            // workgroups for 16256 sub-items.  With the adaptive stop the list is short and not known here: twice what is resident.
+            const int nsub = (int)std::min<long long>(ctx->p.ransac_adaptive ? 2 * G.score : (1 << 20), (long long)npairs * chunks * 4);   // one workgroup per sub-item (a fixed grid of 2048 walking them: config 3 + 0.17 ms)
             hipLaunchKernelGGL(k_ransac_hyp_list, dim3(nb), dim3(64), HYP_LDS_BYTES, st, P, first, max_iters,
                                npairs, d_n1, d_n2, d_samples, d_rstate, d_hyp, S, (const int32_t*)d_worklist, chunks);
             if (roots16)
@@ -1588,9 +1624,9 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
             else           // one hypothesis per lane
                 // one workgroup (wave) per 64-hypothesis item: the items differ in their numbers of real roots, a fixed grid walking
                 // them in strides left a quarter of the chip idle at the end (2.0 -> 1.5 ms per 1.02 M polynomials)
-                hipLaunchKernelGGL(k_hyp_roots_packed, dim3(std::min(1 << 20, npairs * chunks)), dim3(64), 0, st, P, first, max_iters, npairs, d_rstate,
+                hipLaunchKernelGGL(k_hyp_roots_packed, dim3(std::min(G.roots, npairs * chunks)), dim3(64), 0, st, P, first, max_iters, npairs, d_rstate,
                                    d_hyp, S, (const int32_t*)d_worklist, chunks);
-            hipLaunchKernelGGL(k_hyp_models, dim3(std::min(4096, (npairs * chunks + 3) / 4)), dim3(256), 0, st, P, first, max_iters, npairs, d_rstate,
+            hipLaunchKernelGGL(k_hyp_models, dim3(std::min(G.models, (npairs * chunks + 3) / 4)), dim3(256), 0, st, P, first, max_iters, npairs, d_rstate,
                                d_hyp, S, d_models, (const int32_t*)d_worklist, chunks);
             hipLaunchKernelGGL(k_hyp_score, dim3(nsub), dim3(256), 0, st, P, first, max_iters, npairs, d_rstate, d_n1, d_n2, d_hyp, S,
                                d_models, d_counts, (const int32_t*)d_worklist, chunks);

@@ -91,7 +91,7 @@ struct Plan {
     int32_t* d_counts = nullptr;             // npairs x max_iters x 10  (-1 = no model)
     int32_t* d_rstate = nullptr;             // npairs x 4: niters, maxGood, bestIter, bestModel
     PoseOut* d_pose = nullptr;               // npairs
-    int32_t* d_worklist = nullptr;           // 1 + npairs: pairs that need RANSAC chunks beyond the first
+    int32_t* d_worklist = nullptr;           // 2 + npairs: count, pairs that need RANSAC chunks beyond the first, item counter of the roots kernel
     double* d_hyp = nullptr;                 // npairs x max_iters hypothesis records (VIS_HYP_DOUBLES each, element-major)
     int max_iters = 0;
     bool have_prev = false;                  // batch: record 0 holds the previous batch's last frame
