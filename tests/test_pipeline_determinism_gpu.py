@@ -114,3 +114,34 @@ def test_sync_and_timings_before_the_first_run_leave_no_error_behind(vislam, can
     c2.batch_run(dev.data_ptr(), n); c2.batch_sync()
     assert c2.batch_results(n)[0].tobytes() == want
     c.close(); c2.close()
+
+
+def test_work_list_item_counter_is_reset_when_pair_zero_has_no_model(vislam, canvas):
+    """k_hyp_roots_packed claims work-list items from a counter that the scan building the list zeroes.  The first pair of a fresh
+    stream has no predecessor (no model to estimate: the scan leaves early for it) -- the counter must be zeroed all the same, or
+    the second stream on a context skips every item beyond the resident grid and scores the previous stream's roots.  Two different
+    streams through ONE context (reset in between), RANSAC with the adaptive stop off and 2000 iterations so that the list is
+    long (159 pairs x 32 items); the second must equal the same stream on a fresh context."""
+    import torch
+    n = 160
+    p = vislam.default_params(); p.fy = p.fx
+    p.ransac_adaptive, p.ransac_max_iters = 0, 2000
+    fa = np.stack([vislam.synth_frame(canvas, t, W, H) for t in range(n)])
+    fb = np.stack([vislam.synth_frame(canvas, 500 + 2 * t, W, H) for t in range(n)])
+    da, db = torch.from_numpy(fa).cuda(), torch.from_numpy(fb).cuda()
+
+    def run(ctx, d):
+        ctx.batch_run(d.data_ptr(), n); ctx.batch_sync()
+        assert ctx.batch_status() == 0
+        pose, good, ng = ctx.batch_results(n)
+        return pose.tobytes(), ng.tobytes()
+
+    fresh = vislam.Context(0, p); fresh.batch_plan(W, H, W, n)
+    want = run(fresh, db)
+    fresh.close()
+    c = vislam.Context(0, p); c.batch_plan(W, H, W, n)
+    run(c, da)
+    c.batch_reset()                                             # a new stream: pair 0 has no predecessor again
+    got = run(c, db)
+    c.close()
+    assert got[1] == want[1] and got[0] == want[0]

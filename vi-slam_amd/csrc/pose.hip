@@ -1250,6 +1250,9 @@ __global__ __launch_bounds__(64) void k_ransac_scan(PoseParams P, int hi, const 
                                                     int32_t* __restrict__ worklist) {
     const int pair = blockIdx.x, lane = threadIdx.x;
     int32_t* rs = rstate + (size_t)pair * RS;
+    // k_hyp_roots_packed's item counter behind the list: zeroed by the scan that builds the list (it runs once, before the work-list
+    // kernels) -- here, in front of every early return (pair 0 may well be a pair without a model to estimate)
+    if (worklist && pair == 0 && lane == 0) worklist[1 + gridDim.x] = 0;
     if (rs[5] != 0) {
         if (rs[5] == 1 && lane == 0) {
             rs[2] = 0; rs[3] = 0; rs[1] = 5; rs[7] = 1; rs[4] = 1;
@@ -1290,7 +1293,6 @@ __global__ __launch_bounds__(64) void k_ransac_scan(PoseParams P, int hi, const 
     if (lane == 0) {
         rs[0] = niters; rs[1] = maxGood; rs[2] = bi; rs[3] = bm; rs[4] = iter; rs[7] = iter;
         if (worklist && niters > hi && hi < P.max_iters) worklist[1 + atomicAdd(&worklist[0], 1)] = pair;   // needs more hypotheses
-        if (worklist && pair == 0) worklist[1 + gridDim.x] = 0;   // k_hyp_roots_packed's item counter (this scan runs once, before the work-list kernels)
     }
 }
 
