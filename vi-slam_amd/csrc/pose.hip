@@ -1199,6 +1199,7 @@ __global__ __launch_bounds__(256) void k_hyp_score(PoseParams P, int h0, int h_e
                 for (int a = tid; a < na; a += 256) {
                     const uint32_t code = sAmb[a];
                     const int t = (int)(code >> 16), gi = (int)(code & 0xFFFFu), tag = sTag[t];
+                    if (gi >= M) continue;                         // (a lane without a point: only a non-finite model can leave it undecided)
                     if (sampson_in_f64(mbase + (size_t)(tag >> 4) * 90 + 9 * (tag & 15), pa[2 * gi], pa[2 * gi + 1], pb[2 * gi], pb[2 * gi + 1], kLo, kHi, thr2))
                         atomicAdd(&sGood[t], 1);
                 }
