@@ -208,6 +208,33 @@ def run_leg(dev, w, h, B, R, params, seed, canvas_dim, steps, warmup, stages=Non
         torch.cuda.empty_cache()
 
 
+def pose_kernels(leg):
+    """the pose kernels of a loaded leg against the measured issue ceilings: instruction counts and standalone launch durations from the
+    committed counter pass (profiles/pmc_pose.json: tools/final_profile.sh step 4, other run, same kernels and workload; a counter pass
+    serialises the kernels), double-precision ceiling = tools/f64_rates.hip's Horner pair (v_mul_f64 + v_add_f64, 2 waves per SIMD) of the
+    same lease, single-precision ceiling = valu_peak_measured.full_rate_class of profiles/pmc_traffic.json.  k_hyp_score decides in single
+    precision (its double fallback is a fraction of a percent of the decisions) and is priced against the single-precision ceiling; in
+    the few-correspondences form of the fixed-1000 leg it is bound by model staging and LDS adds, not by the arithmetic.  Everything
+    else is double precision."""
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_pose.json")))
+        ks = pj["legs"][leg]
+        f64 = pj["f64_issue_ceiling"]["by_instruction_2_waves_per_simd_4_chains"]["v_mul_f64 + v_add_f64 (Horner step, 2 instr)"]
+        f32 = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["valu_peak_measured"]["full_rate_class"]
+        out = {"counters_from": f"profiles/pmc_pose.json legs.{leg} (commit {pj.get('measured_at_commit')})", "f64_issue_ceiling": f64, "f32_full_rate_ceiling": f32,
+               "unit": "wave-instr/s", "kernels": {}}
+        for k, v in ks.items():
+            if v.get("SQ_INSTS_VALU", 0) < 1e6:
+                continue
+            single = (k == "k_hyp_score")
+            out["kernels"][k] = {"ms_standalone": v["ms"], "valu_wave_insts": v["SQ_INSTS_VALU"], "salu_wave_insts": v.get("SQ_INSTS_SALU"),
+                                 "achieved": v["valu_wave_insts_per_s"], "ceiling": "f32 full rate" if single else "f64",
+                                 "frac": v["valu_wave_insts_per_s"] / (f32 if single else f64)}
+        return out
+    except Exception as e:
+        return {"error": f"profiles/pmc_pose.json unusable: {e!r}"}
+
+
 def usable_cpus():
     """host threads this process may really use: the scheduler affinity mask, capped by the cgroup CPU quota (a GPU box
     hands one GPU's share of a 256-thread host to the job)"""
@@ -432,7 +459,7 @@ def main():
             except Exception as e:
                 legs[name] = {"error": repr(e)}
         q1 = p.copy(); q1.ransac_adaptive = 0
-        guarded("s752_fixed1000", lambda: dict(run_leg(dev, W, H, B, R, q1, vdist.SINGLE_SEED, 4096, 6, 2),
+        guarded("s752_fixed1000", lambda: dict(run_leg(dev, W, H, B, R, q1, vdist.SINGLE_SEED, 4096, 6, 2), pose_kernels=pose_kernels("f1000"),
                 what="headline step with ransac_adaptive = 0: 1000 five-point hypotheses per frame pair, every candidate E scored on every match"))
         guarded("s752_parallax", lambda: dict(run_leg(dev, W, H, B, R, p, vdist.SINGLE_SEED, 4096, 20, 3, parallax=True),
                 what="S-752P: two depth layers (1.5x parallax) + independently moving objects; adaptive RANSAC, same parameters as the headline"))
@@ -484,7 +511,7 @@ def main():
         q3.nfeatures, q3.nlevels, q3.w_size, q3.h_size = 4000, 4, 1920, 1080
         q3.fy = q3.fx
         q3.ransac_adaptive, q3.ransac_max_iters, q3.pose_input = 0, 2000, 1
-        guarded("config3_s1080", lambda: dict(run_leg(dev, 1920, 1080, 128, 2, q3, 0xE0C00003, 8192, 5, 2),
+        guarded("config3_s1080", lambda: dict(run_leg(dev, 1920, 1080, 128, 2, q3, 0xE0C00003, 8192, 5, 2), pose_kernels=pose_kernels("c3"),
                 what="BASELINE configs[2]: 1920x1080, 4-level pyramid, 4000 kps/frame, 4000x4000 knn both directions, essential RANSAC with a FIXED "
                      "2000 iterations on the un-gridded symmetric matches (pose_input = SYM) + recoverPose; 128 frames per step"))
         q5 = vislam.default_params()

@@ -3,6 +3,7 @@
 # 1. rocprofv3 --kernel-trace --stats of the default bench command (side legs off: they would mix other configurations into the per-kernel averages)
 # 2. the same with the side legs on (configs 3 / 5, fixed-1000 RANSAC, parallax, alignment): one stats file for the legs
 # 3. PMC passes (separate runs, no trace domain besides --kernel-trace) of the pipeline workload and of the gradient stage
+# 4. a PMC pass of the loaded pose legs + tools/f64_rates (profiles/pmc_pose.json)
 set -e
 OUT=${1:-gpurun_out/final}
 COMMIT=${2:-unknown}
@@ -26,4 +27,11 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAI
 done
 python3 $R/tools/pmc_summarize.py $R/$OUT/grad 1024 $COMMIT > $R/$OUT/pmc_grad_summary.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/grad_stats -- python3 $R/tools/profile_gradient.py > $R/$OUT/grad_stats.log 2>&1
+# 4. the pose kernels under load (fixed-1000 S-752, config 3): instruction counts + standalone durations, and the double-precision issue rates
+for leg in f1000:fixed1000_probe.py c3:config3_probe.py; do
+  n=${leg%%:*}; py=${leg#*:}
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $R/$OUT/pose/$n -- python3 $R/tools/$py > $R/$OUT/pose_$n.log 2>&1
+done
+$R/vi-slam_amd/lib/f64_rates > $R/$OUT/f64_rates.log 2>&1
+python3 $R/tools/pmc_pose_summarize.py $R/$OUT/pose $COMMIT $R/$OUT/f64_rates.log > $R/$OUT/pmc_pose_summary.log 2>&1
 echo final_profile done
