@@ -1042,7 +1042,7 @@ __global__ __launch_bounds__(256) void k_hyp_score(PoseParams P, int h0, int h_e
     __shared__ uint32_t sAmb[AMB_CAP];
     __shared__ int32_t sNamb;
     __shared__ int32_t sBase[16], sCnt[16], sTag[160], sGood[160], sTotal;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const float thr2 = (float)(P.thr * P.thr);
     const double tmid = 0.5 * ((double)thr2 + (double)__uint_as_float(__float_as_uint(thr2) + 1u));
     const double kLo = tmid * (1.0 - 0x1p-40), kHi = tmid * (1.0 + 0x1p-40);
