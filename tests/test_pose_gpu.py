@@ -59,6 +59,23 @@ def test_essential_ransac_and_pose(vislam, orc, ctx, n, outl, noise, seed):
         assert np.abs(Ro - R).max() < 1e-3 and np.abs(to - t).max() < 1e-3
 
 
+@pytest.mark.parametrize("seed,outl,noise,fx,thr,iters,adaptive", [(249849968, 0.0, 0.5, 150.0, 1.0, 300, 1), (653569463, 0.3, 0.5, 150.0, 0.25, 17, 1),
+                                                                    (249849968, 0.0, 0.5, 150.0, 1.0, 300, 0)])
+def test_five_correspondences_without_a_model(vislam, orc, ctx, seed, outl, noise, fx, thr, iters, adaptive):
+    """count == modelPoints: a single solver run on all five points; when it finds no model the answer is "no E, no inliers, no
+    iteration" (RANSACPointSetRegistrator::run returns false), not an all-ones mask around a stale model.  Found by
+    tools/stress_pose.py (2 of 16954 random problems)."""
+    p = vislam.default_params()
+    p.fx = p.fy = fx
+    p.ransac_threshold, p.ransac_prob, p.ransac_max_iters, p.ransac_adaptive = thr, 0.9, iters, adaptive
+    ctx.set_params(p)
+    x1, x2, R, t = two_view(5, seed, outl, noise)
+    oE, omask, oninl, oiters = orc.essential_ransac(p, x1, x2)
+    assert (oninl, oiters) == (0, 0)                              # the cases were picked for that
+    E, mask, ninl, iters_run = ctx.essential_ransac(x1, x2)
+    assert (ninl, iters_run) == (0, 0) and not mask.any() and np.abs(E).max() == 0
+
+
 def test_ransac_fixed_iterations(vislam, orc, ctx):
     p = vislam.default_params()
     p.fy = p.fx

@@ -1256,7 +1256,10 @@ __global__ __launch_bounds__(64) void k_ransac_scan(PoseParams P, int hi, const 
     if (worklist && pair == 0 && lane == 0) worklist[1 + gridDim.x] = 0;
     if (rs[5] != 0) {
         if (rs[5] == 1 && lane == 0) {
-            rs[2] = 0; rs[3] = 0; rs[1] = 5; rs[7] = 1; rs[4] = 1;
+            // M == 5: one hypothesis from all five points, its FIRST model, an all-ones mask -- or nothing at all when the solver
+            // found no model (oracle/pose.cpp: `if (nm <= 0) return`; hbest = -1 once the hypothesis has been scored, hi > 0)
+            const bool none = hi > 0 && hbest[(size_t)pair * P.max_iters] < 0;
+            rs[2] = none ? -1 : 0; rs[3] = 0; rs[1] = none ? 0 : 5; rs[7] = none ? 0 : 1; rs[4] = 1;
             if (worklist && hi == 0) worklist[1 + atomicAdd(&worklist[0], 1)] = pair;     // no first chunk ran: its one hypothesis is still to be solved
         }
         return;
