@@ -600,7 +600,9 @@ extern "C" int orc_pipeline_frame(const vis_params* p, const uint8_t* img, int w
     std::memset(res, 0, sizeof(*res));
     // Camera::Update (src/Camera.cpp:63-72): the half pyramid is built every frame by the reference
     std::vector<uint8_t> lv[5]; uint8_t* lp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    for (int l = 1; l < 5; l++) { lv[l].resize((size_t)(w >> l) * (h >> l) + 16); lp[l] = lv[l].data(); }
+    int32_t hw[5], hh[5];
+    orc_half_pyramid_dims(w, h, hw, hh);                         // cv::resize's rounded sizes: 375 -> 188, not 375 >> 1
+    for (int l = 1; l < 5; l++) { lv[l].resize((size_t)hw[l] * hh[l] + 16); lp[l] = lv[l].data(); }
     orc_half_pyramid(img, w, h, stride, lp);
     std::vector<vis_keypoint> k; std::vector<uint8_t> d;
     int rc = orb_detect_compute(*p, img, w, h, stride, k, d);
@@ -654,7 +656,9 @@ extern "C" int orc_pipeline_stream_mt(const vis_params* p, const uint8_t* frames
         std::memset(&R[(size_t)i], 0, sizeof(orc_frame_result));
         const uint8_t* img = frames + (size_t)i * fbytes;
         std::vector<uint8_t> lv[5]; uint8_t* lp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-        for (int l = 1; l < 5; l++) { lv[l].resize((size_t)(w >> l) * (h >> l) + 16); lp[l] = lv[l].data(); }
+        int32_t hw[5], hh[5];
+        orc_half_pyramid_dims(w, h, hw, hh);
+        for (int l = 1; l < 5; l++) { lv[l].resize((size_t)hw[l] * hh[l] + 16); lp[l] = lv[l].data(); }
         orc_half_pyramid(img, w, h, stride, lp);
         if (orb_detect_compute(*p, img, w, h, stride, K[(size_t)i], D[(size_t)i])) err = 1;
         R[(size_t)i].n_kp = (int)K[(size_t)i].size();

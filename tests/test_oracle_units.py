@@ -351,3 +351,18 @@ def test_half_pyramid_partial_blocks(orc):
     lv2 = orc.half_pyramid(img2)
     assert lv2[1].shape == (11, 16) and lv2[2].shape == (6, 8)
     assert (lv2[2][5] == lv2[1][10, 0]).all()       # the mean of two equal pixels
+
+
+def test_pipeline_frame_on_a_size_that_does_not_halve_exactly(orc, vislam, canvas):
+    """orc_pipeline_frame builds Camera::Update's half pyramid every frame: its level buffers must have cv::resize's rounded sizes
+    (375 -> 188 rows, not 375 >> 1 = 187: the first form overflowed its buffers at 500 x 375; found by tools/stress_batch.py, runs
+    under ASan / UBSan in tests/test_oracle_asan.py like every test of this file)."""
+    p = vislam.default_params()
+    p.w_size, p.h_size, p.nfeatures, p.nlevels = 150, 110, 100, 3
+    p.fy = p.fx
+    prev = None
+    for t in range(3):
+        k, d, r = orc.pipeline_frame(p, vislam.synth_frame(canvas, 20 + t, 150, 110), prev)
+        prev = (k, d)
+        assert r.n_kp == len(k) > 20
+    assert r.n_sym > 10

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""tools/stress_detect.py [SECONDS] [SEED] -- randomised parity of detect + describe + match + Camera::Update on the GPU box: random
+image sizes (any size, not only multiples of 16), contents (stream crops, crops at reduced contrast, uniform noise, blurred noise,
+checkerboards, flat patches pasted in), ORB parameters (nfeatures 20 ... 3000, 1 ... 8 levels, scale factor, FAST / edge
+thresholds) through the single-frame C ABI against the CPU oracle: keypoints, descriptors, 2-NN tables, symmetric / good matches and
+the half pyramid, all bit for bit.  Prints one line per failure and a summary; exit code 1 on any failure.  Not part of the test
+suite (unbounded run time); tests/test_detect_gpu.py, test_match_gpu.py, test_edge_cases_gpu.py hold the fixed cases."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "vi-slam_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import vislam  # noqa: E402
+import oracle_bind as orc  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 4321
+rng = np.random.default_rng(seed0)
+ctx = vislam.Context(0)
+canvas = vislam.synth_canvas(2048, 0xE0C00001)
+
+
+def content(w, h):
+    kind = int(rng.integers(0, 6))
+    t = int(rng.integers(0, 400))
+    if kind == 0:
+        return vislam.synth_frame(canvas, t, w, h), vislam.synth_frame(canvas, t + 1, w, h)
+    if kind == 1:
+        a, b = vislam.synth_frame(canvas, t, w, h), vislam.synth_frame(canvas, t + 2, w, h)
+        q = int(rng.choice([2, 4, 8]))
+        return (a // q + 100).astype(np.uint8), (b // q + 100).astype(np.uint8)
+    if kind == 2:
+        a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        return a, np.roll(a, 3, axis=1)
+    if kind == 3:
+        a = rng.integers(0, 256, (h + 8, w + 8)).astype(np.float64)
+        k = np.ones(5) / 5
+        a = np.apply_along_axis(lambda r: np.convolve(r, k, "same"), 1, a)
+        a = np.apply_along_axis(lambda c: np.convolve(c, k, "same"), 0, a)
+        a = np.clip((a - a.mean()) * 4 + 128, 0, 255).astype(np.uint8)
+        return np.ascontiguousarray(a[:h, :w]), np.ascontiguousarray(a[2:h + 2, 5:w + 5])
+    if kind == 4:
+        s = int(rng.choice([4, 7, 8, 16]))
+        yy, xx = np.mgrid[0:h, 0:w]
+        a = (((yy // s + xx // s) & 1) * int(rng.choice([60, 200])) + 20).astype(np.uint8)
+        return a, np.roll(a, 1, axis=0)
+    a, b = vislam.synth_frame(canvas, t, w, h), vislam.synth_frame(canvas, t + 1, w, h)
+    a = a.copy(); b = b.copy()
+    for _ in range(3):
+        y0, x0 = int(rng.integers(0, h - 8)), int(rng.integers(0, w - 8))
+        a[y0:y0 + h // 3, x0:x0 + w // 3] = int(rng.integers(0, 256)); b[y0:y0 + h // 3, x0:x0 + w // 3] = a[y0, x0]
+    return a, b
+
+
+t_end = time.time() + budget
+runs = fails = 0
+while time.time() < t_end:
+    w = int(rng.choice([96, 150, 188, 320, 321, 500, 641, 752, 1000])); h = int(rng.choice([64, 110, 120, 240, 243, 375, 479, 480, 600]))
+    p = vislam.default_params()
+    p.w_size, p.h_size = w, h
+    p.nfeatures = int(rng.choice([20, 100, 300, 500, 1000, 1000, 3000]))
+    p.nlevels = int(rng.choice([1, 2, 3, 5, 8, 8]))
+    p.scale_factor = float(rng.choice([1.2, 1.2, 1.1, 1.5, 2.0]))
+    p.fast_threshold = int(rng.choice([5, 10, 20, 20, 40]))
+    p.edge_threshold = int(rng.choice([22, 31, 31, 40]))
+    p.sym_mode = int(rng.integers(0, 2))
+    # the smallest level must still hold the border twice over (the reference's own requirement on its inputs)
+    sc = p.scale_factor ** (p.nlevels - 1)
+    if min(w, h) / sc < 2 * p.edge_threshold + 8:
+        continue
+    a, b = content(w, h)
+    what = "set_params"
+    try:
+        ctx.set_params(p)
+        what = "detect"
+        k0, d0 = ctx.orb_detect_compute(a, slot=0)
+        k1, d1 = ctx.orb_detect_compute(b, slot=1)
+        ok0, od0 = orc.orb_detect_compute(p, a)
+        ok1, od1 = orc.orb_detect_compute(p, b)
+        ok = k0.tobytes() == ok0.tobytes() and k1.tobytes() == ok1.tobytes() and d0.tobytes() == od0.tobytes() and d1.tobytes() == od1.tobytes()
+        if ok and len(k0) and len(k1):
+            what = "knn"
+            g12, g21 = ctx.bf_knn2_hamming(0, 1, len(k0), len(k1))
+            o12, o21 = orc.knn2_hamming(d0, d1)
+            ok = g12.tobytes() == o12.tobytes() and g21.tobytes() == o21.tobytes()
+            if ok:
+                what = "filters"
+                good, sym = ctx.good_matches(0, 1)
+                og, osym = orc.good_matches(p, k0, k1, o12, o21)
+                ok = sym.tobytes() == osym.tobytes() and good.tobytes() == og.tobytes()
+        if ok and min(w, h) >= 32:
+            what = "half pyramid"
+            got = ctx.camera_update(a)
+            want = orc.half_pyramid(a)
+            ok = len(got) == len(want) and all(np.array_equal(x, y) for x, y in zip(got, want))
+    except Exception as e:                                       # an error code is a failure here: every drawn configuration is valid
+        ok = False
+        what += " raised " + repr(e)[:200]
+    runs += 1
+    if not ok:
+        fails += 1
+        print("FAIL at", what, dict(w=w, h=h, n=p.nfeatures, levels=p.nlevels, sf=p.scale_factor, fast=p.fast_threshold, edge=p.edge_threshold,
+                                    sym=p.sym_mode), flush=True)
+print(f"stress_detect: {runs} configurations, {fails} failures, seed {seed0}")
+ctx.close()
+sys.exit(1 if fails else 0)
