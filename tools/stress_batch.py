@@ -36,6 +36,11 @@ while time.time() < t_end:
     p.ransac_threshold = float(rng.choice([0.5, 1.0, 1.0, 2.0]))
     # (pose_input stays VIS_POSE_GRID: the oracle's per-frame pipeline models the reference's, which has no other)
     n = int(rng.integers(3, 28))
+    if rng.random() < 0.05:                                      # a long stream with the adaptive stop off: a work list beyond the resident grid of
+        w, h = 320, 240                                          # the roots kernel (its items are claimed from a counter), ~10 s of oracle time
+        p.w_size, p.h_size, p.nfeatures, p.nlevels = w, h, 200, 5
+        p.ransac_adaptive, p.ransac_max_iters = 0, 1000
+        n = int(rng.integers(150, 200))
     par = bool(rng.integers(0, 2))
     t0 = int(rng.integers(0, 300)); step = int(rng.choice([1, 1, 2, 5]))
     frames = []
