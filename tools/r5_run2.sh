@@ -1,0 +1,5 @@
+set -x
+cd $GRAFT_REPO_ROOT
+timeout -k 10 400 python -m pytest tests/test_detect_gpu.py tests/test_edge_cases_gpu.py tests/test_pipeline_determinism_gpu.py -x -q -m gpu > gpurun_out/r5c_detect.log 2>&1 && \
+bash tools/multi_bench.sh 2 vi-slam_amd/lib/libvislam_hip_r4.so vi-slam_amd/lib/libvislam_hip.so > gpurun_out/r5c_ab.log 2>&1
+tail -3 gpurun_out/r5c_detect.log; cat gpurun_out/r5c_ab.log

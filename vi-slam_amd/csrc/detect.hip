@@ -268,26 +268,49 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_fast
-#define FT_W VIS_FT_W
-#define FT_H VIS_FT_H
-#define PX_XO 16             // the LDS pixel tile starts 16 px left of the tile: rows are whole 16-byte vectors
-#define PX_W (FT_W + 32)     // 160 bytes per LDS pixel row (needs 3 ring + 1 NMS halo each side)
-#define PX_H (FT_H + 8)
-#define SC_W (FT_W + 2)
-#define SC_H (FT_H + 2)
-#define SC_S (FT_W + 4)      // LDS score row stride
+// k_fast: streaming FAST-9/16 + 3x3 NMS, one WAVE per two strip segments ("items"), no workgroup barrier.
+//
+// An item is a strip of 32 lanes x 4 pixels (one dword per lane and row) that a half wave marches down, 8 score rows per chunk, at
+// most VIS_FS_NCH chunks.  Everything between the image and the candidate slot is private to the wave:
+//   * rows arrive as ONE coalesced dword load per lane and row, requested a whole chunk (8 rows) ahead; the raw dword goes into a
+//     16-row LDS ring (for the score phase), its 7-bit reduction stays in registers: a row is reduced once and serves as the lower,
+//     the centre and the upper row of the axis pretest of three different score rows (the tiled kernel read five LDS dwords and
+//     reduced five operands per 4-pixel unit);
+//   * the east / west operands of the pretest come from the neighbour lanes (DPP wave shifts) -- no LDS access in the pretest at all;
+//   * the pass bits of a chunk (8 rows x 4 pixels) are one 32-bit register per lane; the set bits are compacted into an LDS queue
+//     (wave-wide prefix sum, no atomics), scored densely (cornerScore<16>, both polarities in one packed chain) into a 16-row score
+//     ring, and the 3x3 NMS + border cull runs over the queue one row behind the scores (the last row of a pass is carried to the next).
+// Per 4-pixel unit and row: 1 global load, 1 LDS store, ~24 vector instructions for the pretest (the tiled kernel: 2.5 LDS stores,
+// 5 LDS loads, ~41 vector instructions plus a quarter of its instructions in the tile load / clear / halo bookkeeping).
+// Results are the tiled kernel's: the pretest is the same necessary condition, cornerScore and the NMS are unchanged, candidate
+// order inside a slot is irrelevant (k_select sorts).
+#define FS_LANES 32
+#define FS_ROWB 256                              // bytes per ring row: 64 lanes x 4 pixels
+#define FS_RING 16                               // pixel / score ring rows (two chunks of 8)
+#define FS_MIRROR 6                              // ring rows 0..5 are stored a second time behind row 15: a 7-row window never wraps
+#define FS_QCAP 512                              // queue entries per pass (a chunk with more passers is worked through 2 rows at a time)
+#define FS_PX_BYTES ((FS_RING + FS_MIRROR) * FS_ROWB)
+#define FS_SC_BYTES (FS_RING * FS_ROWB)
+#define FS_Q_BYTES ((FS_QCAP + 64) * 2)          // + one scratch entry per lane (branch-free append)
+#define FS_CAR_BYTES (2 * 256 * 2)               // two carry lists (ping-pong): the passers of one score row
+#define FS_WAVE_LDS (FS_PX_BYTES + FS_SC_BYTES + FS_Q_BYTES + FS_CAR_BYTES)
+#define TILE_CAND_CAP VIS_TILE_CAND_CAP
+static_assert(FS_LANES * 4 - 8 == VIS_FS_EMIT_W, "strip geometry (geometry.cpp)");
+static_assert(2 * 4 * FS_LANES <= FS_QCAP, "two rows of passers fit the queue");
 
 // full cornerScore<16> without the early exit (callers have already thinned the candidates).  Both polarities
 // run in one v_pk_*_i16 chain: X[k] = (v - p_k, p_k - v); the minimum over 9 consecutive X picks the dark-arc
 // margin in the low half and minus the bright-arc maximum in the high half, so
 //   max_k min9(X).lo = A (cv::cornerScore's a0),  max_k min9(X).hi = -b0,  score = max(a0, -b0) - 1.
+// c0 = the pixel 3 rows above and 3 columns left of the centre (all offsets are non-negative immediates), S = row stride.
 typedef short pk16 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int fast_score16_full(const uint8_t* c, int t) {
-    const int S = PX_W;
-    const uint32_t v = c[0];
-    const int off[16] = {3 * S, 3 * S + 1, 2 * S + 2, S + 3, 3, -S + 3, -2 * S + 2, -3 * S + 1,
-                         -3 * S, -3 * S - 1, -2 * S - 2, -S - 3, -3, S - 3, 2 * S - 2, 3 * S - 1};
+template <int S>
+__device__ __forceinline__ int fast_score16_full(const uint8_t* c0, int t) {
+    const uint32_t v = c0[3 * S + 3];
+#define RO(dy, dx) ((3 + (dy)) * S + 3 + (dx))
+    const int off[16] = {RO(3, 0), RO(3, 1), RO(2, 2), RO(1, 3), RO(0, 3), RO(-1, 3), RO(-2, 2), RO(-3, 1),
+                         RO(-3, 0), RO(-3, -1), RO(-2, -2), RO(-1, -3), RO(0, -3), RO(1, -3), RO(2, -2), RO(3, -1)};
+#undef RO
     pk16 X[16], m2[16], m4[16];
     // X[k] = (v - p_k, p_k - v) in ONE instruction per ring pixel: v_pk_mad_i16 (p_k, p_k) * (-1, +1) + (v, -v); the ring byte is
     // used as loaded (both halves of the product read its low half: op_sel), no (v, p_k) register has to be assembled first
@@ -295,7 +318,7 @@ __device__ __forceinline__ int fast_score16_full(const uint8_t* c, int t) {
     const uint32_t sgn = 0x0001FFFFu;                                                  // (-1, +1)
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const uint32_t pk = c[off[k]];
+        const uint32_t pk = c0[off[k]];
         uint32_t x;
         asm("v_pk_mad_i16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(x) : "v"(pk), "s"(sgn), "v"(vpair));
         X[k] = __builtin_bit_cast(pk16, x);
@@ -312,57 +335,29 @@ __device__ __forceinline__ int fast_score16_full(const uint8_t* c, int t) {
     return s >= t ? s : 0;
 }
 
-// cheap necessary condition on the two axis pairs of the ring (N/S and E/W): a 9-arc contains at least one pixel of
-// every opposite pair, so both pairs must show a pixel darker than v-t (or both a pixel brighter than v+t).
-__device__ __forceinline__ bool fast_pretest(const uint8_t* c, int t) {
-    const int S = PX_W;
-    const int v = c[0];
-    const int n = v - c[3 * S], so = v - c[-3 * S], e = v - c[3], w = v - c[-3];
-    const int mn = min(max(n, so), max(e, w));
-    const int mx = max(min(n, so), min(e, w));
-    return mn > t || mx < -t;
-}
+// LDS traffic inside ONE wave is processed in issue order; only the compiler must be kept from
+// reordering the accesses (waves of a block use disjoint LDS regions).
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+                         __builtin_amdgcn_wave_barrier();                        \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
-// ---- packed (2 x 16 bit) pretest on 4 horizontally adjacent pixels held as the 4 bytes of a dword.
-// Lanes of a register = pixels (px0, px2) "even" resp. (px1, px3) "odd": centre / north / south operands are then plain
-// full-rate and / shift extractions of the aligned dwords, only the east / west operands need a v_perm_b32.
-// The test is the axis half of fast_pretest(): both opposite pairs (N,S) and (E,W) must show a pixel darker than v-t
-// (or both a pixel brighter than v+t) -- still a necessary condition for a 9-arc, 6 LDS dword reads, 8 v_perm and 16
-// packed min/max fewer per 4 pixels than the 8-pixel version, at the price of 30 % more candidates for the dense
-// cornerScore (which runs in whole 256-entry rounds: 336 -> 444 entries per tile are still two rounds).
-__device__ __forceinline__ pk16 as_pk(uint32_t v) { return __builtin_bit_cast(pk16, v); }
-__device__ __forceinline__ pk16 pmin(pk16 a, pk16 b) { return __builtin_elementwise_min(a, b); }
-__device__ __forceinline__ pk16 pmax(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
-// bytes i and j of the 8-byte string hi:lo as 2 x u16
-#define PICKB(hi, lo, i, j) as_pk(__builtin_amdgcn_perm((hi), (lo), 0x0c000c00u | (uint32_t)(i) | ((uint32_t)(j) << 16)))
+// one record per k_fast wave (two items of one level; an odd item count leaves the last wave's second half idle: nch = 0), built
+// once per plan: everything a wave needs arrives with one 64-byte scalar load
+struct FastWave {
+    const uint8_t* img;          // level image (nullptr: level 0 = the batch of the call)
+    uint32_t* cand;              // level candidate slots
+    uint32_t frame_bytes;        // bytes per frame of the level image
+    int32_t stride;
+    uint32_t wh;                 // w | h << 16
+    int32_t x0[2];               // pixel column of lane 0 of the half (dword aligned; its first emitting column is x0 + 4)
+    int32_t y0[2];               // first score row of the half (its first emitting row is y0 + 1)
+    uint32_t nl;                 // chunks of half 0 | chunks of half 1 << 8 | level << 16
+    uint32_t ntiles;             // items of the level
+    uint32_t tile[2];            // item index inside the level
+    uint32_t tile_base;          // first global item index of the level (tile_cnt)
+};
+static_assert(sizeof(FastWave) == 64, "FastWave is read as s_load_dwordx16");
 
-// > t in a half <=> that pixel passes
-__device__ __forceinline__ pk16 pretest_axis(pk16 c, pk16 n, pk16 so, pk16 e, pk16 w) {
-    const pk16 mx = pmax(pmin(n, so), pmin(e, w));     // dark arc: every pair has a ring pixel < c - t
-    const pk16 mn = pmin(pmax(n, so), pmax(e, w));     // bright arc: every pair has a ring pixel > c + t
-    return pmax(c - mx, mn - c);
-}
-
-// one record per FAST tile of the pyramid (all levels), built once per plan: everything a workgroup needs arrives with one
-// pair of scalar loads instead of a level search + two integer divisions in SALU code
-struct FastTile { const uint8_t* img; uint32_t* cand; uint32_t frame_bytes; int w, h, stride, ox, oy; uint32_t ntiles_tile; int level; };   // ntiles_tile = ntiles << 16 | tile
-static_assert(sizeof(FastTile) == 48, "FastTile is read as s_load_dwordx8 + x4");
-#ifndef FAST_SPARSE_MAX
-#define FAST_SPARSE_MAX 6                   // fullest lane of a wave up to which the queue append walks set bits (fast_tile)
-#endif
-#define TILE_CAND_CAP (FT_W * FT_H / 4)     // 3x3 NMS bound per FT_W x FT_H tile: a tile's slot can never overflow
-
-// ONE launch for all pyramid levels of all frames.  Grid (8, tiles, ceil(frames / 8)): blockIdx.x is the XCD the workgroup
-// lands on (workgroups are dealt to the 8 XCDs round-robin in x-fastest order), so all tiles of frame 8 z + x meet in one L2
-// -- the same placement as xcd_frame_map() without its integer divisions.  Phases: (A) pixel tile + halo -> LDS with 16-byte
-// loads, (B) pretest on every score position, survivors are compacted into an LDS queue, (C) dense full cornerScore on the
-// queue, (D) 3x3 NMS + border cull on the scored survivors -> packed candidates in the tile's own slot.
-#ifdef VIS_FAST_PROFILE                     // diagnostic build (make EXTRA=-DVIS_FAST_PROFILE): s_memtime stamps between the phases
-#define FAST_STAMP_SLOTS (1 << 20)          // workgroups of the largest stamped launch
-#define FAST_STAMP(i) do { if (stamps && tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tdelta[i] = (unsigned)(t_ - tprev); tprev = t_; } } while (0)
-#else
-#define FAST_STAMP(i) do { } while (0)
-#endif
 // Speculative threshold (batched streams).  KeyPointsFilter::retainBest(2 * quota) keeps, per level, the corners whose score
 // reaches a cut that is far above the FAST threshold t (S-752: 61..82 against t = 20) and moves little from frame to frame.  A
 // corner below the cut is neither kept nor able to suppress a kept one in the 3x3 NMS (strict >), so FAST may run with ANY
@@ -370,252 +365,274 @@ static_assert(sizeof(FastTile) == 48, "FastTile is read as s_load_dwordx8 + x4")
 // the previous batch's cuts (k_tau_update: min over the frames - margin); k_select VERIFIES it per (frame, level): fewer than
 // 2 * quota candidates at tau > t means the prediction was too high there -> that (frame, level) goes on a device work list and is
 // redone at t by k_fast_fix / k_select_fix.  Exact for every input; only the speed depends on how coherent the stream is.
-__device__ __forceinline__ void fast_tile(const FastTile& V, const uint8_t* __restrict__ frames0, int total_tiles, int f, int gtile,
-                                          int threshold, int edge, int32_t* __restrict__ tile_cnt, unsigned long long* __restrict__ stamps) {
-    __shared__ __attribute__((aligned(16))) uint32_t px[PX_H * PX_W / 4];
-    __shared__ __attribute__((aligned(16))) uint8_t sc[(SC_H * SC_S + 15) / 16 * 16];
-    __shared__ uint16_t queue[SC_H * SC_W + 64];        // + one scratch word per lane (branch-free append)
-    __shared__ int lcount, qn;
-    const int tid = threadIdx.x;
-    const int ox = V.ox, oy = V.oy, w = V.w, h = V.h, stride = V.stride;
-    // tiles that cannot emit (entirely inside the culled border) do nothing
-    if (ox + FT_W <= edge || ox >= w - edge || oy + FT_H <= edge || oy >= h - edge) return;
+__device__ __forceinline__ void fast_wave(const FastWave& V, const uint8_t* __restrict__ frames0, int total_tiles, int f,
+                                          int threshold, int edge, int32_t* __restrict__ tile_cnt, unsigned char* __restrict__ lds) {
+    typedef __attribute__((address_space(3))) uint16_t lds_u16;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int hh = lane >> 5, lq = lane & (FS_LANES - 1);
+    const int w = (int)(V.wh & 0xFFFFu), h = (int)(V.wh >> 16), stride = V.stride;
+    const int nch0 = (int)(V.nl & 0xFFu), nch1 = (int)((V.nl >> 8) & 0xFFu);
+    const int nchunks = max(nch0, nch1);                                       // wave-uniform
+    const int x0 = hh ? V.x0[1] : V.x0[0], y0 = hh ? V.y0[1] : V.y0[0], nch = hh ? nch1 : nch0;
     const uint8_t* base = (V.img ? V.img : frames0) + (size_t)f * V.frame_bytes;       // level 0 is the caller's batch
-    // every tile owns a fixed slot of TILE_CAND_CAP candidates: no returning atomics, no cross-tile ordering
-    uint32_t* slot = V.cand + ((size_t)f * (V.ntiles_tile >> 16) + (V.ntiles_tile & 0xFFFFu)) * TILE_CAND_CAP;
-    if (tid == 0) { lcount = 0; qn = 0; }
-#ifdef VIS_FAST_PROFILE
-    unsigned long long tprev = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    unsigned tdelta[6] = {0, 0, 0, 0, 0, 0};
-#endif
-    // tile + halo -> LDS: 10 x 16-byte vectors per row (rows start 16 px left of the tile so every vector
-    // is aligned in memory when stride % 16 == 0; otherwise dword loads)
-    if ((stride & 15) == 0) {
-        // both vectors of a thread are in flight before the first LDS store
-        static_assert(PX_H * (PX_W / 16) <= 512, "two vectors per thread");
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 v[2];
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int i = tid + 256 * k;
-            const int r = i / (PX_W / 16), c4 = i - r * (PX_W / 16);
-            const int gx = ox - PX_XO + c4 * 16, gy = oy - 4 + r;
-            v[k] = u32x4{0u, 0u, 0u, 0u};
-            if (i < PX_H * (PX_W / 16) && gy >= 0 && gy < h && gx >= 0 && gx + 15 < stride)
-                v[k] = *(const __attribute__((address_space(1))) u32x4*)(uintptr_t)(base + (size_t)gy * stride + gx);   // global, not flat: the level-0 select hides the address space
-        }
-#pragma unroll
-        for (int k = 0; k < 2; k++)
-            if (tid + 256 * k < PX_H * (PX_W / 16)) reinterpret_cast<u32x4*>(px)[tid + 256 * k] = v[k];
-    } else {
-        for (int wv = tid; wv < PX_H * (PX_W / 4); wv += 256) {
-            const int r = wv / (PX_W / 4), cw = wv % (PX_W / 4);
-            const int gx = ox - PX_XO + cw * 4, gy = oy - 4 + r;
-            uint32_t v = 0;
-            if (gy >= 0 && gy < h && gx >= 0 && gx + 3 < stride)
-                v = *(const __attribute__((address_space(1))) uint32_t*)(uintptr_t)(base + (size_t)gy * stride + gx);
-            px[wv] = v;
-        }
-    }
-    for (int i = tid; i < (SC_H * SC_S + 15) / 16; i += 256) reinterpret_cast<uint4*>(sc)[i] = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();
-    FAST_STAMP(0);
-    const uint8_t* pxb = reinterpret_cast<const uint8_t*>(px);
+    const int xpix = x0 + 4 * lq;
+    const uint32_t coff = (uint32_t)min(xpix, stride - 4);                     // (a lane beyond the row holds no valid position)
     // real scores are needed one pixel beyond the emit region (NMS neighbours), nowhere else
     const int lox = max(3, edge - 1), hix = min(w - 3, w - edge + 1);
     const int loy = max(3, edge - 1), hiy = min(h - 3, h - edge + 1);
-    {
-        // score columns 1..128 (the tile's own columns): unit = 4 adjacent positions whose centre pixels are one aligned LDS
-        // dword; 34 rows x 32 units, 8 rows per iteration, the unit column of a thread is fixed (256 % 32 == 0).
-        //
-        // Byte-SWAR pretest on plain 32-bit integer instructions (4 pixels per instruction, the full-rate class: add / sub /
-        // and / or / shift) instead of 2 pixels per half-rate v_pk_*_i16.  Pixels are reduced to 7 bits (p >> 1), so bit 7 of
-        // every byte is free to hold the sign of a per-byte difference.  With K = ceil(t / 2):
-        //     ring pixel darker than c - t    =>  c7 - r7 >= K        ring pixel brighter than c + t  =>  r7 - c7 >= K
-        // (necessary conditions: the test may pass more pixels than the exact one, never fewer; cornerScore decides.)
-        //     cD = c7 + (128 - (K-1))   per byte, no carry        D = cD - r7:  bit 7 set <=> c7 - r7 >= K-1   ("dark")
-        //     B  = D + (2K-3):  bit 7 CLEAR <=> r7 - c7 >= K-1 + (0 or 1)                                         ("bright")
-        // A byte whose subtraction wraps (|difference| > 118) borrows 1 from / carries 1 into its left neighbour: the tests
-        // use K-1 resp. 2K-3 instead of K and 2K-2, which absorbs exactly that unit, and the wrapped byte itself reads
-        // "pass".  tests/test_independent_numpy.py replays these formulas in numpy exhaustively over (c, r, t).
-        // The axis test itself is unchanged: both opposite pairs (N,S) and (E,W) must show a dark pixel, or both a bright one.
-        const int q = tid & (FT_W / 4 - 1);
-        const int gx0 = ox + 4 * q;                                      // image x of position sx = 4q+1
-        uint32_t capmask = 0;                                            // bit 7 of byte j: position j of the unit is inside the x range
+    // valid positions of the lane: byte j of colbits is all ones when pixel j may be scored.  The west operand of the first lane's
+    // pixels 0..2 and the east operand of the last lane's pixels 1..3 lie outside the strip.
+    uint32_t colbits = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) capmask |= (gx0 + j >= lox && gx0 + j < hix) ? (0x80u << (8 * j)) : 0u;
-        const int sy_lo = max(0, loy - (oy - 1)), sy_hi = min(SC_H, hiy - (oy - 1));     // valid score rows of this tile
-        const int lane = tid & 63;
-        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const uint32_t HB = 0x80808080u, M7 = 0x7f7f7f7fu;
-        const int K = (threshold + 1) >> 1;
-        const bool swar = K >= 3 && K <= 128;                            // t < 5: every position goes to cornerScore
-        const uint32_t kD = HB - (uint32_t)(K - 1) * 0x01010101u;
-        const uint32_t kB = (uint32_t)(2 * K - 3) * 0x01010101u;
-        const uint32_t passall = swar ? 0u : 0xFFFFFFFFu;
-        constexpr int NIT = (SC_H + 7) / 8;
-        static_assert(NIT <= 8, "one mask byte per pixel of the unit");
-        uint32_t pm[NIT];                                                // pass bits of the thread's unit in iteration it (bits 7, 15, 23, 31)
-        uint32_t mask = 0;                                               // the same bits in ONE register
+    for (int j = 0; j < 4; j++) {
+        const bool ok = xpix + j >= lox && xpix + j < hix && (lq > 0 || j == 3) && (lq < FS_LANES - 1 || j == 0);
+        colbits |= ok ? (0xFFu << (8 * j)) : 0u;
+    }
+    const int rlo = max(0, loy - y0), rhi = min(hiy - y0, 8 * nch);            // valid score rows of the half: y0 + [rlo, rhi)
+    // LDS of this wave
+    uint32_t* const px32 = reinterpret_cast<uint32_t*>(lds);
+    const uint8_t* const pxb = lds;
+    uint8_t* const sc = lds + FS_PX_BYTES;
+    uint16_t* const Q = reinterpret_cast<uint16_t*>(lds + FS_PX_BYTES + FS_SC_BYTES);
+    uint16_t* const CAR = Q + FS_QCAP + 64;
+    // rows: load chunk k = rows y0 - 5 + 8 k .. + 7 of the half (ring slots 8 (k & 1) ..).  Score row q of chunk c (q = 8 c + r) has its
+    // centre in ring row q + 5, i.e. it needs load chunks c (last 6 rows) and c + 1.
+    const uint32_t voff_max = (uint32_t)((h - 1) * stride) + coff;
+    uint32_t voff = (uint32_t)(max(y0 - 5, 0) * stride) + coff;
+    auto ld = [&](uint32_t o) -> uint32_t {
+        return *(const __attribute__((address_space(1))) uint32_t*)(uintptr_t)(base + (size_t)o);   // global, not flat: the level-0 select hides the address space
+    };
+    // (rows below the image -- the chunk requested behind a segment's last one, the shorter half of a wave -- repeat the last row:
+    // one v_min per row; nothing reads them as a valid position)
+    auto load8 = [&](uint32_t (&d)[8]) {
 #pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            pm[it] = 0;
-            const int wr = it * 8 + 2 * wv;                              // the wave's row pair: wr (lanes 0..31), wr + 1 (lanes 32..63)
-            if (wr < sy_hi && wr + 1 >= sy_lo) {
-                const int sy = it * 8 + (tid >> 5);
-                uint32_t cm = capmask;
-                if (wr < sy_lo || wr + 1 >= sy_hi) cm = (sy >= sy_lo && sy < sy_hi) ? cm : 0u;
-                const uint32_t* r0 = px + (sy + 3) * (PX_W / 4) + q + (PX_XO / 4 - 1);   // r0[1] = the 4 centre pixels
-                const uint32_t c0 = r0[0], Cc = r0[1], c2 = r0[2];
-                const uint32_t Nn = r0[3 * (PX_W / 4) + 1], Ss = r0[-3 * (PX_W / 4) + 1];
-                const uint32_t Ee = __builtin_amdgcn_alignbyte(c2, Cc, 3);               // +3 px: bytes 3..6 of c2:C
-                const uint32_t Ww = __builtin_amdgcn_alignbyte(Cc, c0, 1);               // -3 px: bytes 1..4 of C:c0
-                const uint32_t cD = ((Cc >> 1) & M7) + kD;
-                const uint32_t dn = cD - ((Nn >> 1) & M7), ds = cD - ((Ss >> 1) & M7);
-                const uint32_t de = cD - ((Ee >> 1) & M7), dw = cD - ((Ww >> 1) & M7);
+        for (int i = 0; i < 8; i++) { d[i] = ld(min(voff, voff_max)); voff += (uint32_t)stride; }
+    };
+    const uint32_t M7 = 0x7f7f7f7fu;
+    uint32_t old[8], nw[8], nxt[8];
+    load8(old);
+    load8(nw);
+    load8(nxt);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        px32[i * 64 + lane] = old[i];
+        if (i < FS_MIRROR) px32[(FS_RING + i) * 64 + lane] = old[i];
+        px32[(8 + i) * 64 + lane] = nw[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) { old[i] = (old[i] >> 1) & M7; nw[i] = (nw[i] >> 1) & M7; }
+    // Byte-SWAR axis pretest on plain 32-bit integer instructions (4 pixels per instruction, the full-rate class).  Pixels are reduced
+    // to 7 bits (p >> 1), so bit 7 of every byte is free to hold the sign of a per-byte difference.  With K = ceil(t / 2):
+    //     ring pixel darker than c - t    =>  c7 - r7 >= K        ring pixel brighter than c + t  =>  r7 - c7 >= K
+    // (necessary conditions: the test may pass more pixels than the exact one, never fewer; cornerScore decides.)
+    //     cD = c7 + (128 - (K-1))   per byte, no carry        D = cD - r7:  bit 7 set <=> c7 - r7 >= K-1   ("dark")
+    //     B' = ~(D + (2K-3)) = ~(2K-3) - D:  bit 7 SET <=> r7 - c7 >= K-1 + (0 or 1)                           ("bright")
+    // A byte whose subtraction wraps (|difference| > 118) borrows 1 from / carries 1 into its left neighbour: the tests
+    // use K-1 resp. 2K-3 instead of K and 2K-2, which absorbs exactly that unit, and the wrapped byte itself reads
+    // "pass".  tests/test_independent_numpy.py replays these formulas in numpy exhaustively over (c, r, t).
+    // The axis test: both opposite pairs (upper, lower) and (east, west) must show a dark pixel, or both a bright one.
+    const int K = (threshold + 1) >> 1;
+    const bool swar = K >= 3 && K <= 128;                                      // t < 5: every position goes to cornerScore
+    const uint32_t kD = 0x80808080u - (uint32_t)(K - 1) * 0x01010101u;
+    const uint32_t nkB = ~((uint32_t)(2 * K - 3) * 0x01010101u);
+    const uint32_t lane5 = (uint32_t)lane << 5;
+    const uint32_t q_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)Q;          // LDS byte address
+    const uint32_t a_scr = q_base + 2u * (uint32_t)(FS_QCAP + lane);
+    // candidate slots of the two items and their fill
+    uint32_t* const candf = V.cand + (size_t)f * V.ntiles * TILE_CAND_CAP;
+    int cnt0 = 0, cnt1 = 0;                                                     // wave-uniform
+    int ncar = 0, qcar = 0, cur = 0;                                            // carried passers: count, their score row, list in use
+    WAVE_SYNC();
+    for (int c = 0; c < nchunks; c++) {
+        uint32_t mask = 0xFFFFFFFFu;                                            // bit 8 j + r: pixel j of score row 8 c + r passes
+        if (swar) {
+            mask = 0;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t Cc = r < 3 ? old[r + 5] : nw[r - 3];
+                const uint32_t Up = r < 6 ? old[r + 2] : nw[r - 6];
+                const uint32_t Lo = nw[r];
+                const uint32_t cl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Cc, 0x138, 0xF, 0xF, true);    // wave_shr:1: lane i <- lane i - 1
+                const uint32_t cr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Cc, 0x130, 0xF, 0xF, true);    // wave_shl:1: lane i <- lane i + 1
+                const uint32_t Ee = __builtin_amdgcn_alignbyte(cr, Cc, 3);       // +3 px: bytes 3..6 of cr:Cc
+                const uint32_t Ww = __builtin_amdgcn_alignbyte(Cc, cl, 1);       // -3 px: bytes 1..4 of Cc:cl
+                const uint32_t cD = Cc + kD;
+                const uint32_t dn = cD - Up, ds = cD - Lo, de = cD - Ee, dw = cD - Ww;
+                const uint32_t bn = nkB - dn, bs = nkB - ds, be = nkB - de, bw = nkB - dw;
                 const uint32_t dark = (dn | ds) & (de | dw);
-                const uint32_t nbright = ((dn + kB) & (ds + kB)) | ((de + kB) & (dw + kB));   // bit 7 set: a pair without a bright pixel
-                const uint32_t pass = (dark | ~nbright | passall) & cm;
-                pm[it] = pass;
-                mask |= (pass >> (7 - it)) & (0x01010101u << it);         // bit 8 j + it: pixel j of iteration it
-
+                const uint32_t pass = ((bn | bs) & (be | bw)) | dark;             // bit 7 of byte j: pixel j passes
+                mask |= (r == 7 ? pass : (pass >> (7 - r))) & (0x01010101u << r);
             }
         }
-        int n = __popc(mask);                                            // candidates of this thread
-        // halo score columns 0 and 129 (NMS neighbours of the first/last tile column): byte-wise test by the first 2*SC_H threads
-        bool hp = false;
-        int hpos = 0;
-        if (tid < 2 * SC_H) {
-            const int sy = tid >> 1, sx = (tid & 1) ? SC_W - 1 : 0;
-            const int gx = ox - 1 + sx, gy = oy - 1 + sy;
-            hp = gy >= loy && gy < hiy && gx >= lox && gx < hix && fast_pretest(pxb + (sy + 3) * PX_W + (sx + PX_XO - 1), threshold);
-            hpos = sy * SC_W + sx;
-            n += hp ? 1 : 0;
+        {
+            // rows of this chunk that may be scored: q = 8 c + r in [rlo, rhi)
+            const int lo_ = min(max(rlo - 8 * c, 0), 8), hi_ = min(max(rhi - 8 * c, 0), 8);
+            const uint32_t rb = ((1u << hi_) - 1u) & ~((1u << lo_) - 1u);
+            mask &= colbits & (rb * 0x01010101u);
         }
-        // Queue append without ballots: wave-wide exclusive prefix sum of the per-thread counts (DPP row shifts + row
-        // broadcasts), ONE LDS reservation per wave, then every thread writes its candidates to consecutive entries.  A
-        // thread whose bit is clear stores into its own scratch entry behind the queue (no exec-mask juggling); the entry
-        // index advances by the bit.  Queue order is irrelevant: k_select sorts.
-        int incl = n;
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);      // row_shr:1
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);      // row_shr:2
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);      // row_shr:4
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);      // row_shr:8
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, true);      // row_bcast:15 -> rows 1, 3
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, true);      // row_bcast:31 -> rows 2, 3
-        const int tot = __builtin_amdgcn_readlane(incl, 63);
-        if (tot) {
-            typedef __attribute__((address_space(3))) uint16_t lds_u16;
-            const uint32_t q_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)queue;      // LDS byte addresses
-            const uint32_t qn_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&qn;
-            uint32_t qb = 0;
-            if (lane == 0)        // one returning LDS add per wave (inline: the compiler's atomic optimizer would wrap it in a second wave reduction)
-                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(qb) : "v"(qn_addr), "v"(tot) : "memory");
-            qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
-            uint32_t a_idx = q_base + 2u * (uint32_t)(qb + incl - n);           // byte address of the thread's next entry
-            const uint32_t a_scr = q_base + 2u * (uint32_t)(SC_H * SC_W + lane);
-            const int pos0 = (tid >> 5) * SC_W + 4 * q + 1;
-            // With the speculative threshold about 3 % of the positions pass (S-752), clustered: a thread has 0 .. 4 candidates, the
-            // fullest lane of a wave 4.4 on average -- a loop over the set bits (11 instructions and ONE store per round, the wave
-            // runs max-over-lanes rounds) then beats the fixed 80 instructions + 20 stores of the dense form below, which stays for
-            // waves with a crowded lane (corner-dense images, the fix-up pass at the base threshold).
-            int nmax = n - (hp ? 1 : 0);
-            nmax = max(nmax, __builtin_amdgcn_update_dpp(0, nmax, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
-            nmax = max(nmax, __builtin_amdgcn_update_dpp(0, nmax, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
-            nmax = max(nmax, __builtin_amdgcn_update_dpp(0, nmax, 0x141, 0xF, 0xF, false));    // row_half_mirror
-            nmax = max(nmax, __builtin_amdgcn_update_dpp(0, nmax, 0x140, 0xF, 0xF, false));    // row_mirror
-            const int wmax = max(max(__builtin_amdgcn_readlane(nmax, 0), __builtin_amdgcn_readlane(nmax, 16)),
-                                 max(__builtin_amdgcn_readlane(nmax, 32), __builtin_amdgcn_readlane(nmax, 48)));
-            if (wmax <= FAST_SPARSE_MAX) {
-                uint32_t m = mask;
-                for (int r = 0; r < wmax; r++) {                                  // wave-uniform trip count
-                    const bool has = m != 0;
-                    const int b = __builtin_ctz(m | 0x80000000u);
-                    m &= m - 1;
-                    const int pos = pos0 + (b & 7) * (8 * SC_W) + (b >> 3);
-                    *(lds_u16*)(uintptr_t)(has ? a_idx : a_scr) = (uint16_t)pos;
-                    a_idx += has ? 2u : 0u;
-                }
-            } else
-#pragma unroll
-            for (int it = 0; it < NIT; it++) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    // 4 instructions per entry.  mk = the sign-extended 2-bit field (pass bit, 0) = -2 / 0: as a v_bfi_b32 mask it
-                    // takes everything but bit 0 from the queue address (both addresses are even), and it is the address step.
-                    const int mk = __builtin_amdgcn_sbfe((int)pm[it], 8 * j + 6, 2);
-                    uint32_t a;
-                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(a) : "v"(mk), "v"(a_idx), "v"(a_scr));
-                    *(lds_u16*)(uintptr_t)a = (uint16_t)(pos0 + it * 8 * SC_W + j);
-                    a_idx -= (uint32_t)mk;
-                }
+        // the score rows of this chunk (ring slots 8 (c & 1) ..) start at zero: positions that are not scored read 0 in the NMS
+        {
+            uint4* z = reinterpret_cast<uint4*>(sc + (c & 1) * (8 * FS_ROWB)) + 2 * lane;
+            z[0] = make_uint4(0u, 0u, 0u, 0u); z[1] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        // passes over the rows of the chunk: all 8 at once, or 2 at a time when the chunk has more passers than the queue holds
+        uint32_t m = mask;
+        int n = __popc(m);
+        auto prefix = [&](int v) -> int {                                       // wave-wide inclusive prefix sum (DPP row shifts + row broadcasts)
+            v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);      // row_shr:1
+            v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);      // row_shr:2
+            v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);      // row_shr:4
+            v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);      // row_shr:8
+            v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);      // row_bcast:15 -> rows 1, 3
+            v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);      // row_bcast:31 -> rows 2, 3
+            return v;
+        };
+        int incl = prefix(n);
+        int tot = __builtin_amdgcn_readlane(incl, 63);
+        const int step = tot > FS_QCAP ? 2 : 8;
+        for (int a = 0; a < 8; a += step) {
+            if (step != 8) {
+                m = mask & (((1u << step) - 1u) << a) * 0x01010101u;
+                n = __popc(m);
+                incl = prefix(n);
+                tot = __builtin_amdgcn_readlane(incl, 63);
             }
-            if (wv < 2) *(lds_u16*)(uintptr_t)(hp ? a_idx : a_scr) = (uint16_t)hpos;    // waves 0 and 1 hold the halo threads
+            const int qlast = 8 * c + a + step - 1;                              // the row whose lower neighbours are not scored yet
+            int nnew = 0;
+            if (tot | ncar) {
+                // (1) queue append without ballots or atomics: every lane writes its passers to consecutive entries behind the lanes before
+                // it; entry = lane << 5 | bit = (4 lane + j) << 3 | r.  A lane that has run out of bits stores into its scratch entry.
+                {
+                    uint32_t a_idx = q_base + 2u * (uint32_t)(incl - n);
+                    uint32_t mm = m;
+                    while (__builtin_amdgcn_ballot_w64(mm != 0u)) {
+                        const bool has = mm != 0u;
+                        const uint32_t b = (uint32_t)__builtin_ctz(mm | 0x80000000u);
+                        mm &= mm - 1u;
+                        *(lds_u16*)(uintptr_t)(has ? a_idx : a_scr) = (uint16_t)(lane5 | b);
+                        a_idx += has ? 2u : 0u;
+                    }
+                }
+                WAVE_SYNC();
+                // (2) dense cornerScore on the queue
+                for (int i0 = 0; i0 < tot; i0 += 64) {
+                    const int i = i0 + lane;
+                    if (i < tot) {
+                        const uint32_t e = Q[i];
+                        const int xl = (int)(e >> 3) & 0xFF, qq = 8 * c + (int)(e & 7u);
+                        // 7 x 7 window: ring rows qq + 2 .. qq + 8 (the centre is ring row qq + 5), columns xl - 3 .. xl + 3
+                        const uint8_t* c0 = pxb + (((qq + 2) & (FS_RING - 1)) * FS_ROWB + xl - 3);
+                        const int s = fast_score16_full<FS_ROWB>(c0, threshold);
+                        sc[(qq & (FS_RING - 1)) * FS_ROWB + xl] = (uint8_t)s;
+                    }
+                }
+                WAVE_SYNC();
+                // (3) 3x3 NMS + border cull over the carried row and this pass's rows but the last, which is carried on
+                const int ntotal = ncar + tot;
+                const int car_rd = FS_QCAP + 64 + cur * 256, car_wr = FS_QCAP + 64 + (cur ^ 1) * 256;       // entry offsets from Q
+                for (int i0 = 0; i0 < ntotal; i0 += 64) {
+                    const int i = i0 + lane;
+                    const bool act = i < ntotal, isc = i < ncar;
+                    const uint32_t e = act ? Q[isc ? car_rd + i : i - ncar] : 0u;
+                    const int xl = (int)(e >> 3) & 0xFF;
+                    const int q = isc ? qcar : 8 * c + (int)(e & 7u);
+                    const uint8_t* p1 = sc + ((q & (FS_RING - 1)) * FS_ROWB + xl);
+                    const uint8_t* p0 = sc + (((q - 1) & (FS_RING - 1)) * FS_ROWB + xl);
+                    const uint8_t* p2 = sc + (((q + 1) & (FS_RING - 1)) * FS_ROWB + xl);
+                    const int s = act ? (int)p1[0] : 0;
+                    const bool later = !isc && q == qlast;
+                    const int half = xl >> 7, xi = xl & 127;
+                    const int gx = (half ? V.x0[1] : V.x0[0]) + xi, gy = (half ? V.y0[1] : V.y0[0]) + q;
+                    const int qmax = 8 * (half ? nch1 : nch0) - 2;
+                    // all eight neighbours at once (a short-circuit chain is up to eight dependent LDS round trips, and this kernel runs at 3-4 waves per SIMD)
+                    const int n0 = p0[-1], n1 = p0[0], n2 = p0[1], n3 = p1[-1], n4 = p1[1], n5 = p2[-1], n6 = p2[0], n7 = p2[1];
+                    const int nmax = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
+                    const bool em = s > nmax && !later && q >= 1 && q <= qmax && xi >= 4 && xi <= 4 * FS_LANES - 5 &&
+                                    gx >= edge && gx < w - edge && gy >= edge && gy < h - edge;      // (s > nmax >= 0: a zero score never emits)
+                    const unsigned long long bm = __builtin_amdgcn_ballot_w64(em);
+                    if (bm) {
+                        const unsigned long long b1 = __builtin_amdgcn_ballot_w64(em && half), b0 = bm & ~b1;
+                        const unsigned long long mine = half ? b1 : b0;
+                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+                        const uint32_t o = (half ? V.tile[1] : V.tile[0]) * TILE_CAND_CAP + (uint32_t)((half ? cnt1 : cnt0) + rank);
+                        if (em) candf[o] = ((uint32_t)s << 24) | ((uint32_t)gy << 12) | (uint32_t)gx;
+                        cnt0 += __popcll(b0); cnt1 += __popcll(b1);
+                    }
+                    const bool cy = s > 0 && later;
+                    const unsigned long long bc = __builtin_amdgcn_ballot_w64(cy);
+                    if (bc) {
+                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bc, 0u));
+                        if (cy) Q[car_wr + nnew + rank] = (uint16_t)e;
+                        nnew += __popcll(bc);
+                    }
+                }
+                WAVE_SYNC();
+                cur ^= 1;
+            }
+            ncar = nnew; qcar = qlast;
+        }
+        // the next chunk's rows: ring slots of the load chunk that is no longer needed, 7-bit copies into the register window, and the
+        // request for the chunk after it.  Unconditional (behind the last chunk the rows are clamped and never used): a load under a
+        // condition gets a register of its own and a copy at the loop's back edge -- which has to WAIT for the load just issued.
+        {
+            const int par = c & 1;
+#pragma unroll
+            for (int i = 0; i < 8; i++) px32[(8 * par + i) * 64 + lane] = nxt[i];
+            if (par == 0) {
+#pragma unroll
+                for (int i = 0; i < FS_MIRROR; i++) px32[(FS_RING + i) * 64 + lane] = nxt[i];
+            }
+            // (the empty asm ties the row offset to the reduced values: the loads below cannot be scheduled in front of the last use of
+            // the registers they are to land in -- otherwise they get registers of their own and a copy behind a vmcnt(0) at the back edge)
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                uint32_t t = (nxt[i] >> 1) & M7;
+                asm volatile("" : "+v"(t), "+v"(voff));
+                old[i] = nw[i]; nw[i] = t;
+            }
+            load8(nxt);
+            WAVE_SYNC();
         }
     }
-    __syncthreads();
-    FAST_STAMP(1);
-    const int nq = qn;
-    for (int i = tid; i < nq; i += 256) {
-        const int pos = queue[i];
-        const int sy = pos / SC_W, sx = pos - sy * SC_W;
-        const int s = fast_score16_full(pxb + (sy + 3) * PX_W + (sx + PX_XO - 1), threshold);
-        sc[sy * SC_S + sx] = (uint8_t)s;
+    if (lane == 0) {
+        int32_t* tc = tile_cnt + (size_t)f * total_tiles + V.tile_base;
+        if (nch0) tc[V.tile[0]] = cnt0;
+        if (nch1) tc[V.tile[1]] = cnt1;
     }
-    __syncthreads();
-    FAST_STAMP(2);
-    for (int i = tid; i < nq; i += 256) {
-        const int pos = queue[i];
-        const int sy = pos / SC_W, sx = pos - sy * SC_W;
-        const int gx = ox - 1 + sx, gy = oy - 1 + sy;
-        if (sx < 1 || sx > FT_W || sy < 1 || sy > FT_H) continue;     // halo positions belong to neighbour tiles
-        const uint8_t* p = sc + sy * SC_S + sx;
-        const int s = p[0];
-        if (s && gx >= edge && gx < w - edge && gy >= edge && gy < h - edge &&
-            s > p[-1] && s > p[1] && s > p[-SC_S - 1] && s > p[-SC_S] && s > p[-SC_S + 1] &&
-            s > p[SC_S - 1] && s > p[SC_S] && s > p[SC_S + 1]) {
-            slot[atomicAdd(&lcount, 1)] = ((uint32_t)s << 24) | ((uint32_t)gy << 12) | (uint32_t)gx;
-        }
-    }
-    __syncthreads();
-    FAST_STAMP(3);
-#ifdef VIS_FAST_PROFILE
-    const unsigned wg = (blockIdx.z * gridDim.y + blockIdx.y) * 8 + blockIdx.x;
-    if (stamps && tid == 0 && wg < FAST_STAMP_SLOTS) {                  // one private record per workgroup: no contention
-        unsigned long long* rec = stamps + (size_t)wg * 8;
-        for (int i = 0; i < 6; i++) rec[i] = tdelta[i];
-        rec[6] = (unsigned long long)nq; rec[7] = 0;
-    }
-#endif
-    if (tid == 0) tile_cnt[(size_t)f * total_tiles + gtile] = lcount;
 }
 
-__global__ __launch_bounds__(256) void k_fast(const FastTile* __restrict__ tiles, const uint8_t* __restrict__ frames0, int total_tiles,
-                                              int threshold, int edge, int32_t* __restrict__ tile_cnt, int nframes,
-                                              unsigned long long* __restrict__ stamps, const int32_t* __restrict__ tau) {
-    const int f = blockIdx.z * 8 + blockIdx.x, gtile = blockIdx.y;
-    if (f >= nframes) return;
-    const FastTile V = tiles[gtile];
-    fast_tile(V, frames0, total_tiles, f, gtile, tau ? tau[V.level] : threshold, edge, tile_cnt, stamps);
+#ifndef FS_WPB
+#define FS_WPB 1                 // waves per workgroup (the waves of a workgroup share nothing)
+#endif
+// ONE launch for all pyramid levels of all frames.  Grid (8, waves / FS_WPB, ceil(frames / 8)): blockIdx.x is the XCD the workgroup
+// lands on (workgroups are dealt to the 8 XCDs round-robin in x-fastest order), so all work of frame 8 z + x meets in one L2
+// -- the same placement as xcd_frame_map() without its integer divisions.
+__global__ __launch_bounds__(64 * FS_WPB) void k_fast(const FastWave* __restrict__ waves, const uint8_t* __restrict__ frames0, int total_tiles, int total_waves,
+                                                       int threshold, int edge, int32_t* __restrict__ tile_cnt, int nframes, const int32_t* __restrict__ tau) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FS_WPB * FS_WAVE_LDS];
+    const int f = blockIdx.z * 8 + blockIdx.x;
+    const int wi = blockIdx.y * FS_WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (f >= nframes || wi >= total_waves) return;
+    const FastWave V = waves[wi];
+    fast_wave(V, frames0, total_tiles, f, tau ? tau[V.nl >> 16] : threshold, edge, tile_cnt, lds + (threadIdx.x >> 6) * FS_WAVE_LDS);
 }
 
 // work list: fix[0] = number of (frame, level) entries, fix[1 + i] = frame * L + level.  A small fixed grid walks
-// (entry, tile of that level) items; with an empty list (the normal case) every workgroup leaves at once.
-struct FixLevels { int tile_base[VIS_MAX_LEVELS], ntiles[VIS_MAX_LEVELS], L, max_tiles; };
-__global__ __launch_bounds__(256) void k_fast_fix(const FastTile* __restrict__ tiles, const uint8_t* __restrict__ frames0, int total_tiles,
-                                                  int threshold, int edge, int32_t* __restrict__ tile_cnt, FixLevels X,
-                                                  const int32_t* __restrict__ fix) {
-    const int items = fix[0] * X.max_tiles;
-    for (int wk = blockIdx.x; wk < items; wk += gridDim.x) {
-        const int e = fix[1 + wk / X.max_tiles], j = wk % X.max_tiles;
+// (entry, wave of that level) items; with an empty list (the normal case) every wave leaves at once.
+struct FixLevels { int wave_base[VIS_MAX_LEVELS], nwaves[VIS_MAX_LEVELS], L, max_waves; };
+__global__ __launch_bounds__(64 * FS_WPB) void k_fast_fix(const FastWave* __restrict__ waves, const uint8_t* __restrict__ frames0, int total_tiles,
+                                                           int threshold, int edge, int32_t* __restrict__ tile_cnt, FixLevels X,
+                                                           const int32_t* __restrict__ fix) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FS_WPB * FS_WAVE_LDS];
+    const int items = fix[0] * X.max_waves;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (int wk = blockIdx.x * FS_WPB + wv; wk < items; wk += gridDim.x * FS_WPB) {
+        const int e = fix[1 + wk / X.max_waves], j = wk % X.max_waves;
         const int f = e / X.L, l = e - f * X.L;
-        if (j < X.ntiles[l]) {                                        // workgroup-uniform
-            const int gtile = X.tile_base[l] + j;
-            const FastTile V = tiles[gtile];
-            if (threadIdx.x == 0) tile_cnt[(size_t)f * total_tiles + gtile] = 0;      // tiles that cannot emit return without a count
-            fast_tile(V, frames0, total_tiles, f, gtile, threshold, edge, tile_cnt, nullptr);
+        if (j < X.nwaves[l]) {                                        // wave-uniform
+            const FastWave V = waves[X.wave_base[l] + j];
+            fast_wave(V, frames0, total_tiles, f, threshold, edge, tile_cnt, lds + wv * FS_WAVE_LDS);
         }
-        __syncthreads();
     }
 }
 
@@ -744,12 +761,6 @@ __global__ __launch_bounds__(256) void k_tau_update(const int32_t* __restrict__ 
 __device__ const float g_pattern[256 * 4] = {
 #include "orb_pattern.inc"
 };
-
-// LDS traffic inside ONE wave is processed in issue order; only the compiler must be kept from
-// reordering the accesses (waves of a block use disjoint LDS regions, some exit early).
-#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
-                         __builtin_amdgcn_wave_barrier();                        \
-                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 struct DescArgs {
     int umax[16];
@@ -1194,59 +1205,43 @@ static void fill_desc_args(const vis_params& p, DescArgs& G, std::vector<uint32_
     }
 }
 
-// diagnostic: with VIS_FAST_STAMPS set in the environment thread 0 of every k_fast workgroup stores its s_memtime deltas
-// between the phase barriers into a private record; vis_debug_fast_stamps sums and clears them (tools/fast_phases.py).
-// Unset (the default): nullptr, no stamp executes.
-#ifdef VIS_FAST_PROFILE
-static unsigned long long* g_fast_stamps = nullptr;
-static unsigned long long* vis_fast_stamps() {
-    static const bool on = getenv("VIS_FAST_STAMPS") != nullptr;
-    if (on && !g_fast_stamps) {
-        if (hipMalloc((void**)&g_fast_stamps, (size_t)FAST_STAMP_SLOTS * 8 * sizeof(unsigned long long)) != hipSuccess) { g_fast_stamps = nullptr; return nullptr; }
-        (void)hipMemset(g_fast_stamps, 0, (size_t)FAST_STAMP_SLOTS * 8 * sizeof(unsigned long long));
-    }
-    return on ? g_fast_stamps : nullptr;
-}
-// out[0..5]: cycles of the phases load / pretest / score / nms / (unused) summed over the workgroups of the launches since the
-// last call, out[6] queue entries, out[8] workgroups
-extern "C" int vis_debug_fast_stamps(unsigned long long out[16]) {
-    if (!g_fast_stamps) return VIS_E_STATE;
-    if (hipDeviceSynchronize() != hipSuccess) return VIS_E_HIP;
-    std::vector<unsigned long long> h((size_t)FAST_STAMP_SLOTS * 8);
-    if (hipMemcpy(h.data(), g_fast_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return VIS_E_HIP;
-    for (int i = 0; i < 16; i++) out[i] = 0;
-    for (size_t b = 0; b < (size_t)FAST_STAMP_SLOTS; b++) {
-        const unsigned long long* r = &h[b * 8];
-        if (r[0] == 0 && r[1] == 0) continue;
-        for (int i = 0; i < 8; i++) out[i] += r[i];
-        out[8]++;
-    }
-    (void)hipMemset(g_fast_stamps, 0, h.size() * sizeof(unsigned long long));
-    return VIS_OK;
-}
-#else
-static unsigned long long* vis_fast_stamps() { return nullptr; }
-extern "C" int vis_debug_fast_stamps(unsigned long long out[16]) { (void)out; return VIS_E_STATE; }   // needs the VIS_FAST_PROFILE build
-#endif
+// (the phase stamps of the tiled k_fast of rounds 1-4 are gone with its workgroup phases; the entry point stays in the ABI)
+extern "C" int vis_debug_fast_stamps(unsigned long long out[16]) { (void)out; return VIS_E_STATE; }
 
-// the per-tile records of k_fast (levels >= 1 point into the plan's pyramid; level 0 is the batch of the call: img = nullptr)
+// the per-wave records of k_fast (levels >= 1 point into the plan's pyramid; level 0 is the batch of the call: img = nullptr).
+// Item i of a level = (segment i / strips, strip i % strips); a wave takes items 2 j and 2 j + 1 of ONE level.
 int build_fast_tiles(vis_ctx* ctx, Plan* pl) {
-    std::vector<FastTile> t((size_t)pl->total_tiles);
+    std::vector<FastWave> t;
     const int e = ctx->p.edge_threshold;
+    const int x00 = (e - 4) & ~3;                       // pixel column of lane 0 of the first strip (vis_compute_levels)
     for (int l = 0; l < pl->L; l++) {
-        const LevelInfo& V = pl->lv[l];
-        if (V.frame_bytes > 0xFFFFFFFFull) return VIS_E_INVALID;
-        for (int i = 0; i < V.tiles_x * V.tiles_y; i++) {
-            FastTile& r = t[(size_t)V.tile_base + i];
+        LevelInfo& V = pl->lv[l];
+        const int items = V.tiles_x * V.tiles_y;
+        if (V.frame_bytes > 0xFFFFFFFFull || items > 65535) return VIS_E_INVALID;
+        V.wave_base = (int)t.size(); V.nwaves = (items + 1) / 2;
+        const int emit_rows = V.h - 2 * e;
+        for (int j = 0; j < V.nwaves; j++) {
+            FastWave r = {};
             r.img = l == 0 ? nullptr : pl->d_pyr[l]; r.cand = pl->d_cand[l]; r.frame_bytes = (uint32_t)V.frame_bytes;
-            r.w = V.w; r.h = V.h; r.stride = V.stride; r.ntiles_tile = ((uint32_t)(V.tiles_x * V.tiles_y) << 16) | (uint32_t)i; r.level = l;
-            if (V.tiles_x * V.tiles_y > 65535) return VIS_E_INVALID;
-            // tile grid origin = (edge rounded down to 16, edge): see vis_compute_levels
-            r.ox = (e & ~15) + (i % V.tiles_x) * FT_W; r.oy = e + (i / V.tiles_x) * FT_H;
+            r.stride = V.stride; r.wh = (uint32_t)V.w | ((uint32_t)V.h << 16);
+            r.ntiles = (uint32_t)items; r.tile_base = (uint32_t)V.tile_base;
+            uint32_t nch[2] = {0, 0};
+            for (int k = 0; k < 2; k++) {
+                const int i = std::min(2 * j + k, items - 1);          // (an idle second half repeats the first one's geometry: its loads stay inside the image)
+                const int seg = i / V.tiles_x, strip = i % V.tiles_x;
+                r.x0[k] = x00 + strip * VIS_FS_EMIT_W; r.y0[k] = e - 1 + seg * VIS_FS_EMIT_H; r.tile[k] = (uint32_t)i;
+                // emitting rows of the segment -> chunks of 8 score rows (one halo row above and below)
+                const int rows = std::max(0, std::min(VIS_FS_EMIT_H, emit_rows - seg * VIS_FS_EMIT_H));
+                nch[k] = 2 * j + k < items ? (uint32_t)std::max(1, (rows + 2 + 7) / 8) : 0u;
+            }
+            r.nl = nch[0] | (nch[1] << 8) | ((uint32_t)l << 16);
+            t.push_back(r);
         }
     }
-    HIPCHK(ctx, hipMalloc((void**)&pl->d_fast_tiles, t.size() * sizeof(FastTile)));
-    HIPCHK(ctx, hipMemcpy(pl->d_fast_tiles, t.data(), t.size() * sizeof(FastTile), hipMemcpyHostToDevice));
+    pl->total_waves = (int)t.size();
+    if (pl->total_waves > 65535 * FS_WPB) return VIS_E_INVALID;          // k_fast: gridDim.y
+    HIPCHK(ctx, hipMalloc((void**)&pl->d_fast_tiles, t.size() * sizeof(FastWave)));
+    HIPCHK(ctx, hipMemcpy(pl->d_fast_tiles, t.data(), t.size() * sizeof(FastWave), hipMemcpyHostToDevice));
     return VIS_OK;
 }
 
@@ -1316,8 +1311,8 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
     const int t_base = ctx->p.fast_threshold;
     const int32_t* tau = pl->speculate ? pl->d_tau : nullptr;            // batched streams only (see fast_tile)
     {
-        hipLaunchKernelGGL(k_fast, dim3(8, pl->total_tiles, (n + 7) / 8), dim3(256), 0, st, (const FastTile*)pl->d_fast_tiles, d_frames,
-                           pl->total_tiles, t_base, ctx->p.edge_threshold, pl->d_tile_cnt, n, vis_fast_stamps(), tau);
+        hipLaunchKernelGGL(k_fast, dim3(8, (pl->total_waves + FS_WPB - 1) / FS_WPB, (n + 7) / 8), dim3(64 * FS_WPB), 0, st, (const FastWave*)pl->d_fast_tiles, d_frames,
+                           pl->total_tiles, pl->total_waves, t_base, ctx->p.edge_threshold, pl->d_tile_cnt, n, tau);
         nfast = 1;
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[2], st);
@@ -1338,9 +1333,9 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
                             pl->d_seg_cnt, pl->d_flags, max_surv, n, tau, t_base, seg_cut, fix);
     if (pl->speculate) {
         // redo what the prediction got wrong (normally nothing: both grids find an empty list and leave), then predict the next batch
-        FixLevels X; X.L = L; X.max_tiles = max_nt;
-        for (int l = 0; l < VIS_MAX_LEVELS; l++) { X.tile_base[l] = l < L ? pl->lv[l].tile_base : 0; X.ntiles[l] = l < L ? pl->lv[l].tiles_x * pl->lv[l].tiles_y : 0; }
-        hipLaunchKernelGGL(k_fast_fix, dim3(2048), dim3(256), 0, st, (const FastTile*)pl->d_fast_tiles, d_frames, pl->total_tiles, t_base,
+        FixLevels X; X.L = L; X.max_waves = 1;
+        for (int l = 0; l < VIS_MAX_LEVELS; l++) { X.wave_base[l] = l < L ? pl->lv[l].wave_base : 0; X.nwaves[l] = l < L ? pl->lv[l].nwaves : 0; X.max_waves = std::max(X.max_waves, X.nwaves[l]); }
+        hipLaunchKernelGGL(k_fast_fix, dim3(4096 / FS_WPB), dim3(64 * FS_WPB), 0, st, (const FastWave*)pl->d_fast_tiles, d_frames, pl->total_tiles, t_base,
                            ctx->p.edge_threshold, pl->d_tile_cnt, X, (const int32_t*)pl->d_fix);
         const int fix_grid = n * L;                      // one workgroup per possible work-list entry (<= 4096 frames x 16 levels)
         if (big) hipLaunchKernelGGL(k_select_fix_1024, dim3(fix_grid), dim3(1024), sel_lds, st, D, pl->d_tile_cnt, pl->total_tiles,

@@ -24,12 +24,13 @@ int vis_compute_levels(const vis_params& p, int w, int h, int stride0, LevelInfo
         if (lv[l].w < 8 || lv[l].h < 8) return VIS_E_INVALID;
         lv[l].stride = (l == 0) ? stride0 : ((lv[l].w + 63) / 64) * 64;
         lv[l].frame_bytes = (size_t)lv[l].stride * lv[l].h;
-        // FAST tiles (128 x 32) cover only the region that can emit keypoints, [edge, w-edge) x [edge, h-edge);
-        // the x origin is rounded down to 16 so that k_fast's 16-byte tile loads stay aligned
-        const int e = p.edge_threshold, tx0 = e & ~15;
-        lv[l].tiles_x = std::max(1, (lv[l].w - e - tx0 + 127) / 128);
-        lv[l].tiles_y = std::max(1, (lv[l].h - 2 * e + VIS_FT_H - 1) / VIS_FT_H);
-        lv[l].cand_cap = lv[l].tiles_x * lv[l].tiles_y * (VIS_FT_W * VIS_FT_H / 4);
+        // FAST items (k_fast, detect.hip): a strip segment of VIS_FS_EMIT_W x VIS_FS_EMIT_H emitting positions inside the region that can
+        // emit keypoints, [edge, w-edge) x [edge, h-edge); the pixel window of the first strip starts at a dword-aligned column
+        // (edge - 4 rounded down to 4; its first emitting column is 4 pixels further).  tiles_x = strips, tiles_y = segments.
+        const int e = p.edge_threshold, ex0 = ((e - 4) & ~3) + 4;
+        lv[l].tiles_x = std::max(1, (lv[l].w - e - ex0 + VIS_FS_EMIT_W - 1) / VIS_FS_EMIT_W);
+        lv[l].tiles_y = std::max(1, (lv[l].h - 2 * e + VIS_FS_EMIT_H - 1) / VIS_FS_EMIT_H);
+        lv[l].cand_cap = lv[l].tiles_x * lv[l].tiles_y * VIS_TILE_CAND_CAP;
         lv[l].tile_base = l == 0 ? 0 : lv[l - 1].tile_base + lv[l - 1].tiles_x * lv[l - 1].tiles_y;
     }
     float factor = (float)(1.0 / sf);

@@ -12,21 +12,26 @@
 #define VIS_NSLOTS 32            // device keyframe slots of the single-frame API (Camera::frameList)
 #define VIS_RANSAC_MAX_M 8192    // max correspondences per RANSAC problem
 #define VIS_MAX_MODELS 10
-#define VIS_FT_W 128              // FAST tile (k_fast workgroup) in pixels; the candidate slot of a tile holds VIS_FT_W*VIS_FT_H/4 entries
-#ifndef VIS_FT_H
-#define VIS_FT_H 32
-#endif
+// k_fast (detect.hip) works on ITEMS: a strip of 32 lanes x 4 pixels = 128 pixel columns (120 of them emit; 1 score halo + 3 ring
+// columns on either side) marched down 8 score rows at a time, at most VIS_FS_NCH chunks = 8 * NCH - 2 emitting rows.  An item owns a
+// candidate slot sized by the 3x3-NMS bound of its emit region (60 x 15 = 900 <= 1024): a slot cannot overflow.
+#define VIS_FS_EMIT_W 120
+#define VIS_FS_NCH 4
+#define VIS_FS_EMIT_H (8 * VIS_FS_NCH - 2)
+#define VIS_TILE_CAND_CAP 1024
+static_assert(((VIS_FS_EMIT_W + 1) / 2) * ((VIS_FS_EMIT_H + 1) / 2) <= VIS_TILE_CAND_CAP, "NMS bound of an item");
 
 struct LevelInfo {
     int w, h, stride;            // stride: bytes per row of the level buffer (level 0: caller's)
     int quota;                   // nfeaturesPerLevel
     float scale;                 // layerScale
     size_t frame_bytes;          // stride*h
-    int cand_cap;                // tiles * 512: every 64x32 FAST tile owns a slot sized by the 3x3-NMS bound
+    int cand_cap;                // tiles * VIS_TILE_CAND_CAP: every FAST item owns a slot sized by the 3x3-NMS bound
     int tile_base;               // first global tile index of this level
     int surv_cap;                // survivors of the FAST cut (2*quota + ties), LDS sort size
     int keep_cap;                // kept per level (quota + ties)
-    int tiles_x, tiles_y;        // FAST tiles
+    int tiles_x, tiles_y;        // FAST items: strips x segments
+    int wave_base, nwaves;       // k_fast waves of this level (two items each) in the plan's FastWave table
 };
 
 // device-resident compact kNN entry: key = (dist << 16) | trainIdx, 0xFFFFFFFF = none
@@ -44,10 +49,11 @@ struct Plan {
     uint8_t* d_stage = nullptr;              // single-frame upload staging (stride x h)
     uint8_t* d_pyr[VIS_MAX_LEVELS] = {};     // level l >= 1: B x h_l x stride_l
     uint32_t* d_rs_tab[VIS_MAX_LEVELS] = {}; // level l >= 1: coefficient tables of the resize step l-1 -> l (detect.hip k_resize_tab; built on first use)
-    uint32_t* d_cand[VIS_MAX_LEVELS] = {};   // B x tiles_l x 512 packed (score<<24 | y<<12 | x)
+    uint32_t* d_cand[VIS_MAX_LEVELS] = {};   // B x tiles_l x VIS_TILE_CAND_CAP packed (score<<24 | y<<12 | x)
     int32_t* d_tile_cnt = nullptr;           // B x total_tiles candidates per tile
     int total_tiles = 0;
-    void* d_fast_tiles = nullptr;            // total_tiles x FastTile (detect.hip): per-tile record of k_fast
+    void* d_fast_tiles = nullptr;            // total_waves x FastWave (detect.hip): per-wave record of k_fast (two items of one level)
+    int total_waves = 0;
     int32_t* d_seg_cnt = nullptr;            // B x L kept counts
     float4*  d_seg_kp[VIS_MAX_LEVELS] = {};  // B x keep_cap (x, y, response, unused)
     int32_t* d_flags = nullptr;              // device error flags (1 word)
