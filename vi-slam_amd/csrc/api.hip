@@ -119,7 +119,7 @@ extern "C" void vis_destroy(vis_ctx* ctx) {
     if (ctx->match_stream) { (void)hipStreamSynchronize(ctx->match_stream); (void)hipStreamDestroy(ctx->match_stream); }
     if (ctx->ev_detect_done) (void)hipEventDestroy(ctx->ev_detect_done);
     if (ctx->ev_match_start) (void)hipEventDestroy(ctx->ev_match_start);
-    for (int i = 0; i < 2; i++) if (ctx->ev_match_done[i]) (void)hipEventDestroy(ctx->ev_match_done[i]);
+    for (int i = 0; i < VIS_BATCH_SETS; i++) if (ctx->ev_match_done[i]) (void)hipEventDestroy(ctx->ev_match_done[i]);
     if (ctx->update_stream) { (void)hipStreamSynchronize(ctx->update_stream); (void)hipStreamDestroy(ctx->update_stream); }
     if (ctx->ev_update_fork) (void)hipEventDestroy(ctx->ev_update_fork);
     if (ctx->ev_update_done) (void)hipEventDestroy(ctx->ev_update_done);
@@ -133,7 +133,7 @@ static void sync_all(vis_ctx* ctx) {
     if (ctx->match_stream) (void)hipStreamSynchronize(ctx->match_stream);
     if (ctx->pose_stream) (void)hipStreamSynchronize(ctx->pose_stream);
     ctx->pose_pending = false; ctx->results_pending = false; ctx->align_pending = false;
-    if (ctx->batch) ctx->batch->match_pending[0] = ctx->batch->match_pending[1] = false;
+    if (ctx->batch) for (int i = 0; i < VIS_BATCH_SETS; i++) ctx->batch->match_pending[i] = false;
 }
 
 extern "C" const char* vis_last_error(vis_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -231,7 +231,7 @@ void plan_destroy(Plan* pl) {
     }
     F(pl->d_fast_tiles); F(pl->d_tile_cnt); F(pl->d_seg_cnt); F(pl->d_flags); F(pl->d_angle_tab); F(pl->d_half); F(pl->d_gx); F(pl->d_gy); F(pl->d_g); F(pl->d_tau); F(pl->d_seg_cut); F(pl->d_fix);
     F(pl->d_kps); F(pl->d_desc); F(pl->d_nkp); F(pl->d_descx);
-    for (int i = 0; i < 2; i++) { F(pl->d_pq[i]); F(pl->d_pt[i]); F(pl->d_pqn[i]); }
+    for (int i = 0; i < VIS_BATCH_SETS; i++) { F(pl->d_pq[i]); F(pl->d_pt[i]); F(pl->d_pqn[i]); }
     F(pl->d_knn12); F(pl->d_knn21);
     F(pl->d_sym); F(pl->d_nsym); F(pl->d_good); F(pl->d_ngood); F(pl->d_p1); F(pl->d_p2); F(pl->d_hf); F(pl->d_wf);
     F(pl->d_n1); F(pl->d_n2); F(pl->d_mask); F(pl->d_samples); F(pl->d_models); F(pl->d_counts); F(pl->d_rstate); F(pl->d_pose); F(pl->d_worklist); F(pl->d_hyp);
@@ -272,7 +272,7 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
     DALLOC(pl->d_tile_cnt, (size_t)B * pl->total_tiles); DALLOC(pl->d_seg_cnt, (size_t)B * L + VIS_MAX_LEVELS);   // + padding: k_describe reads VIS_MAX_LEVELS counts per frame
     if (pl->total_tiles > 65535) { plan_destroy(pl); return VIS_E_INVALID; }        // k_fast: gridDim.y
     { int rc2 = build_fast_tiles(ctx, pl); if (rc2) { plan_destroy(pl); return rc2; } }
-    if (nsets == 2) {                                              // batched stream plans predict the FAST threshold from batch to batch
+    if (nsets > 1) {                                               // batched stream plans predict the FAST threshold from batch to batch
         pl->speculate = true;
         DALLOC(pl->d_tau, L); DALLOC(pl->d_seg_cut, (size_t)B * L); DALLOC(pl->d_fix, (size_t)B * L + 1);
         std::vector<int32_t> t0((size_t)L, ctx->p.fast_threshold);
@@ -863,7 +863,7 @@ extern "C" int vis_batch_plan(vis_ctx* ctx, int w, int h, int stride, int max_fr
     (void)hipSetDevice(ctx->device);
     sync_all(ctx);
     plan_destroy(ctx->batch); ctx->batch = nullptr;
-    return plan_create(ctx, w, h, stride, max_frames, max_frames + 1, max_frames, &ctx->batch, 2);
+    return plan_create(ctx, w, h, stride, max_frames, max_frames + 1, max_frames, &ctx->batch, VIS_BATCH_SETS);
 }
 
 extern "C" int vis_batch_reset(vis_ctx* ctx) {
@@ -890,12 +890,12 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
     hipStream_t sA = ctx->stream, sM = ctx->match_stream, sP = ctx->pose_stream;
     ctx->tm.launches_total = 0;
     const bool detect = (stages & VIS_STAGE_DETECT) != 0;
-    const int cur = detect ? (pl->run_count & 1) : (pl->last_base / pl->rec_per_set);   // run_count is committed only when every launch succeeded
+    const int cur = detect ? (pl->run_count % pl->nsets) : (pl->last_base / pl->rec_per_set);   // run_count is committed only when every launch succeeded
     const int base = cur * pl->rec_per_set;
     int rc = VIS_OK;
     bool have_prev = pl->have_prev;
     if (detect) {
-        // this record set was last read by the matcher two batches ago
+        // this record set was last read by the matcher nsets batches ago
         if (pl->match_pending[cur]) HIPCHK(ctx, hipStreamWaitEvent(sA, ctx->ev_match_done[cur], 0));
         if (pl->carry_from > 0) have_prev = true;      // previous batch's last frame -> record 0 of this set: copied by launch_detect's first kernel
     }
@@ -994,7 +994,7 @@ extern "C" int vis_batch_sync(vis_ctx* ctx) {
     const bool had_pose = ctx->pose_pending;
     if (ctx->pose_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->pose_stream));
     ctx->pose_pending = false; ctx->results_pending = false; ctx->align_pending = false;
-    if (ctx->batch) ctx->batch->match_pending[0] = ctx->batch->match_pending[1] = false;
+    if (ctx->batch) for (int i = 0; i < VIS_BATCH_SETS; i++) ctx->batch->match_pending[i] = false;
     if (ctx->ev_ok) {
         collect_detect_timings(ctx);
         float a = 0;

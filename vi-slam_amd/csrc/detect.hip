@@ -277,62 +277,75 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
 //     the centre and the upper row of the axis pretest of three different score rows (the tiled kernel read five LDS dwords and
 //     reduced five operands per 4-pixel unit);
 //   * the east / west operands of the pretest come from the neighbour lanes (DPP wave shifts) -- no LDS access in the pretest at all;
-//   * the pass bits of a chunk (8 rows x 4 pixels) are one 32-bit register per lane; the set bits are compacted into an LDS queue
-//     (wave-wide prefix sum, no atomics), scored densely (cornerScore<16>, both polarities in one packed chain) into a 16-row score
-//     ring, and the 3x3 NMS + border cull runs over the queue one row behind the scores (the last row of a pass is carried to the next).
-// Per 4-pixel unit and row: 1 global load, 1 LDS store, ~24 vector instructions for the pretest (the tiled kernel: 2.5 LDS stores,
-// 5 LDS loads, ~41 vector instructions plus a quarter of its instructions in the tile load / clear / halo bookkeeping).
+//   * the pass bits of a chunk (8 rows x 4 pixels, dark and bright polarity apart) are two 32-bit registers per lane; the set bits are
+//     compacted into an LDS queue (wave-wide prefix sum, no atomics) and scored TWO entries per lane, ONE polarity each, in gfx950's
+//     three-input packed half-precision min / max (fast_score16_pair) into a 10-row score ring; entries that score move on to the 3x3 NMS
+//     + border cull, which runs one row behind the scores (the scored entries of a pass's last row are carried to the next pass).
+// 10 KB of LDS and 88 VGPRs per wave: 16 one-wave workgroups per CU.  Measured against the tiled kernel of rounds 1-4 (512 frames of
+// S-752 at the predicted thresholds, last dispatch, tools/pmc_kernel.sh): vector instructions 213 M -> 180 M, scalar 107 M -> 29 M,
+// 376 -> 330 us alone; at 13 waves per CU (12 KB) 366 us, at 9 waves 440 us -- the kernel is a chain of LDS / global round trips per wave,
+// occupancy is what hides them.
 // Results are the tiled kernel's: the pretest is the same necessary condition, cornerScore and the NMS are unchanged, candidate
 // order inside a slot is irrelevant (k_select sorts).
 #define FS_LANES 32
-#define FS_ROWB 256                              // bytes per ring row: 64 lanes x 4 pixels
+#define FS_ROWB 264                              // bytes per ring row: 64 lanes x 4 pixels + 8 (66 dwords: vertically adjacent positions -- corners
+                                                 // cluster -- fall into different LDS banks; with 64 the byte gathers of the score phase conflicted 3x as often)
+#define FS_ROWD (FS_ROWB / 4)
 #define FS_RING 16                               // pixel / score ring rows (two chunks of 8)
 #define FS_MIRROR 6                              // ring rows 0..5 are stored a second time behind row 15: a 7-row window never wraps
-#define FS_QCAP 512                              // queue entries per pass (a chunk with more passers is worked through 2 rows at a time)
+#define FS_QCAP 512                              // queue entries per pass (a chunk with more passers is worked through row by row)
 #define FS_PX_BYTES ((FS_RING + FS_MIRROR) * FS_ROWB)
-#define FS_SC_BYTES (FS_RING * FS_ROWB)
+#define FS_SCR 10                                // score ring rows: the NMS of a chunk sees score rows 8 c - 2 .. 8 c + 7 (slot = row mod 10)
+#define FS_SC_BYTES (FS_SCR * FS_ROWB)
 #define FS_Q_BYTES ((FS_QCAP + 64) * 2)          // + one scratch entry per lane (branch-free append)
-#define FS_CAR_BYTES (2 * 256 * 2)               // two carry lists (ping-pong): the passers of one score row
-#define FS_WAVE_LDS (FS_PX_BYTES + FS_SC_BYTES + FS_Q_BYTES + FS_CAR_BYTES)
+#define FS_CAR_BYTES (2 * 256)                   // two carry lists (ping-pong) of one byte per entry (4 lane + j): the scored passers of one score row
+#ifndef FS_PAD
+#define FS_PAD 0                                 // occupancy experiments: extra LDS bytes per wave
+#endif
+#define FS_WAVE_LDS (FS_PX_BYTES + FS_SC_BYTES + FS_Q_BYTES + FS_CAR_BYTES + FS_PAD)
 #define TILE_CAND_CAP VIS_TILE_CAND_CAP
 static_assert(FS_LANES * 4 - 8 == VIS_FS_EMIT_W, "strip geometry (geometry.cpp)");
-static_assert(2 * 4 * FS_LANES <= FS_QCAP, "two rows of passers fit the queue");
+static_assert(2 * 2 * 4 * FS_LANES <= FS_QCAP, "the passers of one row (both polarities) fit the queue");
 
-// full cornerScore<16> without the early exit (callers have already thinned the candidates).  Both polarities
-// run in one v_pk_*_i16 chain: X[k] = (v - p_k, p_k - v); the minimum over 9 consecutive X picks the dark-arc
-// margin in the low half and minus the bright-arc maximum in the high half, so
-//   max_k min9(X).lo = A (cv::cornerScore's a0),  max_k min9(X).hi = -b0,  score = max(a0, -b0) - 1.
-// c0 = the pixel 3 rows above and 3 columns left of the centre (all offsets are non-negative immediates), S = row stride.
+// cornerScore<16> without the early exit (callers have already thinned the candidates): with X[k] = v - p_k the minimum over 9
+// consecutive X is the dark-arc margin of the arc starting at k, the maximum over the 16 arcs is cv::cornerScore's a0; with
+// X[k] = p_k - v the same chain gives -b0; score = max(a0, -b0) - 1.
 typedef short pk16 __attribute__((ext_vector_type(2)));
+// TWO queue entries per lane, ONE polarity each (the halves of a packed register hold entry A and entry B): the
+// pretest knows which polarity passed, and a position cannot have a dark AND a bright 9-arc (18 > 16 ring pixels), so the other
+// polarity's chain is wasted work -- 112 packed instructions per two entries instead of 96 per entry.  sg = (+1 | -1) per half
+// (dark: v - p_k, bright: p_k - v); a position whose pretest passed both polarities is in the queue twice, at most one entry scores.
 template <int S>
-__device__ __forceinline__ int fast_score16_full(const uint8_t* c0, int t) {
-    const uint32_t v = c0[3 * S + 3];
+__device__ __forceinline__ pk16 fast_score16_pair(const uint8_t* a0, const uint8_t* b0, uint32_t nsg, int t) {
+    const uint32_t va = a0[3 * S + 3], vb = b0[3 * S + 3];
 #define RO(dy, dx) ((3 + (dy)) * S + 3 + (dx))
     const int off[16] = {RO(3, 0), RO(3, 1), RO(2, 2), RO(1, 3), RO(0, 3), RO(-1, 3), RO(-2, 2), RO(-3, 1),
                          RO(-3, 0), RO(-3, -1), RO(-2, -2), RO(-1, -3), RO(0, -3), RO(1, -3), RO(2, -2), RO(3, -1)};
 #undef RO
-    pk16 X[16], m2[16], m4[16];
-    // X[k] = (v - p_k, p_k - v) in ONE instruction per ring pixel: v_pk_mad_i16 (p_k, p_k) * (-1, +1) + (v, -v); the ring byte is
-    // used as loaded (both halves of the product read its low half: op_sel), no (v, p_k) register has to be assembled first
-    const uint32_t vpair = v - (v << 16);                                              // (v, -v)
-    const uint32_t sgn = 0x0001FFFFu;                                                  // (-1, +1)
+    // X[k] = sg (v - p_k) = p_k * (-sg) + sg v per half: one pack (the two ring bytes into the halves of a register) and one
+    // v_pk_mad_i16.  The addend also carries 0x6500 per half: the 16-bit pattern 0x6500 + X (|X| <= 255) IS the half-precision number
+    // 1280 + X, so the integer result can go straight into gfx950's three-input packed half-precision minimum / maximum -- min over 9
+    // consecutive X as min3 of min3 (32 instructions), max over the 16 arcs as a chain of max3 (8): 40 instead of 80 two-input ones.
+    // Every value is a small integer, exact in half precision; min / max commute with the bias.
+    const pk16 V2 = {(short)va, (short)vb};
+    const pk16 SV = -(V2 * __builtin_bit_cast(pk16, nsg)) + pk16{(short)0x6500, (short)0x6500};     // sg v = -(nsg v); nsg = -sg = (-1 | +1) per half
+    uint32_t X[16], m3[16], m9[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const uint32_t pk = c0[off[k]];
-        uint32_t x;
-        asm("v_pk_mad_i16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(x) : "v"(pk), "s"(sgn), "v"(vpair));
-        X[k] = __builtin_bit_cast(pk16, x);
+        const uint32_t pk = (uint32_t)a0[off[k]] | ((uint32_t)b0[off[k]] << 16);
+        asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(X[k]) : "v"(pk), "v"(nsg), "v"(__builtin_bit_cast(uint32_t, SV)));
     }
 #pragma unroll
-    for (int k = 0; k < 16; k++) m2[k] = __builtin_elementwise_min(X[k], X[(k + 1) & 15]);
+    for (int k = 0; k < 16; k++) asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(m3[k]) : "v"(X[k]), "v"(X[(k + 1) & 15]), "v"(X[(k + 2) & 15]));
 #pragma unroll
-    for (int k = 0; k < 16; k++) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
-    pk16 acc = {(short)-255, (short)-255};
+    for (int k = 0; k < 16; k++) asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(m9[k]) : "v"(m3[k]), "v"(m3[(k + 3) & 15]), "v"(m3[(k + 6) & 15]));
+    uint32_t acc;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(acc) : "v"(m9[0]), "v"(m9[1]), "v"(m9[2]));
 #pragma unroll
-    for (int k = 0; k < 16; k++)
-        acc = __builtin_elementwise_max(acc, __builtin_elementwise_min(__builtin_elementwise_min(m4[k], m4[(k + 4) & 15]), X[(k + 8) & 15]));
-    const int s = max((int)acc.x, (int)acc.y) - 1;
-    return s >= t ? s : 0;
+    for (int k = 3; k < 15; k += 2) asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(acc) : "v"(acc), "v"(m9[k]), "v"(m9[k + 1]));
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(acc) : "v"(acc), "v"(m9[15]), "v"(m9[15]));
+    const int sa = (int)(acc & 0xFFFFu) - 0x6500 - 1, sb = (int)(acc >> 16) - 0x6500 - 1;
+    return pk16{(short)(sa >= t ? sa : 0), (short)(sb >= t ? sb : 0)};
 }
 
 // LDS traffic inside ONE wave is processed in issue order; only the compiler must be kept from
@@ -394,7 +407,9 @@ __device__ __forceinline__ void fast_wave(const FastWave& V, const uint8_t* __re
     const uint8_t* const pxb = lds;
     uint8_t* const sc = lds + FS_PX_BYTES;
     uint16_t* const Q = reinterpret_cast<uint16_t*>(lds + FS_PX_BYTES + FS_SC_BYTES);
-    uint16_t* const CAR = Q + FS_QCAP + 64;
+    uint8_t* const CAR = reinterpret_cast<uint8_t*>(Q + FS_QCAP + 64);
+    auto sc_slot = [](int q) -> int { return q - FS_SCR * ((q * 205) >> 11); };         // q mod 10 for 0 <= q < 1024 / 15
+    static_assert(8 * VIS_FS_NCH < 1000, "range of the multiply-shift quotient");
     // rows: load chunk k = rows y0 - 5 + 8 k .. + 7 of the half (ring slots 8 (k & 1) ..).  Score row q of chunk c (q = 8 c + r) has its
     // centre in ring row q + 5, i.e. it needs load chunks c (last 6 rows) and c + 1.
     const uint32_t voff_max = (uint32_t)((h - 1) * stride) + coff;
@@ -415,9 +430,9 @@ __device__ __forceinline__ void fast_wave(const FastWave& V, const uint8_t* __re
     load8(nxt);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        px32[i * 64 + lane] = old[i];
-        if (i < FS_MIRROR) px32[(FS_RING + i) * 64 + lane] = old[i];
-        px32[(8 + i) * 64 + lane] = nw[i];
+        px32[i * FS_ROWD + lane] = old[i];
+        if (i < FS_MIRROR) px32[(FS_RING + i) * FS_ROWD + lane] = old[i];
+        px32[(8 + i) * FS_ROWD + lane] = nw[i];
     }
 #pragma unroll
     for (int i = 0; i < 8; i++) { old[i] = (old[i] >> 1) & M7; nw[i] = (nw[i] >> 1) & M7; }
@@ -444,9 +459,10 @@ __device__ __forceinline__ void fast_wave(const FastWave& V, const uint8_t* __re
     int ncar = 0, qcar = 0, cur = 0;                                            // carried passers: count, their score row, list in use
     WAVE_SYNC();
     for (int c = 0; c < nchunks; c++) {
-        uint32_t mask = 0xFFFFFFFFu;                                            // bit 8 j + r: pixel j of score row 8 c + r passes
+        // bit 8 j + r: pixel j of score row 8 c + r passes the dark (maskD) / the bright (maskB) axis test
+        uint32_t maskD = 0xFFFFFFFFu, maskB = 0xFFFFFFFFu;
         if (swar) {
-            mask = 0;
+            maskD = 0; maskB = 0;
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const uint32_t Cc = r < 3 ? old[r + 5] : nw[r - 3];
@@ -459,25 +475,35 @@ __device__ __forceinline__ void fast_wave(const FastWave& V, const uint8_t* __re
                 const uint32_t cD = Cc + kD;
                 const uint32_t dn = cD - Up, ds = cD - Lo, de = cD - Ee, dw = cD - Ww;
                 const uint32_t bn = nkB - dn, bs = nkB - ds, be = nkB - de, bw = nkB - dw;
-                const uint32_t dark = (dn | ds) & (de | dw);
-                const uint32_t pass = ((bn | bs) & (be | bw)) | dark;             // bit 7 of byte j: pixel j passes
-                mask |= (r == 7 ? pass : (pass >> (7 - r))) & (0x01010101u << r);
+                const uint32_t dark = (dn | ds) & (de | dw);                      // bit 7 of byte j: pixel j passes
+                const uint32_t bright = (bn | bs) & (be | bw);
+                // (x & sel) | mask as ONE full-rate v_bitop3_b32 (the compiler's v_and_or_b32 issues at half rate: tools/dpp_rates.hip)
+                maskD = __builtin_amdgcn_bitop3_b32(r == 7 ? dark : (dark >> (7 - r)), 0x01010101u << r, maskD, 0xEA);
+                maskB = __builtin_amdgcn_bitop3_b32(r == 7 ? bright : (bright >> (7 - r)), 0x01010101u << r, maskB, 0xEA);
             }
         }
         {
             // rows of this chunk that may be scored: q = 8 c + r in [rlo, rhi)
             const int lo_ = min(max(rlo - 8 * c, 0), 8), hi_ = min(max(rhi - 8 * c, 0), 8);
             const uint32_t rb = ((1u << hi_) - 1u) & ~((1u << lo_) - 1u);
-            mask &= colbits & (rb * 0x01010101u);
+            const uint32_t valid = colbits & (rb * 0x01010101u);
+            maskD &= valid; maskB &= valid;
         }
-        // the score rows of this chunk (ring slots 8 (c & 1) ..) start at zero: positions that are not scored read 0 in the NMS
+        // the score rows of this chunk (ring slots (8 c) mod 10 .. + 7, wrapping) start at zero: positions that are not scored read 0 in the NMS
+        const int sc0 = sc_slot(8 * c);                                         // wave-uniform
         {
-            uint4* z = reinterpret_cast<uint4*>(sc + (c & 1) * (8 * FS_ROWB)) + 2 * lane;
-            z[0] = make_uint4(0u, 0u, 0u, 0u); z[1] = make_uint4(0u, 0u, 0u, 0u);
+            constexpr int RU = FS_ROWB / 8;                                     // 8-byte units per row
+            unsigned long long* z = reinterpret_cast<unsigned long long*>(sc);
+#pragma unroll
+            for (int k = 0; k < (8 * RU + 63) / 64; k++) {
+                int u = sc0 * RU + 64 * k + lane;
+                u -= u >= FS_SCR * RU ? FS_SCR * RU : 0;
+                if (64 * k + lane < 8 * RU) z[u] = 0ull;
+            }
         }
-        // passes over the rows of the chunk: all 8 at once, or 2 at a time when the chunk has more passers than the queue holds
-        uint32_t m = mask;
-        int n = __popc(m);
+        // passes over the rows of the chunk: all 8 at once, or row by row when the chunk has more passers than the queue holds
+        uint32_t mD = maskD, mB = maskB;
+        int n = __popc(mD) + __popc(mB);
         auto prefix = [&](int v) -> int {                                       // wave-wide inclusive prefix sum (DPP row shifts + row broadcasts)
             v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);      // row_shr:1
             v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);      // row_shr:2
@@ -489,87 +515,104 @@ __device__ __forceinline__ void fast_wave(const FastWave& V, const uint8_t* __re
         };
         int incl = prefix(n);
         int tot = __builtin_amdgcn_readlane(incl, 63);
-        const int step = tot > FS_QCAP ? 2 : 8;
+        const int step = tot > FS_QCAP ? 1 : 8;
         for (int a = 0; a < 8; a += step) {
             if (step != 8) {
-                m = mask & (((1u << step) - 1u) << a) * 0x01010101u;
-                n = __popc(m);
+                const uint32_t sel = 0x01010101u << a;
+                mD = maskD & sel; mB = maskB & sel;
+                n = __popc(mD) + __popc(mB);
                 incl = prefix(n);
                 tot = __builtin_amdgcn_readlane(incl, 63);
             }
             const int qlast = 8 * c + a + step - 1;                              // the row whose lower neighbours are not scored yet
-            int nnew = 0;
-            if (tot | ncar) {
+            const uint8_t* const car_rd = CAR + cur * 256; uint8_t* const car_wr = CAR + (cur ^ 1) * 256;
+            int nnew = 0, nR = 0;                                                // scored passers: of row qlast (carried on) / of the rows before it
+            if (tot) {
                 // (1) queue append without ballots or atomics: every lane writes its passers to consecutive entries behind the lanes before
-                // it; entry = lane << 5 | bit = (4 lane + j) << 3 | r.  A lane that has run out of bits stores into its scratch entry.
+                // it; entry = polarity << 11 | lane << 5 | bit = polarity << 11 | (4 lane + j) << 3 | r.  A lane that has run out of bits
+                // stores into its scratch entry.
                 {
                     uint32_t a_idx = q_base + 2u * (uint32_t)(incl - n);
-                    uint32_t mm = m;
-                    while (__builtin_amdgcn_ballot_w64(mm != 0u)) {
-                        const bool has = mm != 0u;
-                        const uint32_t b = (uint32_t)__builtin_ctz(mm | 0x80000000u);
-                        mm &= mm - 1u;
-                        *(lds_u16*)(uintptr_t)(has ? a_idx : a_scr) = (uint16_t)(lane5 | b);
-                        a_idx += has ? 2u : 0u;
+                    uint32_t dD = mD, dB = mB;
+                    while (__builtin_amdgcn_ballot_w64((dD | dB) != 0u)) {
+                        const bool hasD = dD != 0u, hasB = dB != 0u;
+                        const uint32_t bD = (uint32_t)__builtin_ctz(dD | 0x80000000u), bB = (uint32_t)__builtin_ctz(dB | 0x80000000u);
+                        dD &= dD - 1u; dB &= dB - 1u;
+                        *(lds_u16*)(uintptr_t)(hasD ? a_idx : a_scr) = (uint16_t)(lane5 | bD);
+                        a_idx += hasD ? 2u : 0u;
+                        *(lds_u16*)(uintptr_t)(hasB ? a_idx : a_scr) = (uint16_t)(lane5 | bB | 0x800u);
+                        a_idx += hasB ? 2u : 0u;
                     }
                 }
                 WAVE_SYNC();
-                // (2) dense cornerScore on the queue
-                for (int i0 = 0; i0 < tot; i0 += 64) {
-                    const int i = i0 + lane;
-                    if (i < tot) {
-                        const uint32_t e = Q[i];
-                        const int xl = (int)(e >> 3) & 0xFF, qq = 8 * c + (int)(e & 7u);
-                        // 7 x 7 window: ring rows qq + 2 .. qq + 8 (the centre is ring row qq + 5), columns xl - 3 .. xl + 3
-                        const uint8_t* c0 = pxb + (((qq + 2) & (FS_RING - 1)) * FS_ROWB + xl - 3);
-                        const int s = fast_score16_full<FS_ROWB>(c0, threshold);
-                        sc[(qq & (FS_RING - 1)) * FS_ROWB + xl] = (uint8_t)s;
-                    }
+                // (2) cornerScore on the queue, two entries per lane (A = entry i0 + lane, B = entry i0 + 64 + lane).  Entries that score
+                // are written to the score ring and move on: row qlast to the carry list, the rows before it to the front of the queue
+                // (the survivor list R of the NMS; it never overtakes the entries still to be read).
+                for (int i0 = 0; i0 < tot; i0 += 128) {
+                    const int iA = i0 + lane, iB = i0 + 64 + lane;
+                    const bool actA = iA < tot, actB = iB < tot;
+                    const uint32_t eA = Q[actA ? iA : i0], eB = Q[actB ? iB : i0];
+                    const int xlA = (int)(eA >> 3) & 0xFF, qA = 8 * c + (int)(eA & 7u);
+                    const int xlB = (int)(eB >> 3) & 0xFF, qB = 8 * c + (int)(eB & 7u);
+                    // 7 x 7 window: ring rows q + 2 .. q + 8 (the centre is ring row q + 5), columns xl - 3 .. xl + 3
+                    const uint8_t* a0 = pxb + (((qA + 2) & (FS_RING - 1)) * FS_ROWB + xlA - 3);
+                    const uint8_t* b0 = pxb + (((qB + 2) & (FS_RING - 1)) * FS_ROWB + xlB - 3);
+                    const uint32_t nsg = ((eA & 0x800u) ? 0x0001u : 0xFFFFu) | ((eB & 0x800u) ? 0x00010000u : 0xFFFF0000u);
+                    const pk16 sp = fast_score16_pair<FS_ROWB>(a0, b0, nsg, threshold);
+                    const int sA = actA ? (int)sp.x : 0, sB = actB ? (int)sp.y : 0;
+                    WAVE_SYNC();                                               // (every entry of this round has been read)
+                    const int slA = sc0 + (int)(eA & 7u), slB = sc0 + (int)(eB & 7u);      // (8 c + r) mod 10
+                    if (sA > 0) sc[(slA - (slA >= FS_SCR ? FS_SCR : 0)) * FS_ROWB + xlA] = (uint8_t)sA;
+                    if (sB > 0) sc[(slB - (slB >= FS_SCR ? FS_SCR : 0)) * FS_ROWB + xlB] = (uint8_t)sB;
+                    const bool cA = sA > 0 && qA == qlast, cB = sB > 0 && qB == qlast;
+                    const bool rA = sA > 0 && qA != qlast, rB = sB > 0 && qB != qlast;
+                    const unsigned long long bRA = __builtin_amdgcn_ballot_w64(rA), bRB = __builtin_amdgcn_ballot_w64(rB);
+                    const unsigned long long bCA = __builtin_amdgcn_ballot_w64(cA), bCB = __builtin_amdgcn_ballot_w64(cB);
+                    auto rank = [&](unsigned long long bm) -> int {
+                        return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                    };
+                    if (rA) Q[nR + rank(bRA)] = (uint16_t)eA;
+                    if (rB) Q[nR + __popcll(bRA) + rank(bRB)] = (uint16_t)eB;
+                    nR += __popcll(bRA) + __popcll(bRB);
+                    if (cA) car_wr[nnew + rank(bCA)] = (uint8_t)xlA;
+                    if (cB) car_wr[nnew + __popcll(bCA) + rank(bCB)] = (uint8_t)xlB;
+                    nnew += __popcll(bCA) + __popcll(bCB);
+                    WAVE_SYNC();
                 }
-                WAVE_SYNC();
-                // (3) 3x3 NMS + border cull over the carried row and this pass's rows but the last, which is carried on
-                const int ntotal = ncar + tot;
-                const int car_rd = FS_QCAP + 64 + cur * 256, car_wr = FS_QCAP + 64 + (cur ^ 1) * 256;       // entry offsets from Q
-                for (int i0 = 0; i0 < ntotal; i0 += 64) {
-                    const int i = i0 + lane;
-                    const bool act = i < ntotal, isc = i < ncar;
-                    const uint32_t e = act ? Q[isc ? car_rd + i : i - ncar] : 0u;
-                    const int xl = (int)(e >> 3) & 0xFF;
-                    const int q = isc ? qcar : 8 * c + (int)(e & 7u);
-                    const uint8_t* p1 = sc + ((q & (FS_RING - 1)) * FS_ROWB + xl);
-                    const uint8_t* p0 = sc + (((q - 1) & (FS_RING - 1)) * FS_ROWB + xl);
-                    const uint8_t* p2 = sc + (((q + 1) & (FS_RING - 1)) * FS_ROWB + xl);
-                    const int s = act ? (int)p1[0] : 0;
-                    const bool later = !isc && q == qlast;
-                    const int half = xl >> 7, xi = xl & 127;
-                    const int gx = (half ? V.x0[1] : V.x0[0]) + xi, gy = (half ? V.y0[1] : V.y0[0]) + q;
-                    const int qmax = 8 * (half ? nch1 : nch0) - 2;
-                    // all eight neighbours at once (a short-circuit chain is up to eight dependent LDS round trips, and this kernel runs at 3-4 waves per SIMD)
-                    const int n0 = p0[-1], n1 = p0[0], n2 = p0[1], n3 = p1[-1], n4 = p1[1], n5 = p2[-1], n6 = p2[0], n7 = p2[1];
-                    const int nmax = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
-                    const bool em = s > nmax && !later && q >= 1 && q <= qmax && xi >= 4 && xi <= 4 * FS_LANES - 5 &&
-                                    gx >= edge && gx < w - edge && gy >= edge && gy < h - edge;      // (s > nmax >= 0: a zero score never emits)
-                    const unsigned long long bm = __builtin_amdgcn_ballot_w64(em);
-                    if (bm) {
-                        const unsigned long long b1 = __builtin_amdgcn_ballot_w64(em && half), b0 = bm & ~b1;
-                        const unsigned long long mine = half ? b1 : b0;
-                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
-                        const uint32_t o = (half ? V.tile[1] : V.tile[0]) * TILE_CAND_CAP + (uint32_t)((half ? cnt1 : cnt0) + rank);
-                        if (em) candf[o] = ((uint32_t)s << 24) | ((uint32_t)gy << 12) | (uint32_t)gx;
-                        cnt0 += __popcll(b0); cnt1 += __popcll(b1);
-                    }
-                    const bool cy = s > 0 && later;
-                    const unsigned long long bc = __builtin_amdgcn_ballot_w64(cy);
-                    if (bc) {
-                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bc, 0u));
-                        if (cy) Q[car_wr + nnew + rank] = (uint16_t)e;
-                        nnew += __popcll(bc);
-                    }
-                }
-                WAVE_SYNC();
-                cur ^= 1;
             }
-            ncar = nnew; qcar = qlast;
+            // (3) 3x3 NMS + border cull over the carried row and this pass's scored rows but the last (every entry here has a score > 0)
+            const int ntotal = ncar + nR;
+            for (int i0 = 0; i0 < ntotal; i0 += 64) {
+                const int i = i0 + lane;
+                const bool act = i < ntotal, isc = i < ncar;
+                const uint32_t e = Q[act && !isc ? i - ncar : 0];
+                const int xl = isc ? (int)car_rd[i] : (int)(e >> 3) & 0xFF;
+                const int q = isc ? qcar : 8 * c + (int)(e & 7u);
+                const int s1 = sc_slot(q), s0 = s1 == 0 ? FS_SCR - 1 : s1 - 1, s2 = s1 == FS_SCR - 1 ? 0 : s1 + 1;
+                const uint8_t* p1 = sc + (s1 * FS_ROWB + xl);
+                const uint8_t* p0 = sc + (s0 * FS_ROWB + xl);
+                const uint8_t* p2 = sc + (s2 * FS_ROWB + xl);
+                // all eight neighbours at once (a short-circuit chain is up to eight dependent LDS round trips, and this kernel runs at 3-4 waves per SIMD)
+                const int s = p1[0];
+                const int n0 = p0[-1], n1 = p0[0], n2 = p0[1], n3 = p1[-1], n4 = p1[1], n5 = p2[-1], n6 = p2[0], n7 = p2[1];
+                const int nmax = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
+                const int half = xl >> 7, xi = xl & 127;
+                const int gx = (half ? V.x0[1] : V.x0[0]) + xi, gy = (half ? V.y0[1] : V.y0[0]) + q;
+                const int qmax = 8 * (half ? nch1 : nch0) - 2;
+                const bool em = act && s > nmax && q >= 1 && q <= qmax && xi >= 4 && xi <= 4 * FS_LANES - 5 &&
+                                gx >= edge && gx < w - edge && gy >= edge && gy < h - edge;
+                const unsigned long long bm = __builtin_amdgcn_ballot_w64(em);
+                if (bm) {
+                    const unsigned long long b1 = __builtin_amdgcn_ballot_w64(em && half), b0 = bm & ~b1;
+                    const unsigned long long mine = half ? b1 : b0;
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+                    const uint32_t o = (half ? V.tile[1] : V.tile[0]) * TILE_CAND_CAP + (uint32_t)((half ? cnt1 : cnt0) + rank);
+                    if (em) *(__attribute__((address_space(1))) uint32_t*)(uintptr_t)(candf + o) = ((uint32_t)s << 24) | ((uint32_t)gy << 12) | (uint32_t)gx;   // global, not flat
+                    cnt0 += __popcll(b0); cnt1 += __popcll(b1);
+                }
+            }
+            WAVE_SYNC();
+            cur ^= 1; ncar = nnew; qcar = qlast;
         }
         // the next chunk's rows: ring slots of the load chunk that is no longer needed, 7-bit copies into the register window, and the
         // request for the chunk after it.  Unconditional (behind the last chunk the rows are clamped and never used): a load under a
@@ -577,10 +620,10 @@ __device__ __forceinline__ void fast_wave(const FastWave& V, const uint8_t* __re
         {
             const int par = c & 1;
 #pragma unroll
-            for (int i = 0; i < 8; i++) px32[(8 * par + i) * 64 + lane] = nxt[i];
+            for (int i = 0; i < 8; i++) px32[(8 * par + i) * FS_ROWD + lane] = nxt[i];
             if (par == 0) {
 #pragma unroll
-                for (int i = 0; i < FS_MIRROR; i++) px32[(FS_RING + i) * 64 + lane] = nxt[i];
+                for (int i = 0; i < FS_MIRROR; i++) px32[(FS_RING + i) * FS_ROWD + lane] = nxt[i];
             }
             // (the empty asm ties the row offset to the reduced values: the loads below cannot be scheduled in front of the last use of
             // the registers they are to land in -- otherwise they get registers of their own and a copy behind a vmcnt(0) at the back edge)
@@ -1307,7 +1350,7 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
                                pl->d_pyr[l], V.w, V.h, V.stride, V.frame_bytes, scale_x, scale_y, bxc, per_frame, n, (const uint32_t*)nullptr);
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[1], st);
-    if (after_resize) HIPCHK(ctx, hipEventRecord(after_resize, st));      // the side stream's streaming work starts here (vis_batch_run)
+    if (after_resize) HIPCHK(ctx, hipEventRecord(after_resize, st));      // the side stream's streaming work starts here (vis_batch_run); behind k_fast or k_select instead: same frames/s (round 5)
     const int t_base = ctx->p.fast_threshold;
     const int32_t* tau = pl->speculate ? pl->d_tau : nullptr;            // batched streams only (see fast_tile)
     {

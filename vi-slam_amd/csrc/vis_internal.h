@@ -9,16 +9,17 @@
 #include <vector>
 #include "../../include/vislam_hip.h"
 
+#define VIS_BATCH_SETS 2          // record sets of a batch plan (see Plan)
 #define VIS_NSLOTS 32            // device keyframe slots of the single-frame API (Camera::frameList)
 #define VIS_RANSAC_MAX_M 8192    // max correspondences per RANSAC problem
 #define VIS_MAX_MODELS 10
 // k_fast (detect.hip) works on ITEMS: a strip of 32 lanes x 4 pixels = 128 pixel columns (120 of them emit; 1 score halo + 3 ring
 // columns on either side) marched down 8 score rows at a time, at most VIS_FS_NCH chunks = 8 * NCH - 2 emitting rows.  An item owns a
-// candidate slot sized by the 3x3-NMS bound of its emit region (60 x 15 = 900 <= 1024): a slot cannot overflow.
+// candidate slot sized by the 3x3-NMS bound of its emit region (60 x 31 = 1860 <= 2048): a slot cannot overflow.
 #define VIS_FS_EMIT_W 120
-#define VIS_FS_NCH 4
+#define VIS_FS_NCH 8
 #define VIS_FS_EMIT_H (8 * VIS_FS_NCH - 2)
-#define VIS_TILE_CAND_CAP 1024
+#define VIS_TILE_CAND_CAP 2048
 static_assert(((VIS_FS_EMIT_W + 1) / 2) * ((VIS_FS_EMIT_H + 1) / 2) <= VIS_TILE_CAND_CAP, "NMS bound of an item");
 
 struct LevelInfo {
@@ -103,9 +104,13 @@ struct Plan {
     bool have_prev = false;                  // batch: record 0 holds the previous batch's last frame
     int last_n = 0;                          // frames in the last batch
     int carry_from = 0;                      // absolute record to copy into the next set's record 0 (0 = none)
-    int nsets = 1, rec_per_set = 0, run_count = 0, last_base = 0;   // batch plans double-buffer their records
-    int32_t* d_pq[2] = {nullptr, nullptr}; int32_t* d_pt[2] = {nullptr, nullptr}; int32_t* d_pqn[2] = {nullptr, nullptr};
-    bool match_pending[2] = {false, false};
+    // batch plans keep VIS_BATCH_SETS sets of records (keypoints, descriptors, expanded descriptors) and walk them round-robin: the detect
+    // chain of batch i + SETS waits for the matcher of batch i.  (Round 5: three sets instead of two change nothing -- in steady state the
+    // low-priority matcher / pose streams progress only as fast as the detect chain leaves them room, and the detect stream ends up waiting
+    // for them however far ahead it may run: 393.4 k frames/s with three sets against 395-400 k with two, same build.)
+    int nsets = 1, rec_per_set = 0, run_count = 0, last_base = 0;
+    int32_t* d_pq[VIS_BATCH_SETS] = {}; int32_t* d_pt[VIS_BATCH_SETS] = {}; int32_t* d_pqn[VIS_BATCH_SETS] = {};
+    bool match_pending[VIS_BATCH_SETS] = {};
     bool pair0_valid = false;                // last run: frame 0 had a predecessor
 };
 
@@ -116,7 +121,7 @@ struct vis_ctx {
     hipStream_t pose_stream = nullptr;       // RANSAC/pose of batch i overlaps detect/match of batch i+1
     hipEvent_t ev_filter_done = nullptr, ev_pose_done = nullptr, ev_pose_start = nullptr;
     hipStream_t match_stream = nullptr;      // knn + filters of batch i overlap the detect chain of batch i+1
-    hipEvent_t ev_detect_done = nullptr, ev_match_start = nullptr, ev_match_done[2] = {nullptr, nullptr};
+    hipEvent_t ev_detect_done = nullptr, ev_match_start = nullptr, ev_match_done[VIS_BATCH_SETS] = {};
     hipStream_t update_stream = nullptr;     // VIS_STAGE_UPDATE (Camera::Update): streaming work beside the VALU-bound detect chain
     hipEvent_t ev_update_fork = nullptr, ev_update_done = nullptr;
     bool pose_pending = false;
