@@ -148,8 +148,9 @@ int  vis_level_geometry(vis_ctx* ctx, int w, int h, int32_t* widths, int32_t* he
 /* Sizes of Camera::Update's levels (src/Camera.cpp:68-70: resize(prev, next, Size(), 0.5, 0.5)): cv::resize takes
  * dsize = cvRound(size * 0.5) -- round half to EVEN: 135 -> 68, 137 -> 68 -- so a level can be one row / column larger than the
  * reference's own bookkeeping `w_size[0] >> lvl` (src/Camera.cpp:42-47; 1080 -> 540, 270, 135, 68 against 67).  Both exist
- * here as they do there: buffers, strides and the gradients follow these sizes; the patch builders and the alignment bound
- * their coordinates by `>> lvl` like the reference.  For sizes that halve exactly four times (752x480) they coincide. */
+ * here as they do there: buffers, strides, the gradients and the alignment's test of a WARPED point (src/VISystem.cpp:1299:
+ * `y2 < image2.rows && x2 < image2.cols`) follow these sizes; the patch builders bound the candidate points they emit by `>> lvl`
+ * like the reference.  For sizes that halve exactly four times (752x480) they coincide. */
 void vis_half_pyramid_dims(int w, int h, int32_t lw[5], int32_t lh[5]);
 /* Camera::Update, src/Camera.cpp:63-72: copy + 4x half-resolution levels.
  * out_levels[l] (l=1..4) receives lw[l]*lh[l] bytes (vis_half_pyramid_dims), tightly packed; out_levels[0] may be NULL.
@@ -344,6 +345,10 @@ int  vis_batch_get_matches(vis_ctx* ctx, int frame, vis_dmatch* good, int cap, i
                            int* n_sym);
 int  vis_batch_get_pose(vis_ctx* ctx, int frame, double E[9], double R[9], double t[3],
                         int* n_inliers, int* n_pose_good, int* iters_run);
+/* the inlier mask of findEssentialMat (src/VISystem.cpp:1680, the `mask` argument) for pair `frame` of the last batch: one byte per
+ * correspondence the pose stage saw, in the order it saw them (good matches, or the symmetric matches with VIS_POSE_SYM).
+ * VIS_E_CAPACITY if cap < *n_points (which is still returned). */
+int  vis_batch_get_inlier_mask(vis_ctx* ctx, int frame, uint8_t* mask, int cap, int* n_points);
 /* what the pose stage leaves per pair on the device (vis_batch_results_async copies these records) */
 typedef struct vis_pose_result {
     double E[9], R[9], t[3];

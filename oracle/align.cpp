@@ -281,8 +281,9 @@ extern "C" int orc_estimate_pose_features(const vis_align_params* ap, int w, int
     std::memset(out, 0, sizeof(*out));
     float initial_error = 0.f;
     for (int lvl = ap->first_level; lvl >= ap->last_level; lvl--) {                       // :1182
-        // `cols`, `rows` = the reference's bookkeeping w_[lvl], h_[lvl] = size >> lvl (src/VISystem.cpp InitializePyramid); the Mats it
-        // indexes have Camera::Update's sizes (orc_half_pyramid_dims: up to one row / column more when a size does not halve exactly)
+        // `cols`, `rows` = the reference's bookkeeping w_[lvl], h_[lvl] = size >> lvl (src/VISystem.cpp InitializePyramid): what the patch
+        // builders bound the candidate points by; the Mats it indexes -- and tests the WARPED point against (:1299) -- have Camera::Update's
+        // sizes (orc_half_pyramid_dims: up to one row / column more when a size does not halve exactly)
         const int cols = w >> lvl, rows = h >> lvl, N = n_cand[lvl];
         int32_t alw[5], alh[5]; orc_half_pyramid_dims(w, h, alw, alh);
         const int acols = alw[lvl], arows = alh[lvl];
@@ -309,7 +310,7 @@ extern "C" int orc_estimate_pose_features(const vis_align_params* ap, int w, int
                 x2 = x2 * P[3]; y2 = y2 * P[3];
                 const float z2 = P[2];
                 float inv_z2 = 1 / z2;
-                if (!(y2 > 0 && y2 < rows && x2 > 0 && x2 < cols)) continue;                 // :1280
+                if (!(y2 > 0 && y2 < arows && x2 > 0 && x2 < acols)) continue;               // :1299 `y2<image2.rows && x2<image2.cols`: the Mat's own size
                 if (!(z2 != 0)) continue;                                                   // :1281
                 if (inv_z2 < 0) inv_z2 = 0;                                                 // :1282-1283
                 float Jw[2][6];

@@ -276,3 +276,28 @@ def test_stage_gradient_matches_gradient_batch_and_feeds_the_alignment(vislam, c
     assert np.array_equal(fetch(py, n * fe * 2).view(np.int16), last[3])
     assert np.array_equal(fetch(pgg, n * fe), last[4])
     c.close()
+
+
+def test_warped_points_in_the_extra_row_and_column(vislam, orc, ctx, canvas):
+    """150 x 110: level 2 is a 38 x 28 Mat (cvRound(37.5), cvRound(27.5)) where the reference's bookkeeping says 37 x 27.  The reference
+    tests a WARPED point against the Mat (`y2 < image2.rows && x2 < image2.cols`, src/VISystem.cpp:1299), so points that land in
+    column 37.x / row 27.x count as residuals (round 4 rejected them with the bookkeeping size: ADVICE r4).  Hand-placed candidates
+    at the right / bottom edge of level 2 and a pose that moves them by half a pixel: oracle and kernel agree bit for bit AND the
+    residual count shows the points were accepted."""
+    w, h = 150, 110
+    c = align_cases.case(vislam, orc, canvas, w=w, h=h, dx=1, dy=1, n=20, grad_div=8)
+    lw, lh = vislam.half_pyramid_dims(w, h)
+    assert (lw[2], lh[2]) == (38, 28) and (w >> 2, h >> 2) == (37, 27)
+    pts = np.array([[36.0, y, 1.0, 1.0] for y in range(4, 26, 3)] + [[x, 26.0, 1.0, 1.0] for x in range(4, 36, 3)], np.float32)
+    cand = [np.zeros((0, 4), np.float32)] * 5
+    cand[2] = pts
+    ap = vislam.default_align_params(); oap = orc.default_align_params()
+    for q in (ap, oap):
+        q.fx, q.fy, q.cx, q.cy = 120.0, 120.0, w / 2.0, h / 2.0
+        q.first_level, q.last_level, q.max_iterations = 2, 2, 1
+    # level-2 focal length = 120 / 4 = 30: a translation of 0.04 along x and y moves every point (z = 1) by 1.2 px: x 36 -> 37.2, y 26 -> 27.2
+    init = orc.se3_exp([0.04, 0.04, 0, 0, 0, 0])
+    got = ctx.estimate_pose_features(ap, w, h, c["gray1"], c["gray2"], c["gx"], c["gy"], cand, init)
+    ref = orc.estimate_pose_features(oap, w, h, c["gray1"], c["gray2"], c["gx"], c["gy"], cand, init)
+    _same(got, ref)
+    assert ref.n_residuals[2] == len(pts), (list(ref.n_residuals), len(pts))      # every point counted, including the ones in the extra row / column

@@ -160,3 +160,21 @@ def test_library_se3_host_helpers_equal_the_oracle(vislam, orc):
         M = vislam.se3_matrix(ea)
         assert np.array_equal(M, orc.se3_matrix(oa))
         assert np.array_equal(vislam.se3_from_rt(M[:3, :3], M[:3, 3]).as_array(), orc.se3_from_rt(M[:3, :3], M[:3, 3]).as_array())
+
+
+def test_warped_point_guard_uses_the_size_of_the_indexed_mat(vislam, orc, canvas):
+    """src/VISystem.cpp:1299 tests the warped point with `y2 < image2.rows && x2 < image2.cols`: image2 = grayImage[lvl] has
+    Camera::Update's size (150 x 110 -> level 2: 38 x 28), one row / column more than the bookkeeping `size >> lvl` (37 x 27).  Points
+    warped into column 37.x / row 27.x are residuals (the restatement rejected them with the bookkeeping size)."""
+    w, h = 150, 110
+    c = align_cases.case(vislam, orc, canvas, w=w, h=h, dx=1, dy=1, n=20, grad_div=8)
+    pts = np.array([[36.0, y, 1.0, 1.0] for y in range(4, 26, 3)] + [[x, 26.0, 1.0, 1.0] for x in range(4, 36, 3)], np.float32)
+    cand = [np.zeros((0, 4), np.float32)] * 5
+    cand[2] = pts
+    ap = orc.default_align_params()
+    ap.fx, ap.fy, ap.cx, ap.cy = 120.0, 120.0, w / 2.0, h / 2.0
+    ap.first_level, ap.last_level, ap.max_iterations = 2, 2, 1
+    moved = orc.estimate_pose_features(ap, w, h, c["gray1"], c["gray2"], c["gx"], c["gy"], cand, orc.se3_exp([0.04, 0.04, 0, 0, 0, 0]))   # + 1.2 px in x and y
+    assert moved.n_residuals[2] == len(pts)
+    out = orc.estimate_pose_features(ap, w, h, c["gray1"], c["gray2"], c["gx"], c["gy"], cand, orc.se3_exp([0.08, 0.08, 0, 0, 0, 0]))     # + 2.4 px: beyond the Mat
+    assert out.n_residuals[2] == 0

@@ -155,3 +155,94 @@ def test_batched_pose_on_symmetric_matches(vislam, orc, canvas):
         oR, ot, ong = orc.recover_pose(p, oE, p1, p2)
         assert pose["n_pose_good"] == ong and np.abs(pose["R"] - oR).max() <= 1e-7
     c.close()
+
+
+def test_config3_batched_path_that_the_bench_times(vislam, orc, big_canvas):
+    """bench.py's config-3 leg: a BATCH of 1920x1080 frames, 4 levels, 4000 keypoints, RANSAC with 2000 fixed iterations on the
+    un-gridded symmetric matches (pose_input = SYM), through vis_batch_run(STAGE_FRAME) -- the launch sequence the leg times, not the
+    single-frame entry points -- against the oracle per frame / pair: keypoints, descriptors, both 2-NN tables, symmetric and good
+    matches, inlier masks, inlier counts and iteration numbers exact; E <= 1e-9, R <= 1e-7 (the batch tolerances of DESIGN section 1)."""
+    import torch
+    p = vislam.default_params()
+    p.nfeatures, p.nlevels, p.w_size, p.h_size = 4000, 4, 1920, 1080
+    p.ransac_adaptive, p.ransac_max_iters = 0, 2000
+    p.pose_input = 1                                                  # VIS_POSE_SYM
+    p.fy = p.fx
+    c = vislam.Context(0, p)
+    n = 8
+    frames = np.stack([vislam.synth_frame(big_canvas, t, 1920, 1080, 0xE0C00003) for t in range(n)])
+    dev = torch.from_numpy(frames).cuda()
+    c.batch_plan(1920, 1080, 1920, n)
+    c.batch_run(dev.data_ptr(), n, vislam.STAGE_FRAME)
+    c.batch_sync()
+    assert c.batch_status() == 0
+    # Camera::Update of the same launch (the half pyramid of every frame)
+    dptr, fe = c.batch_half_pyramid()
+    class _Dev:                                                        # the plan's buffer as a torch view
+        __cuda_array_interface__ = {"data": (dptr, False), "shape": (n * fe,), "typestr": "|u1", "version": 2}
+    half = torch.as_tensor(_Dev(), device="cuda").cpu().numpy().reshape(n, fe)
+    for t in (0, n - 1):
+        ref = orc.half_pyramid(frames[t])
+        off = 1920 * 1080
+        for l in range(1, 5):
+            assert np.array_equal(half[t, off:off + ref[l].size].reshape(ref[l].shape), ref[l]), (t, l)
+            off += ref[l].size
+    prev = None
+    for t in range(n):
+        ok, od = orc.orb_detect_compute(p, frames[t], cap=8192)
+        k, d = c.batch_keypoints(t, cap=8192)
+        assert len(k) >= 3900 and k.tobytes() == ok.tobytes() and (d == od).all(), t
+        if prev is not None:
+            o12, o21 = orc.knn2_hamming(prev[1], od)
+            g12, g21 = c.batch_knn(t, cap=8192)
+            assert g12.tobytes() == o12.tobytes() and g21.tobytes() == o21.tobytes(), t
+            og, osym = orc.good_matches(p, prev[0], ok, o12, o21)
+            g, nsym = c.batch_matches(t)
+            assert nsym == len(osym) > 1500 and g.tobytes() == og.tobytes(), t
+            p1 = np.stack([prev[0]["x"][osym["queryIdx"]], prev[0]["y"][osym["queryIdx"]]], 1)
+            p2 = np.stack([ok["x"][osym["trainIdx"]], ok["y"][osym["trainIdx"]]], 1)
+            oE, omask, oninl, oiters = orc.essential_ransac(p, p1, p2)
+            pose = c.batch_pose(t)
+            mask = c.batch_inlier_mask(t)
+            assert pose["iters_run"] == oiters == 2000 and pose["n_inliers"] == oninl, t
+            assert len(mask) == len(omask) and (mask == omask).all(), t
+            s = 1.0 if float((pose["E"] * oE).sum()) >= 0 else -1.0
+            assert np.abs(pose["E"] - s * oE).max() <= 1e-9, t
+            oR, ot, ong = orc.recover_pose(p, oE, p1, p2)
+            assert pose["n_pose_good"] == ong and np.abs(pose["R"] - oR).max() <= 1e-7, t
+        prev = (ok, od)
+    c.close()
+
+
+def test_config5_8000x8000_both_directions_and_exact_filters(vislam, orc, big_canvas):
+    """BASELINE config 5 at full size on TWO DIFFERENT frames: sampled rows of BOTH 2-NN tables (g12 and the transposed pass g21)
+    against a numpy popcount over all 8000 train descriptors, and Matcher's filter chain (ratio, symmetry, y sort, grid cells: O(N) on
+    the CPU) on the GPU's own tables -- symmetric and good matches exact at n = 8000 (round 4 checked counts only)."""
+    p = vislam.default_params()
+    p.nfeatures, p.nlevels, p.w_size, p.h_size = 8000, 8, 3840, 2160
+    c = vislam.Context(0, p)
+    a = vislam.synth_frame(big_canvas, 0, 3840, 2160, 0xE0C00003)
+    b = vislam.synth_frame(big_canvas, 1, 3840, 2160, 0xE0C00003)
+    k0, d0 = c.orb_detect_compute(a, slot=0, cap=16384)
+    k1, d1 = c.orb_detect_compute(b, slot=1, cap=16384)
+    assert len(k0) >= 7900 and len(k1) >= 7900
+    g12, g21 = c.bf_knn2_hamming(0, 1, len(k0), len(k1))
+    assert len(g12) == len(k0) and len(g21) == len(k1)
+    bits0, bits1 = np.unpackbits(d0, axis=1), np.unpackbits(d1, axis=1)
+    rng = np.random.default_rng(5)
+
+    def check(tab, qbits, tbits, nq):
+        rows = np.unique(np.concatenate([[0, 1, nq - 1, nq - 2], rng.integers(0, nq, 96)]))
+        dist = (qbits[rows][:, None, :] != tbits[None, :, :]).sum(2)             # rows x n_train Hamming distances
+        order = np.argsort(dist, axis=1, kind="stable")                           # ties: lower train index first (BFMatcher's scan order)
+        for i, r in enumerate(rows):
+            assert tab["trainIdx"][r, 0] == order[i, 0] and tab["trainIdx"][r, 1] == order[i, 1], (r, tab[r], order[i, :2])
+            assert tab["distance"][r, 0] == dist[i, order[i, 0]] and tab["distance"][r, 1] == dist[i, order[i, 1]]
+            assert tab["queryIdx"][r, 0] == r and tab["queryIdx"][r, 1] == r
+    check(g12, bits0, bits1, len(k0))
+    check(g21, bits1, bits0, len(k1))
+    good, sym = c.good_matches(0, 1)
+    og, osym = orc.good_matches(p, k0, k1, g12, g21)                              # the oracle's filters on the GPU's tables
+    assert sym.tobytes() == osym.tobytes() and good.tobytes() == og.tobytes()
+    assert len(sym) > 2000 and 0 < len(good) <= 49
+    c.close()

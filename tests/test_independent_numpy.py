@@ -877,3 +877,39 @@ def test_single_precision_sampson_error_radii_hold():
         assert not (tin & ~ttruth).any() and not (tout & ttruth).any(), thr
         und = ~(tin | tout)
         assert 0.2 < und.mean() < 0.98, und.mean()                # both kinds occur: the check is not vacuous
+
+
+def _np_half(src):
+    """cv::resize(src, dst, Size(), 0.5, 0.5) as OpenCV 3.2 documents / implements it for an exact factor of 2 (resizeAreaFast_Invoker):
+    dsize = cvRound(size * 0.5) (round half to even); a destination pixel is the mean of the source pixels of its 2 x 2 block that exist:
+    (a + b + c + d + 2) >> 2 for a complete block, saturate_cast<uchar>((float)sum / count) -- round half to even -- otherwise."""
+    h, w = src.shape
+    rhe = lambda n: (n >> 1) + ((n & 1) & ((n >> 1) & 1))              # cvRound(n / 2): ties to even
+    dh, dw = rhe(h), rhe(w)
+    out = np.zeros((dh, dw), np.uint8)
+    s = src.astype(np.int64)
+    for y in range(dh):
+        for x in range(dw):
+            blk = s[2 * y:min(2 * y + 2, h), 2 * x:min(2 * x + 2, w)]
+            if blk.size == 4:
+                out[y, x] = (int(blk.sum()) + 2) >> 2
+            else:
+                out[y, x] = int(np.rint(np.float32(blk.sum()) / np.float32(blk.size)))      # numpy rint = ties to even, like cvRound
+    return out
+
+
+def test_half_pyramid_rule_in_numpy(orc):
+    """the oracle's Camera::Update against the rule written out in numpy (sizes that do and do not halve exactly, incl. the image of the
+    committed half_150x110 fixture): independent of oracle/orb.cpp, still not OpenCV itself (parity unpinned)"""
+    import os
+    rng = np.random.default_rng(11)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "half_150x110.npz"))
+    imgs = [g["img"], rng.integers(0, 256, (47, 61), dtype=np.uint8), rng.integers(0, 256, (19, 18), dtype=np.uint8),
+            rng.integers(0, 256, (64, 96), dtype=np.uint8), (rng.integers(0, 2, (33, 35)) * 255).astype(np.uint8)]
+    for img in imgs:
+        lv = orc.half_pyramid(img)
+        ref = img
+        for l in range(1, 5):
+            ref = _np_half(ref)
+            assert lv[l].shape == ref.shape, (img.shape, l, lv[l].shape, ref.shape)
+            assert np.array_equal(lv[l], ref), (img.shape, l)

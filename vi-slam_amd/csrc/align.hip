@@ -327,7 +327,9 @@ __global__ __launch_bounds__(AL_THREADS) void k_align(AlignArgs G) {
                         const float z2 = P2;
                         float inv_z2 = 1 / z2;
                         const int ix1 = (int)x1, iy1 = (int)y1;
-                        bool v = (y2 > 0 && y2 < rows && x2 > 0 && x2 < cols) && (z2 != 0);
+                        // the warped point is tested against the size of the Mat it indexes (src/VISystem.cpp:1299: image2.rows / image2.cols
+                        // = Camera::Update's level size, up to one row / column MORE than the bookkeeping `size >> lvl`)
+                        bool v = (y2 > 0 && y2 < V.arows && x2 > 0 && x2 < V.acols) && (z2 != 0);
                         if (inv_z2 < 0) inv_z2 = 0;
                         v = v && !(ix1 < 0 || ix1 >= cols || iy1 < 0 || iy1 >= rows);
                         if (v) {

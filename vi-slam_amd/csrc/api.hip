@@ -405,19 +405,32 @@ static int grow_single(vis_ctx* ctx, int capacity) {
     int rc = plan_create(ctx, old->w, old->h, old->stride, 1, VIS_NSLOTS, 1, &np);
     if (rc == VIS_OK && (np->kcap < old->kcap || np->nrec != old->nrec)) { plan_destroy(np); rc = VIS_E_STATE; }
     if (rc) { ctx->p.keypoint_capacity = cap_before; return rc; }       // (the old plan and its slots stay as they were)
-    std::vector<int32_t> nk((size_t)old->nrec);
-    HIPCHK(ctx, hipMemcpy(nk.data(), old->d_nkp, nk.size() * 4, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(np->d_nkp, nk.data(), nk.size() * 4, hipMemcpyHostToDevice));
-    for (int r = 0; r < old->nrec && r < VIS_NSLOTS; r++) {
-        const size_t n = (size_t)std::min(std::max(nk[r], 0), old->kcap);
-        if (!ctx->slot_valid[r] || !n) continue;
-        HIPCHK(ctx, hipMemcpy(np->d_kps + (size_t)r * np->kcap, old->d_kps + (size_t)r * old->kcap, n * sizeof(vis_keypoint), hipMemcpyDeviceToDevice));
-        HIPCHK(ctx, hipMemcpy(np->d_desc + (size_t)r * np->kcap * 32, old->d_desc + (size_t)r * old->kcap * 32, n * 32, hipMemcpyDeviceToDevice));
-        HIPCHK(ctx, hipMemcpy(np->d_descx + (size_t)r * np->kcap * 128, old->d_descx + (size_t)r * old->kcap * 128, n * 128, hipMemcpyDeviceToDevice));
+    // every failure from here on leaves the context as it was: the new plan is destroyed, the capacity restored (the early
+    // returns of HIPCHK leaked `np` and left ctx->p ahead of the live plan)
+    auto copy_records = [&]() -> hipError_t {
+        std::vector<int32_t> nk((size_t)old->nrec);
+        hipError_t e = hipMemcpy(nk.data(), old->d_nkp, nk.size() * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(np->d_nkp, nk.data(), nk.size() * 4, hipMemcpyHostToDevice);
+        for (int r = 0; e == hipSuccess && r < old->nrec && r < VIS_NSLOTS; r++) {
+            const size_t n = (size_t)std::min(std::max(nk[r], 0), old->kcap);
+            if (!ctx->slot_valid[r] || !n) continue;
+            e = hipMemcpy(np->d_kps + (size_t)r * np->kcap, old->d_kps + (size_t)r * old->kcap, n * sizeof(vis_keypoint), hipMemcpyDeviceToDevice);
+            if (e == hipSuccess) e = hipMemcpy(np->d_desc + (size_t)r * np->kcap * 32, old->d_desc + (size_t)r * old->kcap * 32, n * 32, hipMemcpyDeviceToDevice);
+            if (e == hipSuccess) e = hipMemcpy(np->d_descx + (size_t)r * np->kcap * 128, old->d_descx + (size_t)r * old->kcap * 128, n * 128, hipMemcpyDeviceToDevice);
+        }
+        return e;
+    };
+    const hipError_t ce = copy_records();
+    if (ce != hipSuccess) {
+        ctx->err = std::string("grow_single: ") + hipGetErrorString(ce);
+        plan_destroy(np); ctx->p.keypoint_capacity = cap_before;
+        return VIS_E_HIP;
     }
     plan_destroy(old);
     ctx->single = np;
-    plan_destroy(ctx->batch); ctx->batch = nullptr;              // (its capacity belongs to the old parameters)
+    // a batch plan was sized with the old parameters: it goes (sync_all above has drained its streams; results of a finished batch that
+    // the caller has not fetched yet are lost with it -- vis_set_params documents the same for every parameter change)
+    plan_destroy(ctx->batch); ctx->batch = nullptr;
     return VIS_OK;
 }
 
@@ -1109,6 +1122,24 @@ extern "C" int vis_batch_get_matches(vis_ctx* ctx, int frame, vis_dmatch* good, 
     if (frame < 0 || frame >= pl->last_n) return VIS_E_INVALID;
     sync_all(ctx);
     return download_matches(ctx, pl, frame, good, cap, n_good, nullptr, 0, n_sym);
+}
+
+// the inlier mask findEssentialMat left for pair `frame` (one byte per correspondence the pose stage saw: the grid-filtered good
+// matches, or the symmetric matches in their list order with VIS_POSE_SYM)
+extern "C" int vis_batch_get_inlier_mask(vis_ctx* ctx, int frame, uint8_t* mask, int cap, int* n_points) {
+    if (!ctx || !ctx->batch) return VIS_E_STATE;
+    Plan* pl = ctx->batch;
+    if (frame < 0 || frame >= pl->last_n) return VIS_E_INVALID;
+    sync_all(ctx);
+    PoseOut o;
+    HIPCHK(ctx, hipMemcpy(&o, pl->d_pose + frame, sizeof(PoseOut), hipMemcpyDeviceToHost));
+    const int n = std::min(std::max(o.n_points, 0), pl->pose_mcap);
+    if (n_points) *n_points = n;
+    if (mask) {
+        if (n > cap) return VIS_E_CAPACITY;
+        if (n) HIPCHK(ctx, hipMemcpy(mask, pl->d_mask + (size_t)frame * pl->pose_mcap, (size_t)n, hipMemcpyDeviceToHost));
+    }
+    return VIS_OK;
 }
 
 extern "C" int vis_batch_get_pose(vis_ctx* ctx, int frame, double E[9], double R[9], double t[3],

@@ -1039,6 +1039,7 @@ __global__ __launch_bounds__(256) void k_hyp_score(PoseParams P, int h0, int h_e
     // (model, point) decisions that single precision left open, settled afterwards by ALL threads at once: inside the model loop a
     // single undecided lane would hold its whole wave for a double-precision evaluation from global memory
     constexpr int AMB_CAP = 4096;
+    static_assert(VIS_RANSAC_MAX_M <= 65536, "the undecided list packs the point index into 16 bits");
     __shared__ uint32_t sAmb[AMB_CAP];
     __shared__ int32_t sNamb;
     __shared__ int32_t sBase[16], sCnt[16], sTag[160], sGood[160], sTotal;
@@ -1141,26 +1142,27 @@ __global__ __launch_bounds__(256) void k_hyp_score(PoseParams P, int h0, int h_e
             __syncthreads();
             auto round_of = [&](auto ppl_tag, int g0, int mc) {    // PPL rows of 256 points starting at point g0, mc points in all
                 constexpr int PPL = decltype(ppl_tag)::value;
-                ScorePt Q[PPL]; int ninv = 0;
+                ScorePt Q[PPL]; unsigned long long vm[PPL];       // vm: lanes of the wave that hold a point (scalar masks)
 #pragma unroll
                 for (int k = 0; k < PPL; k++) {
                     const bool vq = tid + 256 * k < mc;
                     Q[k] = make_pt(g0 + (vq ? tid + 256 * k : 0));
-                    // a lane without a point: band = -inf makes it a certain inlier of every model (r is finite), taken off the counts
-                    // below -- the ballots need no masks
+                    // a lane without a point: band = -inf makes it a certain inlier of every finite model; the counts and the undecided
+                    // list take only the lanes of vm (a NON-finite model -- fn = inf passes k_hyp_models' `fn > 0` -- gives r = NaN in every
+                    // lane: such lanes used to be subtracted as inliers they never were and listed as undecided points beyond M)
                     if (!vq) { Q[k].x1 = Q[k].y1 = Q[k].x2 = Q[k].y2 = 0.f; Q[k].es2 = 0.f; Q[k].c = -__builtin_inff(); }
-                    ninv += 64 - __popcll(__builtin_amdgcn_ballot_w64(vq));
+                    vm[k] = __builtin_amdgcn_ballot_w64(vq);
                 }
                 for (int t = 0; t < T; t++) {
                     const float4 r0 = *reinterpret_cast<const float4*>(&sE[t][0]), r1 = *reinterpret_cast<const float4*>(&sE[t][4]);
                     const float Em[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, sE[t][8]};
-                    unsigned long long bd[PPL], alld = ~0ull; int cnt = -ninv;
+                    unsigned long long bd[PPL], alld = ~0ull; int cnt = 0;
 #pragma unroll
                     for (int k = 0; k < PPL; k++) {                // branch-free: 20 fma/mul/add + two compares per point
                         bool in, out; sampson_f32(Em, Q[k], tm, kd, in, out);
                         const unsigned long long bi = __builtin_amdgcn_ballot_w64(in), bo = __builtin_amdgcn_ballot_w64(out);   // one compare each
-                        bd[k] = bi | bo; alld &= bd[k];
-                        cnt += __popcll(bi);
+                        bd[k] = bi | bo | ~vm[k]; alld &= bd[k];
+                        cnt += __popcll(bi & vm[k]);
                     }
                     if (__builtin_expect(alld != ~0ull, 0)) {      // wave-uniform: ONE list reservation for all undecided lanes of the wave
                         int tot = 0;
@@ -1615,7 +1617,8 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
             const int chunks = (max_iters - first + 63) / 64;
             // grids = what is resident on the chip at once (occupancy x CUs), walked in strides / by claiming: one workgroup per possible
             // item floods the adaptive headline, whose list is almost empty, with empty workgroups (65 k of them: - 5 % frames/s)
-            static const PoseGrids G = pose_grids(ctx->device);
+            if (!ctx->pose_grids_set) { const PoseGrids g_ = pose_grids(ctx->device); ctx->pose_grid[0] = g_.hyp_list; ctx->pose_grid[1] = g_.roots; ctx->pose_grid[2] = g_.models; ctx->pose_grid[3] = g_.score; ctx->pose_grids_set = true; }
+            const PoseGrids G = {ctx->pose_grid[0], ctx->pose_grid[1], ctx->pose_grid[2], ctx->pose_grid[3]};      // per context = per device, behind its own LDS opt-in (not a process-wide static)
             const int nb = (int)std::min<long long>(G.hyp_list, (long long)npairs * chunks * (64 / QH));
             // k_hyp_score: a workgroup per sub-item when every pair is on the list (adaptive stop off: known on the host) -- workgroups that
             // walk equal items in strides stay in lockstep, their load phases (models, four rows of points per round) coincide on a CU

@@ -128,6 +128,7 @@ struct vis_ctx {
     // vis_batch_align runs on the pose stream (beside the next batch's detect chain): what may not overtake it waits for this event
     hipEvent_t ev_align_fork = nullptr, ev_align_done = nullptr; bool align_pending = false;
     bool pose_attr_set = false;              // > 64 KiB LDS opt-in of the RANSAC solver kernels done on this context's device
+    bool pose_grids_set = false; int pose_grid[4] = {0, 0, 0, 0};   // resident-workgroup grids of the work-list pose kernels on this device (pose.hip pose_grids)
     hipEvent_t ev_results_done = nullptr; bool results_pending = false;   // D2H of the last batch's results (vis_batch_results_async)
     vis_params p;
     std::string err;
