@@ -45,6 +45,40 @@ FAM = ("ms_update", "ms_pyramid", "ms_fast", "ms_select", "ms_describe", "ms_knn
 SIMD_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2       # wave-instr/s: 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md)
 
 
+# a synthetic EuRoC-shaped calibration (no distortion, ORB + GPU Hamming matcher) for the adapter-level leg (legs.single_frame_api.add_frame_gpu)
+CAL_XML = """<?xml version="1.0"?>
+<opencv_storage>
+<in_width type_id="integer"> 752 </in_width>
+<in_height type_id="integer"> 480 </in_height>
+<out_width type_id="integer"> 752 </out_width>
+<out_height type_id="integer"> 480 </out_height>
+<calibration_values type_id="opencv-matrix">
+  <rows>1</rows> <cols>4</cols> <dt>f</dt>
+  <data> 458.654 457.296 367.215 248.375 </data></calibration_values>
+<rectification type_id="opencv-matrix">
+  <rows>1</rows> <cols>4</cols> <dt>f</dt>
+  <data> 0 0 0 0 </data></rectification>
+<imu2cam0Transformation type_id="opencv-matrix">
+  <rows>4</rows> <cols>4</cols> <dt>f</dt>
+  <data> 0.0148655429818 -0.999880929698 0.00414029679422 -0.0216401454975
+         0.999557249008 0.0149672133247 0.025715529948 -0.064676986768
+        -0.0257744366974 0.00375618835797 0.999660727178 0.00981073058949
+         0.0 0.0 0.0 1.0 </data></imu2cam0Transformation>
+<camera_frecuency type_id="float"> 20 </camera_frecuency>
+<imu_frecuency type_id="float"> 200 </imu_frecuency>
+<min_features type_id="integer"> 20</min_features>
+<num_max_keyframes type_id="integer"> 10</num_max_keyframes>
+<start_index type_id="integer"> 0 </start_index>
+<use_gt type_id="integer">1</use_gt>
+<use_ros type_id="integer">0</use_ros>
+<num_cells type_id="integer"> 49</num_cells>
+<length_patch type_id="integer"> 3</length_patch>
+<detector type_id="integer">2</detector>
+<matcher type_id="integer">4</matcher>
+</opencv_storage>
+"""
+
+
 def algorithmic_bytes(px, n):
     """SURVEY.md section 8(d) per-frame figures, split per kernel family (DESIGN.md 'Roofline')."""
     ptot = sum(px)
@@ -507,6 +541,65 @@ def main():
                 ctx.close()
                 torch.cuda.empty_cache()
         guarded("s752_mispredicted_thresholds", leg_mispredict)
+        def leg_single_frame():
+            """the path the drop-in boundary exists for (/root/reference/src/main_vi_slamGPU.cpp:118-123 -> src/VISystemGPU.cpp:137-175): ONE frame
+            per call, handed over in pageable host memory, results handed back to the host -- latency per frame, not batch throughput"""
+            import subprocess, tempfile
+            ctx = vislam.Context(dev.index or 0, p)
+            try:
+                cvs = vislam.synth_canvas(2048, vdist.SINGLE_SEED)
+                n, warm = 200, 6
+                fr = [vislam.synth_frame(cvs, t, W, H, vdist.SINGLE_SEED) for t in range(n + warm + 1)]     # numpy arrays: pageable host memory
+                names = ("vis_camera_update", "vis_orb_detect_compute", "vis_good_matches", "vis_essential_ransac", "vis_recover_pose")
+                per = {k: [] for k in names}
+                tot = []
+                k_prev, _ = ctx.orb_detect_compute(fr[0], slot=0)
+                c0 = None
+                for t in range(1, n + warm + 1):
+                    if t == warm + 1:
+                        per = {k: [] for k in names}; tot = []; c0 = ctx.debug_counters()
+                    ts = [time.perf_counter()]
+                    ctx.camera_update(fr[t]); ts.append(time.perf_counter())
+                    k_cur, _d = ctx.orb_detect_compute(fr[t], slot=t & 1); ts.append(time.perf_counter())
+                    g, _s = ctx.good_matches((t - 1) & 1, t & 1); ts.append(time.perf_counter())
+                    p1 = np.stack([k_prev["x"][g["queryIdx"]], k_prev["y"][g["queryIdx"]]], 1)
+                    p2 = np.stack([k_cur["x"][g["trainIdx"]], k_cur["y"][g["trainIdx"]]], 1)
+                    tb = time.perf_counter()
+                    E, _m, _ni, _it = ctx.essential_ransac(p1, p2); te = time.perf_counter()
+                    ctx.recover_pose(E, p1, p2); tr = time.perf_counter()
+                    for k, dt_ in zip(names, (ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], te - tb, tr - te)):
+                        per[k].append(dt_ * 1e3)
+                    tot.append((ts[3] - ts[0] + tr - tb) * 1e3)
+                    k_prev = k_cur
+                c1 = ctx.debug_counters()
+                pct = lambda v, q: float(np.percentile(np.array(v), q))
+                out = {"what": "per frame, from pageable host memory through the C ABI (ctypes): vis_camera_update + vis_orb_detect_compute + vis_good_matches "
+                               "(knn both directions + filters) + vis_essential_ransac + vis_recover_pose, 752x480 / N = 1000, 200 consecutive S-752 frames; every "
+                               "call returns its results to the host.  Includes the ctypes / numpy wrapper (result arrays are allocated per call).  A 20 Hz camera "
+                               "leaves 50 ms per frame; the CPU oracle needs 1000 / cpu_baseline.value ms",
+                       "frames": n, "ms_per_frame_p50": pct(tot, 50), "ms_per_frame_p95": pct(tot, 95), "ms_per_frame_mean": float(np.mean(tot)),
+                       "frames_per_s_one_at_a_time": 1e3 / float(np.mean(tot)),
+                       "ms_p50_per_entry_point": {k: pct(v, 50) for k, v in per.items()}, "ms_p95_per_entry_point": {k: pct(v, 95) for k, v in per.items()},
+                       "kernel_launches_per_frame": (c1[0] - c0[0]) / n, "host_waits_per_frame": (c1[1] - c0[1]) / n, "async_copies_per_frame": (c1[2] - c0[2]) / n,
+                       "host_waits_per_entry_point": 1}
+            finally:
+                ctx.close()
+                torch.cuda.empty_cache()
+            # the reference's own call: VISystemGPU::AddFrameGPU on the adapter classes (C++, cv::Mat in pageable memory)
+            exe = os.path.join(ROOT, "vi-slam_amd", "lib", "addframe_bench")
+            try:
+                with tempfile.NamedTemporaryFile("w", suffix=".xml", delete=False) as f:
+                    f.write(CAL_XML)
+                r = subprocess.run([exe, f.name, "200", "6"], capture_output=True, text=True, timeout=300)
+                os.unlink(f.name)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                out["add_frame_gpu"] = dict(json.loads(line[-1]), what="VISystemGPU::AddFrameGPU per call on the adapter classes (vi-slam_amd/host/addframe_bench.cpp): Camera::Update, "
+                                            "detect + describe, knn + filters against the last keyframe, Scharr gradients, patch points, Gauss-Newton alignment, Track") if line \
+                    else {"error": (r.stdout + r.stderr)[-400:]}
+            except Exception as e:
+                out["add_frame_gpu"] = {"error": repr(e)}
+            return out
+        guarded("single_frame_api", leg_single_frame)
         q3 = vislam.default_params()
         q3.nfeatures, q3.nlevels, q3.w_size, q3.h_size = 4000, 4, 1920, 1080
         q3.fy = q3.fx

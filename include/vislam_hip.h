@@ -345,6 +345,9 @@ int  vis_batch_get_matches(vis_ctx* ctx, int frame, vis_dmatch* good, int cap, i
                            int* n_sym);
 int  vis_batch_get_pose(vis_ctx* ctx, int frame, double E[9], double R[9], double t[3],
                         int* n_inliers, int* n_pose_good, int* iters_run);
+/* diagnostics: out[0] = kernel launches of this process so far, out[1] = times a single-frame entry point of this context blocked on the
+ * device, out[2] = asynchronous copies those entry points queued, out[3] = 0.  (bench.py `single_frame_api`: per-frame differences.) */
+int  vis_debug_counters(vis_ctx* ctx, unsigned long long out[4]);
 /* the inlier mask of findEssentialMat (src/VISystem.cpp:1680, the `mask` argument) for pair `frame` of the last batch: one byte per
  * correspondence the pose stage saw, in the order it saw them (good matches, or the symmetric matches with VIS_POSE_SYM).
  * VIS_E_CAPACITY if cap < *n_points (which is still returned). */

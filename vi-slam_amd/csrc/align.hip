@@ -504,7 +504,9 @@ extern "C" int vis_estimate_pose_features(vis_ctx* ctx, const vis_align_params* 
         need += 6 * px + (size_t)N * 16 + 6 * 256;
     }
     rc = vis_ensure_scratch(ctx, need + sizeof(vis_se3f) + sizeof(vis_align_result) + 1024);
+    if (!rc) rc = vis_ensure_pin(ctx, need + sizeof(vis_se3f) + sizeof(vis_align_result) + 4096);     // (the caller's arrays are pageable: through the pinned block, one wait per call)
     if (rc) return rc;
+    HostStage hs(ctx);
     Carver cv{(char*)ctx->d_scratch, 0};
     AlignArgs G; std::memset(&G, 0, sizeof(G));
     fill_level_intrinsics(*ap, G);
@@ -519,21 +521,21 @@ extern "C" int vis_estimate_pose_features(vis_ctx* ctx, const vis_align_params* 
         uint8_t* d1 = cv.take<uint8_t>(px); uint8_t* d2 = cv.take<uint8_t>(px);
         int16_t* dgx = cv.take<int16_t>(px); int16_t* dgy = cv.take<int16_t>(px);
         float* dc = cv.take<float>((size_t)N * 4);
-        HIPCHK(ctx, hipMemcpyAsync(d1, gray1[l], px, hipMemcpyHostToDevice, st));
-        HIPCHK(ctx, hipMemcpyAsync(d2, gray2[l], px, hipMemcpyHostToDevice, st));
-        HIPCHK(ctx, hipMemcpyAsync(dgx, gx1[l], px * 2, hipMemcpyHostToDevice, st));
-        HIPCHK(ctx, hipMemcpyAsync(dgy, gy1[l], px * 2, hipMemcpyHostToDevice, st));
-        HIPCHK(ctx, hipMemcpyAsync(dc, cand1[l], (size_t)N * 16, hipMemcpyHostToDevice, st));
+        hs.up(d1, gray1[l], px); hs.up(d2, gray2[l], px);
+        hs.up(dgx, gx1[l], px * 2); hs.up(dgy, gy1[l], px * 2);
+        hs.up(dc, cand1[l], (size_t)N * 16);
         V.i1 = d1; V.i2 = d2; V.gx = dgx; V.gy = dgy; V.cand = dc;
     }
     vis_se3f* d_init = nullptr;
-    if (init) { d_init = cv.take<vis_se3f>(1); HIPCHK(ctx, hipMemcpyAsync(d_init, init, sizeof(vis_se3f), hipMemcpyHostToDevice, st)); }
+    if (init) { d_init = cv.take<vis_se3f>(1); hs.up(d_init, init, sizeof(vis_se3f)); }
     vis_align_result* d_out = cv.take<vis_align_result>(1);
     G.init = d_init; G.out = d_out; G.f1_off = 0; G.f2_off = 0; G.out_off = 0;
     hipLaunchKernelGGL(k_align<false>, dim3(1), dim3(AL_THREADS), 0, st, G);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(out, d_out, sizeof(vis_align_result), hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
+    const void* h_out = hs.down(d_out, sizeof(vis_align_result));
+    rc = hs.wait();
+    if (rc) return rc;
+    std::memcpy(out, h_out, sizeof(vis_align_result));
     return VIS_OK;
 }
 

@@ -107,6 +107,7 @@ extern "C" void vis_destroy(vis_ctx* ctx) {
     if (ctx->pose_stream) (void)hipStreamSynchronize(ctx->pose_stream);
     plan_destroy(ctx->single); plan_destroy(ctx->batch);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->d_sample_table) (void)hipFree(ctx->d_sample_table);
     for (int i = 0; i < 12; i++) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->pose_stream) { (void)hipStreamSynchronize(ctx->pose_stream); (void)hipStreamDestroy(ctx->pose_stream); }
@@ -384,6 +385,34 @@ int vis_ensure_scratch(vis_ctx* ctx, size_t bytes) {
 }
 static inline int ensure_scratch(vis_ctx* ctx, size_t bytes) { return vis_ensure_scratch(ctx, bytes); }
 
+unsigned long long vis_g_launches = 0;
+
+// ---- host staging of the single-frame entry points --------------------------------------------------------------------------------
+// The reference's main hands over pageable host memory (cv::Mat, std::vector) once per camera frame (src/main_vi_slamGPU.cpp:118-123).  A
+// blocking hipMemcpy on such memory is a full host <-> device round trip each; round 4's vis_orb_detect_compute made four of them, the
+// matcher entry six.  Here every transfer of a call goes through the context's pinned block as an ASYNCHRONOUS copy on the context's
+// stream -- uploads are copied into the block first, downloads are copied out of it after the call's ONE wait -- so an entry point blocks
+// once (twice when a result decides what else to fetch).
+int vis_ensure_pin(vis_ctx* ctx, size_t bytes) {
+    if (ctx->h_pin_bytes >= bytes) return VIS_OK;
+    (void)hipStreamSynchronize(ctx->stream);                       // nothing queued may still use the old block
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    ctx->h_pin = nullptr; ctx->h_pin_bytes = 0;
+    const size_t want = std::max(bytes + bytes / 4, (size_t)1 << 20);
+    if (hipHostMalloc(&ctx->h_pin, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->err = "hipHostMalloc of the staging block failed"; return VIS_E_NOMEM; }
+    ctx->h_pin_bytes = want;
+    return VIS_OK;
+}
+// diagnostics: out[0] = kernel launches of this process, out[1] = times a single-frame entry point of this context blocked on the device,
+// out[2] = asynchronous copies it queued (bench.py `single_frame_api`: launches and round trips per frame)
+extern "C" int vis_debug_counters(vis_ctx* ctx, unsigned long long out[4]) {
+    if (!ctx || !out) return VIS_E_INVALID;
+    out[0] = vis_g_launches; out[1] = ctx->n_host_waits; out[2] = ctx->n_copies; out[3] = 0;
+    return VIS_OK;
+}
+
+__global__ void k_set_pair(int32_t* q, int32_t* t, int32_t vq, int32_t vt) { *q = vq; *t = vt; }
+
 static int ensure_single(vis_ctx* ctx, int w, int h) {
     (void)hipSetDevice(ctx->device);
     if (ctx->single && ctx->single->w == w && ctx->single->h == h) return VIS_OK;
@@ -460,16 +489,20 @@ extern "C" int vis_camera_update(vis_ctx* ctx, const uint8_t* img, int w, int h,
     lvl_bytes[0] = (size_t)w * h;
     for (int l = 1; l < 5; l++) { lvl_bytes[l] = (size_t)lw[l] * lh[l]; total += lvl_bytes[l] + 256; }
     int rc = ensure_scratch(ctx, total + 1024);
+    if (!rc) rc = vis_ensure_pin(ctx, 2 * total + 4096);
     if (rc) return rc;
     Carver cv{(char*)ctx->d_scratch, 0};
     uint8_t* d[5];
     for (int l = 0; l < 5; l++) d[l] = cv.take<uint8_t>(lvl_bytes[l]);
-    HIPCHK(ctx, hipMemcpy2DAsync(d[0], w, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+    HostStage hs(ctx);
+    hs.up2d(d[0], w, img, stride, w, h);
     rc = launch_half_pyramid(ctx, d[0], w, h, w, d);
     if (rc) return rc;
-    for (int l = 0; l < 5; l++)
-        if (out_levels[l]) HIPCHK(ctx, hipMemcpyAsync(out_levels[l], d[l], lvl_bytes[l], hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const void* got[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int l = 0; l < 5; l++) if (out_levels[l]) got[l] = hs.down(d[l], lvl_bytes[l]);
+    rc = hs.wait();
+    if (rc) return rc;
+    for (int l = 0; l < 5; l++) if (out_levels[l]) std::memcpy(out_levels[l], got[l], lvl_bytes[l]);
     return VIS_OK;
 }
 
@@ -505,19 +538,27 @@ extern "C" int vis_compute_gradient(vis_ctx* ctx, const uint8_t* img, int w, int
     uint8_t* d_gray = cv.take<uint8_t>(fe);
     int16_t* d_gx = cv.take<int16_t>(fe); int16_t* d_gy = cv.take<int16_t>(fe);
     uint8_t* d_g = cv.take<uint8_t>(fe);
-    HIPCHK(ctx, hipMemcpy2DAsync(d_img, ws, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+    rc = vis_ensure_pin(ctx, (size_t)w * h + fe * 5 + 4096);
+    if (rc) return rc;
+    HostStage hs(ctx);
+    hs.up2d(d_img, ws, img, stride, w, h);
     rc = vis_gradient_batch(ctx, d_img, w, h, ws, 1, scale, d_gray, d_gx, d_gy, d_g);
     if (rc) return rc;
     int lw[5], lh[5]; vis_half_dims(w, h, lw, lh);
+    // the three outputs are dense over the five levels: one copy each, cut into levels on the host
+    const int16_t* h_gx = (const int16_t*)hs.down(d_gx, fe * 2);
+    const int16_t* h_gy = (const int16_t*)hs.down(d_gy, fe * 2);
+    const uint8_t* h_g = (const uint8_t*)hs.down(d_g, fe);
+    rc = hs.wait();
+    if (rc) return rc;
     size_t off = 0;
     for (int l = 0; l < 5; l++) {
         const size_t cnt = (size_t)lw[l] * lh[l];
-        if (gx[l]) HIPCHK(ctx, hipMemcpyAsync(gx[l], d_gx + off, cnt * 2, hipMemcpyDeviceToHost, ctx->stream));
-        if (gy[l]) HIPCHK(ctx, hipMemcpyAsync(gy[l], d_gy + off, cnt * 2, hipMemcpyDeviceToHost, ctx->stream));
-        if (g[l]) HIPCHK(ctx, hipMemcpyAsync(g[l], d_g + off, cnt, hipMemcpyDeviceToHost, ctx->stream));
+        if (gx[l]) std::memcpy(gx[l], h_gx + off, cnt * 2);
+        if (gy[l]) std::memcpy(gy[l], h_gy + off, cnt * 2);
+        if (g[l]) std::memcpy(g[l], h_g + off, cnt);
         off += cnt;
     }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return VIS_OK;
 }
 
@@ -533,19 +574,26 @@ extern "C" int vis_patch_points(vis_ctx* ctx, const vis_keypoint* good, int n, i
     float* d_patch = cv.take<float>((size_t)5 * std::max(cap, 1) * 4);
     float* d_debug = cv.take<float>((size_t)5 * std::max(cap, 1) * 4);
     int32_t* d_cnt = cv.take<int32_t>(10);
-    if (m) HIPCHK(ctx, hipMemcpyAsync(d_good, good, (size_t)m * sizeof(vis_keypoint), hipMemcpyHostToDevice, ctx->stream));
+    rc = vis_ensure_pin(ctx, (size_t)200 * sizeof(vis_keypoint) + (size_t)10 * std::max(cap, 1) * 16 + 4096);
+    if (rc) return rc;
+    HostStage hs(ctx);
+    hs.up(d_good, good, (size_t)m * sizeof(vis_keypoint));
     rc = launch_patch_points(ctx, d_good, m, ctx->p.w_size, ctx->p.h_size, d_patch, d_debug, cap, d_cnt);
     if (rc) return rc;
-    int32_t cnt[10];
-    HIPCHK(ctx, hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // counts and both point lists of all five levels behind the kernels (list lengths are not known before the wait: the caller's
+    // capacity is fetched; the builders emit at most 200 keypoints x patch^2 points)
+    const int32_t* cnt = (const int32_t*)hs.down(d_cnt, 40);
+    const float* h_patch = cap ? (const float*)hs.down(d_patch, (size_t)5 * cap * 16) : nullptr;
+    const float* h_debug = cap ? (const float*)hs.down(d_debug, (size_t)5 * cap * 16) : nullptr;
+    rc = hs.wait();
+    if (rc) return rc;
     bool over = false;
     for (int l = 0; l < 5; l++) {
         n_patch[l] = cnt[l]; n_debug[l] = cnt[5 + l];
         over = over || cnt[l] > cap || cnt[5 + l] > cap;
         const int np = std::min(cnt[l], cap), nd = std::min(cnt[5 + l], cap);
-        if (patch[l] && np) HIPCHK(ctx, hipMemcpy(patch[l], d_patch + (size_t)l * cap * 4, (size_t)np * 16, hipMemcpyDeviceToHost));
-        if (debug[l] && nd) HIPCHK(ctx, hipMemcpy(debug[l], d_debug + (size_t)l * cap * 4, (size_t)nd * 16, hipMemcpyDeviceToHost));
+        if (patch[l] && np) std::memcpy(patch[l], h_patch + (size_t)l * cap * 4, (size_t)np * 16);
+        if (debug[l] && nd) std::memcpy(debug[l], h_debug + (size_t)l * cap * 4, (size_t)nd * 16);
     }
     return over ? VIS_E_CAPACITY : VIS_OK;
 }
@@ -574,21 +622,30 @@ extern "C" int vis_orb_detect_compute(vis_ctx* ctx, const uint8_t* img, int w, i
     int rc = ensure_single(ctx, w, h);
     if (rc) return rc;
     Plan* pl = ctx->single;
+    // everything the call may hand back, fetched behind the detect chain in one go: count, device flags and as many keypoint /
+    // descriptor records as the caller can take (the count is not known before the wait; a record set is a few tens of KB)
+    const size_t nfetch = (size_t)std::max(0, std::min(cap, pl->kcap));
+    rc = vis_ensure_pin(ctx, (size_t)w * h + nfetch * (sizeof(vis_keypoint) + 32) + 4096);
+    if (rc) return rc;
     std::memset(&ctx->tm, 0, sizeof(ctx->tm));
-    HIPCHK(ctx, hipMemcpy2DAsync(pl->d_stage, pl->stride, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+    HostStage hs(ctx);
+    hs.up2d(pl->d_stage, pl->stride, img, stride, w, h);
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[0], ctx->stream);
     rc = launch_detect(ctx, pl, pl->d_stage, 1, frame_slot);
     if (rc) return rc;
-    int32_t n = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&n, pl->d_nkp + frame_slot, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const int32_t* h_n = (const int32_t*)hs.down(pl->d_nkp + frame_slot, 4);
+    const int32_t* h_fl = (const int32_t*)hs.down(pl->d_flags, 4);
+    const void* h_kps = kps_out && nfetch ? hs.down(pl->d_kps + (size_t)frame_slot * pl->kcap, nfetch * sizeof(vis_keypoint)) : nullptr;
+    const void* h_desc = desc_out && nfetch ? hs.down(pl->d_desc + (size_t)frame_slot * pl->kcap * 32, nfetch * 32) : nullptr;
+    rc = hs.wait();
+    if (rc) return rc;
     collect_detect_timings(ctx);
     { float a = 0; if (ctx->ev_ok && ev_elapsed(&a, ctx->ev[0], ctx->ev[4])) ctx->tm.ms_total = a; }
-    {   // More tied keypoints than the plan's records hold (KeyPointsFilter::retainBest keeps every tie at its cut: a checkerboard)?  The
+    const int32_t n = *h_n, fl = *h_fl;
+    if (fl) {
+        // More tied keypoints than the plan's records hold (KeyPointsFilter::retainBest keeps every tie at its cut: a checkerboard)?  The
         // caller's `cap` says how many it is prepared to take: grow the per-frame capacity towards it -- the other slots' records move
         // into the re-created plan -- and detect again.  Only what exceeds `cap` (or 65535) is an error.
-        int32_t fl = 0;
-        HIPCHK(ctx, hipMemcpy(&fl, pl->d_flags, 4, hipMemcpyDeviceToHost));
         if ((fl & 12) && !(fl & ~12) && cap > pl->kcap && pl->kcap < 65535) {
             HIPCHK(ctx, hipMemset(pl->d_flags, 0, 4));
             const int want = std::min(65535, std::max(cap, 2 * pl->kcap));
@@ -596,14 +653,14 @@ extern "C" int vis_orb_detect_compute(vis_ctx* ctx, const uint8_t* img, int w, i
             if (rc) return rc;
             return vis_orb_detect_compute(ctx, img, w, h, stride, frame_slot, kps_out, desc_out, cap, n_out);
         }
+        rc = check_flags(ctx, pl);                                 // (reads and clears the flags: the error path may block again)
+        if (rc) return rc;
     }
-    rc = check_flags(ctx, pl);
-    if (rc) return rc;
     ctx->slot_valid[frame_slot] = 1;
     *n_out = n;
     if (n > cap && (kps_out || desc_out)) return VIS_E_CAPACITY;
-    if (kps_out && n) HIPCHK(ctx, hipMemcpy(kps_out, pl->d_kps + (size_t)frame_slot * pl->kcap, (size_t)n * sizeof(vis_keypoint), hipMemcpyDeviceToHost));
-    if (desc_out && n) HIPCHK(ctx, hipMemcpy(desc_out, pl->d_desc + (size_t)frame_slot * pl->kcap * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
+    if (kps_out && n) std::memcpy(kps_out, h_kps, (size_t)n * sizeof(vis_keypoint));
+    if (desc_out && n) std::memcpy(desc_out, h_desc, (size_t)n * 32);
     return VIS_OK;
 }
 
@@ -611,25 +668,22 @@ static int set_single_pair(vis_ctx* ctx, Plan* pl, int slot_q, int slot_t) {
     if (!pl) return VIS_E_STATE;
     if (slot_q < 0 || slot_q >= VIS_NSLOTS || slot_t < 0 || slot_t >= VIS_NSLOTS) return VIS_E_INVALID;
     if (!ctx->slot_valid[slot_q] || !ctx->slot_valid[slot_t]) return VIS_E_STATE;
-    int32_t q = slot_q, t = slot_t;
-    HIPCHK(ctx, hipMemcpy(pl->d_pair_q, &q, 4, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(pl->d_pair_t, &t, 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_set_pair, dim3(1), dim3(1), 0, ctx->stream, pl->d_pair_q, pl->d_pair_t, (int32_t)slot_q, (int32_t)slot_t);   // (two blocking 4-byte uploads before)
+    HIPCHK(ctx, hipGetLastError());
     return VIS_OK;
 }
 
-static int download_knn(vis_ctx* ctx, const uint32_t* d_keys, int n, vis_dmatch* out) {
-    if (!out || n <= 0) return VIS_OK;
-    std::vector<uint32_t> k(2 * (size_t)n);
-    HIPCHK(ctx, hipMemcpy(k.data(), d_keys, k.size() * 4, hipMemcpyDeviceToHost));
+static void keys_to_dmatches(const uint32_t* k, int n, vis_dmatch* out) {
+    if (!out) return;
     for (int q = 0; q < n; q++) { key_to_dmatch(k[2 * q], q, out + 2 * q); key_to_dmatch(k[2 * q + 1], q, out + 2 * q + 1); }
-    return VIS_OK;
 }
 
 extern "C" int vis_bf_knn2_hamming(vis_ctx* ctx, int slot_q, int slot_t, vis_dmatch* out12, vis_dmatch* out21) {
     if (!ctx) return VIS_E_INVALID;
     (void)hipSetDevice(ctx->device);
     Plan* pl = ctx->single;
-    int rc = set_single_pair(ctx, pl, slot_q, slot_t);
+    int rc = pl ? vis_ensure_pin(ctx, (size_t)pl->kcap * 16 + 4096) : VIS_E_STATE;
+    if (!rc) rc = set_single_pair(ctx, pl, slot_q, slot_t);
     if (rc) return rc;
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[4], ctx->stream);
     rc = launch_expand(ctx, pl, slot_q, 1);
@@ -637,14 +691,17 @@ extern "C" int vis_bf_knn2_hamming(vis_ctx* ctx, int slot_q, int slot_t, vis_dma
     if (!rc) rc = launch_match(ctx, pl, 1);
     if (rc) return rc;
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[5], ctx->stream);
-    int32_t nq = 0, nt = 0;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    { float a = 0; if (ctx->ev_ok && ev_elapsed(&a, ctx->ev[4], ctx->ev[5])) ctx->tm.ms_knn = a; }
-    HIPCHK(ctx, hipMemcpy(&nq, pl->d_nkp + slot_q, 4, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(&nt, pl->d_nkp + slot_t, 4, hipMemcpyDeviceToHost));
-    rc = download_knn(ctx, pl->d_knn12, nq, out12);
+    HostStage hs(ctx);
+    const int32_t* h_nq = (const int32_t*)hs.down(pl->d_nkp + slot_q, 4);
+    const int32_t* h_nt = (const int32_t*)hs.down(pl->d_nkp + slot_t, 4);
+    const uint32_t* h12 = out12 ? (const uint32_t*)hs.down(pl->d_knn12, (size_t)pl->kcap * 8) : nullptr;
+    const uint32_t* h21 = out21 ? (const uint32_t*)hs.down(pl->d_knn21, (size_t)pl->kcap * 8) : nullptr;
+    rc = hs.wait();
     if (rc) return rc;
-    return download_knn(ctx, pl->d_knn21, nt, out21);
+    { float a = 0; if (ctx->ev_ok && ev_elapsed(&a, ctx->ev[4], ctx->ev[5])) ctx->tm.ms_knn = a; }
+    keys_to_dmatches(h12, std::min(*h_nq, pl->kcap), out12);
+    keys_to_dmatches(h21, std::min(*h_nt, pl->kcap), out21);
+    return VIS_OK;
 }
 
 extern "C" int vis_bf_knn2_hamming_host(vis_ctx* ctx, const uint8_t* desc_q, int n_q, const uint8_t* desc_t, int n_t,
@@ -654,6 +711,7 @@ extern "C" int vis_bf_knn2_hamming_host(vis_ctx* ctx, const uint8_t* desc_q, int
     (void)hipSetDevice(ctx->device);
     const int kcap = std::max(std::max(n_q, n_t), 1);
     int rc = ensure_scratch(ctx, (size_t)kcap * 32 * 2 + (size_t)kcap * 8 * 2 + (size_t)kcap * 256 + 8192);
+    if (!rc) rc = vis_ensure_pin(ctx, (size_t)kcap * (64 + 16) + 4096);
     if (rc) return rc;
     Carver cv{(char*)ctx->d_scratch, 0};
     Plan tp;
@@ -662,40 +720,51 @@ extern "C" int vis_bf_knn2_hamming_host(vis_ctx* ctx, const uint8_t* desc_q, int
     tp.d_nkp = cv.take<int32_t>(2); tp.d_pair_q = cv.take<int32_t>(1); tp.d_pair_t = cv.take<int32_t>(1);
     tp.d_knn12 = cv.take<uint32_t>((size_t)kcap * 2); tp.d_knn21 = cv.take<uint32_t>((size_t)kcap * 2);
     tp.d_descx = cv.take<int8_t>((size_t)kcap * 256);
-    const int32_t nk[2] = {n_q, n_t}, zero = 0, one = 1;
-    if (n_q) HIPCHK(ctx, hipMemcpy(tp.d_desc, desc_q, (size_t)n_q * 32, hipMemcpyHostToDevice));
-    if (n_t) HIPCHK(ctx, hipMemcpy(tp.d_desc + (size_t)kcap * 32, desc_t, (size_t)n_t * 32, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(tp.d_nkp, nk, 8, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(tp.d_pair_q, &zero, 4, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(tp.d_pair_t, &one, 4, hipMemcpyHostToDevice));
+    const int32_t nk[2] = {n_q, n_t};
+    HostStage hs(ctx);
+    hs.up(tp.d_desc, desc_q, (size_t)n_q * 32);
+    hs.up(tp.d_desc + (size_t)kcap * 32, desc_t, (size_t)n_t * 32);
+    hs.up(tp.d_nkp, nk, 8);
+    hipLaunchKernelGGL(k_set_pair, dim3(1), dim3(1), 0, ctx->stream, tp.d_pair_q, tp.d_pair_t, 0, 1);
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[4], ctx->stream);
     rc = launch_expand(ctx, &tp, 0, 2);
     if (!rc) rc = launch_match(ctx, &tp, 1);
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[5], ctx->stream);
-    if (rc) return rc;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    { float a = 0; if (ctx->ev_ok && ev_elapsed(&a, ctx->ev[4], ctx->ev[5])) ctx->tm.ms_knn = a; }
-    rc = download_knn(ctx, tp.d_knn12, n_q, out12);
-    if (rc) return rc;
-    rc = download_knn(ctx, tp.d_knn21, n_t, out21);
+    const uint32_t* h12 = out12 && n_q ? (const uint32_t*)hs.down(tp.d_knn12, (size_t)n_q * 8) : nullptr;
+    const uint32_t* h21 = out21 && n_t ? (const uint32_t*)hs.down(tp.d_knn21, (size_t)n_t * 8) : nullptr;
     tp = Plan();       // scratch-owned pointers: nothing to free
-    return rc;
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    rc = hs.wait();
+    if (rc) return rc;
+    { float a = 0; if (ctx->ev_ok && ev_elapsed(&a, ctx->ev[4], ctx->ev[5])) ctx->tm.ms_knn = a; }
+    if (h12) keys_to_dmatches(h12, n_q, out12);
+    if (h21) keys_to_dmatches(h21, n_t, out21);
+    return VIS_OK;
 }
 
-static int download_matches(vis_ctx* ctx, Plan* pl, int pair, vis_dmatch* good, int cap, int* n_good,
-                            vis_dmatch* sym_out, int sym_cap, int* n_sym) {
-    int32_t ng = 0, ns = 0;
-    HIPCHK(ctx, hipMemcpy(&ng, pl->d_ngood + pair, 4, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(&ns, pl->d_nsym + pair, 4, hipMemcpyDeviceToHost));
+// the filter results of one pair: queued behind the filter kernel, copied out after the call's wait
+struct MatchFetch { const int32_t* ng; const int32_t* ns; const void* good; const void* sym; size_t ngood_cap, nsym_cap; };
+static MatchFetch fetch_matches(HostStage& hs, Plan* pl, int pair, bool want_good, int cap, bool want_sym, int sym_cap) {
+    MatchFetch f = {};
+    f.ng = (const int32_t*)hs.down(pl->d_ngood + pair, 4);
+    f.ns = (const int32_t*)hs.down(pl->d_nsym + pair, 4);
+    f.ngood_cap = (size_t)std::max(0, std::min(cap, pl->root * pl->root));
+    f.nsym_cap = (size_t)std::max(0, std::min(sym_cap, pl->kcap));
+    if (want_good && f.ngood_cap) f.good = hs.down(pl->d_good + (size_t)pair * pl->root * pl->root, f.ngood_cap * sizeof(vis_dmatch));
+    if (want_sym && f.nsym_cap) f.sym = hs.down(pl->d_sym + (size_t)pair * pl->kcap, f.nsym_cap * sizeof(vis_dmatch));
+    return f;
+}
+static int deliver_matches(const MatchFetch& f, vis_dmatch* good, int cap, int* n_good, vis_dmatch* sym_out, int sym_cap, int* n_sym) {
+    const int ng = *f.ng, ns = *f.ns;
     if (n_good) *n_good = ng;
     if (n_sym) *n_sym = ns;
     if (good) {
         if (ng > cap) return VIS_E_CAPACITY;
-        if (ng) HIPCHK(ctx, hipMemcpy(good, pl->d_good + (size_t)pair * pl->root * pl->root, (size_t)ng * sizeof(vis_dmatch), hipMemcpyDeviceToHost));
+        if (ng) std::memcpy(good, f.good, (size_t)ng * sizeof(vis_dmatch));
     }
     if (sym_out) {
         if (ns > sym_cap) return VIS_E_CAPACITY;
-        if (ns) HIPCHK(ctx, hipMemcpy(sym_out, pl->d_sym + (size_t)pair * pl->kcap, (size_t)ns * sizeof(vis_dmatch), hipMemcpyDeviceToHost));
+        if (ns) std::memcpy(sym_out, f.sym, (size_t)ns * sizeof(vis_dmatch));
     }
     return VIS_OK;
 }
@@ -705,7 +774,8 @@ extern "C" int vis_good_matches(vis_ctx* ctx, int slot_prev, int slot_cur, vis_d
     if (!ctx) return VIS_E_INVALID;
     (void)hipSetDevice(ctx->device);
     Plan* pl = ctx->single;
-    int rc = set_single_pair(ctx, pl, slot_prev, slot_cur);
+    int rc = pl ? vis_ensure_pin(ctx, ((size_t)pl->kcap + (size_t)pl->root * pl->root) * sizeof(vis_dmatch) + 4096) : VIS_E_STATE;
+    if (!rc) rc = set_single_pair(ctx, pl, slot_prev, slot_cur);
     if (rc) return rc;
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[4], ctx->stream);
     rc = launch_expand(ctx, pl, slot_prev, 1);
@@ -716,11 +786,14 @@ extern "C" int vis_good_matches(vis_ctx* ctx, int slot_prev, int slot_cur, vis_d
     rc = launch_filter(ctx, pl, 1);
     if (rc) return rc;
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[6], ctx->stream);
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HostStage hs(ctx);
+    const MatchFetch f = fetch_matches(hs, pl, 0, good != nullptr, cap, sym_out != nullptr, sym_cap);
+    rc = hs.wait();
+    if (rc) return rc;
     { float a = 0;
       if (ctx->ev_ok && ev_elapsed(&a, ctx->ev[4], ctx->ev[5])) ctx->tm.ms_knn = a;
       if (ctx->ev_ok && ev_elapsed(&a, ctx->ev[5], ctx->ev[6])) ctx->tm.ms_filter = a; }
-    return download_matches(ctx, pl, 0, good, cap, n_good, sym_out, sym_cap, n_sym);
+    return deliver_matches(f, good, cap, n_good, sym_out, sym_cap, n_sym);
 }
 
 static uint32_t dmatch_to_key(const vis_dmatch& m) {
@@ -753,22 +826,25 @@ extern "C" int vis_good_matches_host(vis_ctx* ctx, const vis_keypoint* kps1, int
     std::vector<uint32_t> k12(2 * (size_t)kcap, 0xFFFFFFFFu), k21(2 * (size_t)kcap, 0xFFFFFFFFu);
     for (int i = 0; i < 2 * n1; i++) k12[i] = dmatch_to_key(knn12[i]);
     for (int i = 0; i < 2 * n2; i++) k21[i] = dmatch_to_key(knn21[i]);
-    const int32_t nk[2] = {n1, n2}, zero = 0, one = 1;
-    if (n1) HIPCHK(ctx, hipMemcpy(tp.d_kps, kps1, (size_t)n1 * sizeof(vis_keypoint), hipMemcpyHostToDevice));
-    if (n2) HIPCHK(ctx, hipMemcpy(tp.d_kps + kcap, kps2, (size_t)n2 * sizeof(vis_keypoint), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(tp.d_nkp, nk, 8, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(tp.d_pair_q, &zero, 4, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(tp.d_pair_t, &one, 4, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(tp.d_knn12, k12.data(), k12.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(tp.d_knn21, k21.data(), k21.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(tp.d_hf, hf.data(), (size_t)root * 4, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(tp.d_wf, wf.data(), (size_t)root * 4, hipMemcpyHostToDevice));
-    rc = launch_filter(ctx, &tp, 1);
+    const int32_t nk[2] = {n1, n2};
+    rc = vis_ensure_pin(ctx, (size_t)kcap * (2 * sizeof(vis_keypoint) + 16 + sizeof(vis_dmatch)) + (size_t)ncell * sizeof(vis_dmatch) + (size_t)root * 8 + 8192);
     if (rc) { tp = Plan(); return rc; }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    rc = download_matches(ctx, &tp, 0, good, cap, n_good, sym_out, sym_cap, n_sym);
+    HostStage hs(ctx);
+    hs.up(tp.d_kps, kps1, (size_t)n1 * sizeof(vis_keypoint));
+    hs.up(tp.d_kps + kcap, kps2, (size_t)n2 * sizeof(vis_keypoint));
+    hs.up(tp.d_nkp, nk, 8);
+    hipLaunchKernelGGL(k_set_pair, dim3(1), dim3(1), 0, ctx->stream, tp.d_pair_q, tp.d_pair_t, 0, 1);
+    hs.up(tp.d_knn12, k12.data(), k12.size() * 4);
+    hs.up(tp.d_knn21, k21.data(), k21.size() * 4);
+    hs.up(tp.d_hf, hf.data(), (size_t)root * 4);
+    hs.up(tp.d_wf, wf.data(), (size_t)root * 4);
+    rc = launch_filter(ctx, &tp, 1);
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); tp = Plan(); return rc; }
+    const MatchFetch f = fetch_matches(hs, &tp, 0, good != nullptr, cap, sym_out != nullptr, sym_cap);
     tp = Plan();
-    return rc;
+    rc = hs.wait();
+    if (rc) return rc;
+    return deliver_matches(f, good, cap, n_good, sym_out, sym_cap, n_sym);
 }
 
 // shared by vis_essential_ransac / vis_recover_pose
@@ -794,24 +870,28 @@ static int pose_host(vis_ctx* ctx, const float* p1xy, const float* p2xy, int m, 
     PoseOut* d_pose = cv.take<PoseOut>(1);
     int32_t* d_worklist = cv.take<int32_t>(3);
     double* d_hyp = cv.take<double>((size_t)iters * VIS_HYP_DOUBLES);
-    if (m) {
-        HIPCHK(ctx, hipMemcpy(d_p1, p1xy, (size_t)m * 8, hipMemcpyHostToDevice));
-        HIPCHK(ctx, hipMemcpy(d_p2, p2xy, (size_t)m * 8, hipMemcpyHostToDevice));
-    }
+    rc = vis_ensure_pin(ctx, (size_t)mcap * 17 + sizeof(PoseOut) + 4096);
+    if (rc) return rc;
+    HostStage hs(ctx);
+    hs.up(d_p1, p1xy, (size_t)m * 8);
+    hs.up(d_p2, p2xy, (size_t)m * 8);
     const int32_t mm = m;
-    HIPCHK(ctx, hipMemcpy(d_npts, &mm, 4, hipMemcpyHostToDevice));
-    if (E_in) HIPCHK(ctx, hipMemcpy(d_E, E_in, 72, hipMemcpyHostToDevice));
+    hs.up(d_npts, &mm, 4);
+    if (E_in) hs.up(d_E, E_in, 72);
     rc = vis_build_sample_table(ctx, std::min(m, 64));
     if (rc) return rc;
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[6], ctx->stream);
     rc = pose_run(ctx, 1, mcap, iters, d_p1, d_p2, d_npts, d_n1, d_n2, d_samples, d_models, d_counts, d_rstate,
                   E_in ? d_E : nullptr, d_mask, d_pose, do_ransac, do_pose, d_worklist, d_hyp);
-    if (rc) return rc;
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[7], ctx->stream);
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const void* h_pose = hs.down(d_pose, sizeof(PoseOut));
+    const void* h_mask = mask && m ? hs.down(d_mask, (size_t)m) : nullptr;
+    rc = hs.wait();
+    if (rc) return rc;
     { float a = 0; if (ctx->ev_ok && ev_elapsed(&a, ctx->ev[6], ctx->ev[7])) ctx->tm.ms_pose = a; }
-    HIPCHK(ctx, hipMemcpy(out, d_pose, sizeof(PoseOut), hipMemcpyDeviceToHost));
-    if (mask && m) HIPCHK(ctx, hipMemcpy(mask, d_mask, (size_t)m, hipMemcpyDeviceToHost));
+    std::memcpy(out, h_pose, sizeof(PoseOut));
+    if (h_mask) std::memcpy(mask, h_mask, (size_t)m);
     return VIS_OK;
 }
 
@@ -867,6 +947,32 @@ extern "C" int vis_f2f_ransac(vis_ctx* ctx, const vis_keypoint* pts1, const vis_
         if (c[4 * (size_t)i] > countMax) { countMax = c[4 * (size_t)i]; best[0] = c[4 * (size_t)i + 1]; best[1] = c[4 * (size_t)i + 2]; best[2] = c[4 * (size_t)i + 3]; }
     for (int k = 0; k < 3; k++) out_t[k] = scale * best[k];
     if (count_max) *count_max = (int)countMax;
+    return VIS_OK;
+}
+
+// blocking downloads of the batch getters (vis_batch_get_*: test / inspection entry points behind a full synchronisation)
+static int download_knn(vis_ctx* ctx, const uint32_t* d_keys, int n, vis_dmatch* out) {
+    if (!out || n <= 0) return VIS_OK;
+    std::vector<uint32_t> k(2 * (size_t)n);
+    HIPCHK(ctx, hipMemcpy(k.data(), d_keys, k.size() * 4, hipMemcpyDeviceToHost));
+    keys_to_dmatches(k.data(), n, out);
+    return VIS_OK;
+}
+static int download_matches(vis_ctx* ctx, Plan* pl, int pair, vis_dmatch* good, int cap, int* n_good,
+                            vis_dmatch* sym_out, int sym_cap, int* n_sym) {
+    int32_t ng = 0, ns = 0;
+    HIPCHK(ctx, hipMemcpy(&ng, pl->d_ngood + pair, 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(&ns, pl->d_nsym + pair, 4, hipMemcpyDeviceToHost));
+    if (n_good) *n_good = ng;
+    if (n_sym) *n_sym = ns;
+    if (good) {
+        if (ng > cap) return VIS_E_CAPACITY;
+        if (ng) HIPCHK(ctx, hipMemcpy(good, pl->d_good + (size_t)pair * pl->root * pl->root, (size_t)ng * sizeof(vis_dmatch), hipMemcpyDeviceToHost));
+    }
+    if (sym_out) {
+        if (ns > sym_cap) return VIS_E_CAPACITY;
+        if (ns) HIPCHK(ctx, hipMemcpy(sym_out, pl->d_sym + (size_t)pair * pl->kcap, (size_t)ns * sizeof(vis_dmatch), hipMemcpyDeviceToHost));
+    }
     return VIS_OK;
 }
 

@@ -139,6 +139,11 @@ struct vis_ctx {
     bool ev_ok = false;
     // grow-only scratch for the *_host entry points
     void* d_scratch = nullptr; size_t scratch_bytes = 0;
+    // grow-only PINNED host block of the single-frame entry points: a caller's pageable buffer is copied through it, so that every
+    // upload / download of a call is an asynchronous copy on the context's stream and the call blocks ONCE, at its end (HostStage, api.hip)
+    void* h_pin = nullptr; size_t h_pin_bytes = 0;
+    // diagnostics of the single-frame path (vis_debug_counters): times the host blocked on the device / copies queued since the context was made
+    unsigned long long n_host_waits = 0, n_copies = 0;
     int slot_valid[VIS_NSLOTS];
     // cv::RNG sample tables for M in [6, sample_max_m], built on the host for (seed, max_iters)
     int32_t* d_sample_table = nullptr; int sample_max_m = 0; int sample_iters = 0; unsigned long long sample_seed = 0;
@@ -153,6 +158,13 @@ struct VisRange { explicit VisRange(const char* n) { roctxRangePushA(n); } ~VisR
 struct VisRange { explicit VisRange(const char*) {} };
 #endif
 
+// every kernel launch of the library is counted (vis_debug_counters: launches per frame of the single-frame path, bench.py's
+// single_frame_api leg): one increment of a plain global beside a launch that costs microseconds
+extern unsigned long long vis_g_launches;
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
+    do { ++vis_g_launches; kernel<<<(grid), (block), (lds), (stream)>>>(__VA_ARGS__); } while (0)
+
 #define HIPCHK(ctx, call)                                                          \
     do { hipError_t e_ = (call);                                                   \
          if (e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); \
@@ -164,6 +176,58 @@ struct Carver {
     template <class T> T* take(size_t count) { off = (off + 255) & ~(size_t)255; T* p = (T*)(base + off); off += count * sizeof(T); return p; }
 };
 int vis_ensure_scratch(vis_ctx* ctx, size_t bytes);
+
+// ---- host staging of the single-frame entry points (api.hip explains; vis_ensure_pin grows the context's pinned block) ----
+#include <cstring>
+#include <algorithm>
+int vis_ensure_pin(vis_ctx* ctx, size_t bytes);
+struct HostStage {
+    vis_ctx* ctx; char* base; size_t off = 0; hipError_t err = hipSuccess; bool overflow = false;
+    explicit HostStage(vis_ctx* c) : ctx(c), base((char*)c->h_pin) {}
+    void* take(size_t bytes) {
+        off = (off + 63) & ~(size_t)63;
+        if (off + bytes > ctx->h_pin_bytes) { overflow = true; return nullptr; }
+        void* p = base + off; off += bytes; return p;
+    }
+    // host (pageable) -> device, asynchronous: through the pinned block
+    void up(void* d, const void* h, size_t bytes) {
+        if (!bytes) return;
+        void* p = take(bytes);
+        if (!p) return;
+        std::memcpy(p, h, bytes);
+        const hipError_t e = hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess && err == hipSuccess) err = e;
+        ctx->n_copies++;
+    }
+    // rows of an image with a host stride -> a device image with its own stride
+    void up2d(void* d, size_t dpitch, const void* h, size_t hpitch, size_t width, size_t height) {
+        char* p = (char*)take(width * height);
+        if (!p) return;
+        for (size_t y = 0; y < height; y++) std::memcpy(p + y * width, (const char*)h + y * hpitch, width);
+        const hipError_t e = hipMemcpy2DAsync(d, dpitch, p, width, width, height, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess && err == hipSuccess) err = e;
+        ctx->n_copies++;
+    }
+    // device -> the pinned block, asynchronous; valid after wait()
+    void* down(const void* d, size_t bytes) {
+        void* p = take(std::max(bytes, (size_t)4));
+        if (!p || !bytes) return p;
+        const hipError_t e = hipMemcpyAsync(p, d, bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess && err == hipSuccess) err = e;
+        ctx->n_copies++;
+        return p;
+    }
+    // the one place a single-frame entry point blocks
+    int wait() {
+        if (overflow) { ctx->err = "host staging block too small (internal)"; return VIS_E_NOMEM; }
+        if (err != hipSuccess) { ctx->err = std::string("staged copy: ") + hipGetErrorString(err); return VIS_E_HIP; }
+        ctx->n_host_waits++;
+        const hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { ctx->err = std::string("hipStreamSynchronize: ") + hipGetErrorString(e); return VIS_E_HIP; }
+        return VIS_OK;
+    }
+};
+
 
 // ---- host-side geometry / tables (geometry.cpp) ----
 int  vis_compute_levels(const vis_params& p, int w, int h, int stride0, LevelInfo* lv);

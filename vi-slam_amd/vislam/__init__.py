@@ -110,7 +110,7 @@ ABI_SYMBOLS = [
     "vis_bf_knn2_hamming_host", "vis_good_matches", "vis_good_matches_host", "vis_essential_ransac",
     "vis_recover_pose", "vis_f2f_ransac", "vis_batch_plan", "vis_batch_reset", "vis_batch_run",
     "vis_batch_sync", "vis_batch_get_keypoints", "vis_batch_get_knn", "vis_batch_get_matches",
-    "vis_batch_get_pose", "vis_batch_get_inlier_mask", "vis_batch_status", "vis_synth_canvas", "vis_synth_frame",
+    "vis_batch_get_pose", "vis_batch_get_inlier_mask", "vis_debug_counters", "vis_batch_status", "vis_synth_canvas", "vis_synth_frame",
     "vis_gradient_frame_elems", "vis_half_pyramid_dims", "vis_gradient_batch", "vis_compute_gradient", "vis_patch_points",
     "vis_image_list", "vis_image_time", "vis_pgm_info", "vis_image_read",
     "vis_feeder_create", "vis_feeder_destroy", "vis_feeder_host_buffer", "vis_feeder_submit", "vis_feeder_release",
@@ -159,7 +159,9 @@ def _load():
     lib.vis_batch_get_knn.argtypes = [vp, ci, vp, ci, ip, vp, ci, ip]
     lib.vis_batch_get_matches.argtypes = [vp, ci, vp, ci, ip, ip]
     lib.vis_batch_get_pose.argtypes = [vp, ci, vp, vp, vp, ip, ip, ip]
-    lib.vis_batch_get_inlier_mask.argtypes = [vp, ci, vp, ci, ip]
+    if hasattr(lib, "vis_debug_counters"):              # (absent from older A/B builds selected with VISLAM_HIP_LIB)
+        lib.vis_batch_get_inlier_mask.argtypes = [vp, ci, vp, ci, ip]
+        lib.vis_debug_counters.argtypes = [vp, vp]
     lib.vis_batch_status.argtypes = [vp, ip]
     lib.vis_synth_canvas.argtypes = [vp, ci, C.c_uint64]
     lib.vis_synth_frame.argtypes = [vp, ci, C.c_uint64, ci, ci, ci, vp, ci]
@@ -629,6 +631,12 @@ class Context:
         ng, ns = C.c_int(0), C.c_int(0)
         self._chk(lib.vis_batch_get_matches(self._h, frame, _ptr(good), 1024, C.byref(ng), C.byref(ns)), "vis_batch_get_matches")
         return good[:ng.value].copy(), ns.value
+
+    def debug_counters(self):
+        """(kernel launches of the process, host waits of this context's single-frame entry points, asynchronous copies they queued)"""
+        out = (C.c_ulonglong * 4)()
+        self._chk(lib.vis_debug_counters(self._h, out), "vis_debug_counters")
+        return int(out[0]), int(out[1]), int(out[2])
 
     def batch_inlier_mask(self, frame, cap=16384):
         mask = np.zeros(cap, np.uint8)
