@@ -207,3 +207,37 @@ def test_invalid_arguments_are_rejected(vislam, ctx):
         ctx.orb_detect_compute(np.zeros((40, 40), np.uint8))        # smaller than twice the border
     with pytest.raises(vislam.VisError):
         ctx.camera_update(np.zeros((12, 100), np.uint8))             # smaller than 16 rows
+
+
+def _saturated_periodic():
+    """6992 bright pixels in pairs 4 apart (identical FAST scores, identical Harris responses: the partner is outside the radius-3 ring but
+    inside the 9 x 9 Harris window, which RAISES the response) + 4416 isolated ones on a 5-pixel lattice (same FAST score, lower response)"""
+    img = np.full((480, 752), 128, np.uint8)
+    n_a = n_c = 0
+    for y in range(35, 35 + 46 * 5, 5):
+        for x in range(33, 33 + 76 * 9, 9):
+            img[y, x] = 255; img[y, x + 4] = 255; n_a += 2
+    for y in range(285, 285 + 32 * 5, 5):
+        for x in range(33, 33 + 138 * 5, 5):
+            img[y, x] = 255; n_c += 1
+    return img, n_a, n_c
+
+
+def test_saturated_and_periodic_image_returns_every_tie(vislam, orc, ctx):
+    """A saturated AND periodic image (round 4's last internal VIS_E_CAPACITY on valid input): 11408 identical FAST scores --
+    more survivors of the FAST cut than the largest LDS sort holds (8192) -> k_select's windowed mode -- of which 6992 tie at the Harris cut:
+    more carried ties than three quarters of the sort, which round 4 reported as VIS_E_CAPACITY.  KeyPointsFilter::retainBest -- and the
+    oracle -- keep every tie; so does the second walk of the windowed mode now, up to the caller's keypoint_capacity."""
+    img, n_a, n_c = _saturated_periodic()
+    assert n_a == 6992 and n_a > 6144 and n_a + n_c > 8192
+    p = vislam.default_params()
+    p.nfeatures, p.nlevels, p.w_size, p.h_size = 300, 1, 752, 480
+    p.keypoint_capacity = 12000
+    k, d = _check(vislam, orc, ctx, p, img, cap=12000)
+    assert len(k) == n_a and np.unique(k["response"]).size == 1      # every tied keypoint of the pairs, none of the isolated ones
+    # the caller's own capacity is still what bounds the output: too small -> VIS_E_CAPACITY, never a silent cut
+    p.keypoint_capacity = 3000
+    ctx.set_params(p)
+    with pytest.raises(vislam.VisError) as ei:
+        ctx.orb_detect_compute(img, slot=0, cap=3000)
+    assert ei.value.code == -4

@@ -729,6 +729,10 @@ __device__ __forceinline__ float harris7(const uint8_t* __restrict__ img, int st
     return (fa * fb - fc * fc - 0.04f * s * s) * scale_sq_sq;
 }
 
+// the same as a real function: the second walk of k_select's windowed mode (rare: saturated images) calls it, so that a second inlined
+// copy of the 27 loads does not raise the register count of the whole kernel (64 VGPRs = 8 waves per SIMD on the common path)
+__device__ __attribute__((noinline)) float harris7_call(const uint8_t* __restrict__ img, int stride, int x, int y) { return harris7(img, stride, x, y); }
+
 #ifdef VIS_FAST_PROFILE
 __device__ unsigned long long g_sel_stamps[VIS_MAX_LEVELS * 8];      // diagnostic build: cycles per (level, phase) summed over workgroups
 extern "C" int vis_debug_select_stamps(unsigned long long out[VIS_MAX_LEVELS * 8]) {
