@@ -202,6 +202,12 @@ def matcher_roofline(ms_knn, n_desc, pairs, pmc_path=None):
         # SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD; GRBM_GUI_ACTIVE is summed over the 8 XCDs: cycles x 1024 SIMDs
         out["mfma_busy_frac"] = raw["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (raw["GRBM_GUI_ACTIVE"]["mean"] / 8 * 1024)
         out["counters_from"] = "profiles/pmc_traffic.json raw.k_knn_mfma (TCC_HIT_sum, TCC_MISS_sum, SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE; 512 frames per launch)"
+        # HBM traffic of k_knn_mfma against what it must read: the expanded descriptors (128 B each) of both frames of every pair
+        pj = json.load(open(pmc_path or os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        alg_b = 2.0 * n_desc * 128 * pj["batch_frames"]
+        out["hbm_traffic_bytes_per_launch_at_pmc_batch"] = pj["k_knn_mfma"]["hbm_bytes_per_launch"]
+        out["algorithmic_bytes_per_launch_at_pmc_batch"] = alg_b
+        out["traffic_over_algorithmic"] = pj["k_knn_mfma"]["hbm_bytes_per_launch"] / alg_b
     except Exception as e:
         out["counters_error"] = repr(e)
     return out
@@ -319,9 +325,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)   # 200 x 3.7 ms: a timed region long enough for an outside observer (rocm-smi) to see
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="frames per LAUNCH of the pipeline (the plan's device buffers are sized for it)")
-    ap.add_argument("--launches-per-step", type=int, default=4,
-                    help="a step = this many consecutive launches over consecutive frames of the stream (4 x 1024 = 4096 frames per step): the driver's "
-                         "--steps 20 is then 80 launches (0.2 s) instead of 20 (55 ms, 2-3 of which fill and drain the three-stage pipeline)")
+    ap.add_argument("--launches-per-step", type=int, default=20,
+                    help="a step = this many consecutive launches over consecutive frames of the stream (20 x 1024 = 20480 frames per step, 15 GB of resident "
+                         "frames with --ring 2): the driver's --steps 20 is then 400 launches = 1 s of steady state that an outside sampler (rocm-smi) can see "
+                         "(4 launches per step in round 4: 0.2 s, every busy sample read 0 %)")
     ap.add_argument("--ring", type=int, default=2, help="distinct steps' worth of frames resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the side legs (profiling runs)")
@@ -355,7 +362,13 @@ def main():
     stream = Stream(ctx, dev, W, H, B * Q * R, seed)      # generated on the device: no host synthesis, no H2D
     ctx.batch_plan(W, H, W, B)
     dt, step_q = timed_steps(ctx, stream, B, R, a.stages, a.steps, a.warmup, dist, dev, q=Q)
+    dt_rank = dt
     dt = vdist.max_over_ranks(dt, dist, dev)
+    # who ran where: one all_gather of a small POD per rank behind the timed region (N ranks must sit on N different devices)
+    dev_index = local_rank if world > 1 else 0
+    ranks = vdist.gather_rank_records(vdist.pack_rank_record(rank, dev_index, a.steps * B * Q / dt_rank, dt_rank, vislam.device_pci_bus_id(dev_index)),
+                                      dist, dev, world)
+    vdist.check_distinct_devices(ranks)
 
     def step(i):                                          # ONE launch (per-kernel timings, pose load: per launch of B frames)
         ctx.batch_run(stream.ptr((i % (R * Q)) * B), B, a.stages)
@@ -690,10 +703,29 @@ def main():
                             "times from this run; a kernel made of both instruction classes sits between the two measured ceilings"}
         except Exception as e:                                  # loud: the record says what is missing
             valu = {"error": f"profiles/pmc_traffic.json unusable: {e!r}"}
+        # the bound that explains the headline: every vector instruction of the step (all kernels, counter passes) against the time a step takes
+        issue = None
+        try:
+            pj2 = json.load(open(pmc))
+            st_ = pj2["step"]
+            vi_launch = st_["valu_wave_insts_per_step"] * (B / pj2["batch_frames"])
+            t_launch = dt / a.steps / Q
+            pk = pj2["valu_peak_measured"]
+            issue = {"what": "whole step: sum of SQ_INSTS_VALU over every kernel of one launch of frames_per_launch frames (committed counter passes, scaled "
+                             "linearly from their batch) / this run's time per launch", "valu_wave_insts_per_launch": vi_launch,
+                     "salu_wave_insts_per_launch": st_["salu_wave_insts_per_step"] * (B / pj2["batch_frames"]),
+                     "ms_per_launch": t_launch * 1e3, "achieved": vi_launch / t_launch, "unit": "wave-instr/s",
+                     "peak_measured_half_rate_class": pk["half_rate_class"], "peak_measured_full_rate_class": pk["full_rate_class"],
+                     "frac_of_half_rate_ceiling": vi_launch / t_launch / pk["half_rate_class"], "frac_of_full_rate_ceiling": vi_launch / t_launch / pk["full_rate_class"],
+                     "frac": vi_launch / t_launch / pk["half_rate_class"], "valu_wave_insts_per_kernel_at_pmc_batch": st_["valu_wave_insts_per_kernel"],
+                     "pmc_measured_at_commit": pmc_commit}
+        except Exception as e:
+            issue = {"error": f"profiles/pmc_traffic.json has no step totals: {e!r}"}
         fps = vdist.aggregate_fps(world, a.steps, B * Q, dt)
         out = {
             "metric": "frames/sec detect+match+pose, 752x480 mono8", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "ranks": ranks,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "S-752: synthetic 752x480 mono8 EuRoC-shaped stream (frames resident in HBM), 1000 ORB kps x 8 levels, BF-Hamming k=2 "
                                    "both directions + ratio/sym/grid filter, essential RANSAC (adaptive, max 1000) + recoverPose.  S-752 is a planar "
@@ -712,6 +744,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": per_launch_s * 1e3},
             "valu_roofline": valu,
+            "issue_roofline": issue,
             "fast_threshold_prediction": {"tau_next_per_level": [int(x) for x in tau_next], "fast_threshold": int(p.fast_threshold),
                                           "frame_level_pairs_redone_in_the_last_step": int(redone),
                                           "what": "thresholds the next batch's k_fast starts from (min over the last batch's frames of the "

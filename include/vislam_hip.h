@@ -127,6 +127,9 @@ const char* vis_version(void);
 const char* vis_strerror(int code);
 /* replaces cv::cuda::getCudaEnabledDeviceCount(), src/main_vi_slamGPU.cpp:41 */
 int  vis_device_count(void);
+/* PCI address "dddd:bb:dd.f" of HIP device `device` (len >= 16): the multi-GPU launchers gather it per rank (generalises the device
+ * selection of src/main_vi_slamGPU.cpp:41-43: N ranks must sit on N different devices) */
+int  vis_device_pci_bus_id(int device, char* out, int len);
 /* replaces cv::cuda::setDevice(0), src/main_vi_slamGPU.cpp:43, plus object construction */
 int  vis_create(int device, vis_ctx** out);
 void vis_destroy(vis_ctx* ctx);

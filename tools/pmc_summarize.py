@@ -65,5 +65,17 @@ for k in ("k_fast", "k_resize", "k_describe", "k_knn2", "k_knn_mfma", "k_expand"
             # (8 CUs each) -> the fraction of the launch during which a CU's LDS array is busy
             res[k]["lds_idx_active_cycles"] = sq["SQ_LDS_IDX_ACTIVE"]["mean"]
             res[k]["lds_busy_frac"] = sq["SQ_LDS_IDX_ACTIVE"]["mean"] / (sq["SQ_BUSY_CYCLES"]["mean"] * 8.0)
+# the whole step: every kernel of the pipeline (k_synth generates the stream, the rocclr kernels are the profiler workload's own copies / fills)
+step_valu = step_salu = 0.0
+per_kernel = {}
+for k, cs in summary.items():
+    if not k.startswith("k_") or k in ("k_synth", "k_resize_tab") or "SQ_INSTS_VALU" not in cs:
+        continue
+    per_step = cs["SQ_INSTS_VALU"]["mean"] * cs["SQ_INSTS_VALU"]["calls"] / steps
+    step_valu += per_step
+    step_salu += cs.get("SQ_INSTS_SALU", {}).get("mean", 0.0) * cs.get("SQ_INSTS_SALU", {}).get("calls", 0) / steps
+    per_kernel[k] = round(per_step)
+res["step"] = {"what": "sum over every kernel of one pipelined step (all launches of the step), counter means x launches per step",
+               "valu_wave_insts_per_step": step_valu, "salu_wave_insts_per_step": step_salu, "valu_wave_insts_per_kernel": per_kernel, "steps_counted": steps}
 json.dump(res, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "raw"}, indent=1))

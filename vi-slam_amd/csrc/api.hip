@@ -25,6 +25,17 @@ extern "C" const char* vis_strerror(int code) {
     }
 }
 
+// "dddd:bb:dd.f" of a HIP device: what the multi-GPU launchers gather per rank to show that N ranks ran on N different devices
+extern "C" int vis_device_pci_bus_id(int device, char* out, int len) {
+    if (!out || len < 16) return VIS_E_INVALID;
+    out[0] = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return VIS_E_NODEVICE; }
+    if (device < 0 || device >= n) return VIS_E_INVALID;
+    if (hipDeviceGetPCIBusId(out, len, device) != hipSuccess) { (void)hipGetLastError(); return VIS_E_HIP; }
+    return VIS_OK;
+}
+
 extern "C" int vis_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

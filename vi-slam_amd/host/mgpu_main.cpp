@@ -101,17 +101,42 @@ static int run_rank(int rank, int world, int steps, int warmup, int B, const std
     CK_HIP(hipDeviceSynchronize());
     CK_NCCL(ncclAllReduce(d_one, d_one, 1, ncclInt, ncclSum, comm, cs)); CK_HIP(hipStreamSynchronize(cs));
     double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const double dt_rank = dt;
     CK_HIP(hipMemcpy(d_t, &dt, sizeof(double), hipMemcpyHostToDevice));
     CK_NCCL(ncclAllReduce(d_t, d_t, 1, ncclDouble, ncclMax, comm, cs)); CK_HIP(hipStreamSynchronize(cs));
     CK_HIP(hipMemcpy(&dt, d_t, sizeof(double), hipMemcpyDeviceToHost));
     CK_VIS(vis_batch_status(ctx, &flags));
     if (flags) { std::fprintf(stderr, "rank %d: device capacity flag %d\n", rank, flags); return 6; }
+    // ---- who ran where: one ncclAllGather of a 64-byte POD per rank behind the timed region (rank, HIP device, PCI address, frames/s,
+    // seconds); rank 0 prints them and refuses a run in which two ranks shared a device
+    struct RankRec { int32_t rank, device; double fps, seconds; char bus[32]; char pad[8]; };
+    static_assert(sizeof(RankRec) == 64, "the layout of vislam/dist.py pack_rank_record");
+    RankRec mine; std::memset(&mine, 0, sizeof(mine));
+    mine.rank = rank; mine.device = rank; mine.fps = (double)steps * B / dt_rank; mine.seconds = dt_rank;
+    (void)vis_device_pci_bus_id(rank, mine.bus, (int)sizeof(mine.bus));
+    RankRec* d_rec = nullptr;
+    CK_HIP(hipMalloc((void**)&d_rec, sizeof(RankRec) * (size_t)(world + 1)));
+    CK_HIP(hipMemcpy(d_rec + world, &mine, sizeof(mine), hipMemcpyHostToDevice));
+    CK_NCCL(ncclAllGather(d_rec + world, d_rec, sizeof(RankRec), ncclChar, comm, cs)); CK_HIP(hipStreamSynchronize(cs));
+    std::vector<RankRec> recs((size_t)world);
+    CK_HIP(hipMemcpy(recs.data(), d_rec, sizeof(RankRec) * (size_t)world, hipMemcpyDeviceToHost));
+    (void)hipFree(d_rec);
+    std::string ranks_json = "[";
+    for (int i = 0; i < world; i++) {
+        for (int j = 0; j < i; j++)
+            if (std::strncmp(recs[i].bus, recs[j].bus, sizeof(recs[i].bus)) == 0 && recs[i].bus[0]) { std::fprintf(stderr, "ranks %d and %d share device %s\n", j, i, recs[i].bus); return 7; }
+        char buf[256];
+        std::snprintf(buf, sizeof(buf), "%s{\"rank\": %d, \"device\": %d, \"pci_bus_id\": \"%.31s\", \"frames_per_s\": %.3f, \"seconds\": %.6f}", i ? ", " : "",
+                      recs[i].rank, recs[i].device, recs[i].bus, recs[i].fps, recs[i].seconds);
+        ranks_json += buf;
+    }
+    ranks_json += "]";
     if (rank == 0)
         std::printf("{\"metric\": \"frames/sec detect+match+pose, 752x480 mono8\", \"value\": %.3f, \"unit\": \"frames/s\", \"n_gpus\": %d, \"steps\": %d, "
                     "\"warmup\": %d, \"ms_per_step\": %.6f, \"higher_is_better\": true, \"scaling\": \"weak\", \"dtype\": \"u8\", \"data\": \"synthetic\", "
                     "\"config\": {\"workload\": \"S-752 stream per rank, launcher = C++ (vislam_mgpu), RCCL: 1 broadcast of vis_params (%zu B) + timing reductions\", "
-                    "\"frames_per_step_per_gpu\": %d}}\n",
-                    (double)world * steps * B / dt, world, steps, warmup, dt / steps * 1e3, sizeof(vis_params), B);
+                    "\"frames_per_step_per_gpu\": %d}, \"ranks\": %s}\n",
+                    (double)world * steps * B / dt, world, steps, warmup, dt / steps * 1e3, sizeof(vis_params), B, ranks_json.c_str());
     std::fflush(stdout);                                             // the rank leaves through _exit()
     vis_destroy(ctx);
     (void)hipFree(d_frames); (void)hipFree(d_canvas); (void)hipFree(d_p); (void)hipFree(d_one); (void)hipFree(d_t);

@@ -110,7 +110,7 @@ ABI_SYMBOLS = [
     "vis_bf_knn2_hamming_host", "vis_good_matches", "vis_good_matches_host", "vis_essential_ransac",
     "vis_recover_pose", "vis_f2f_ransac", "vis_batch_plan", "vis_batch_reset", "vis_batch_run",
     "vis_batch_sync", "vis_batch_get_keypoints", "vis_batch_get_knn", "vis_batch_get_matches",
-    "vis_batch_get_pose", "vis_batch_get_inlier_mask", "vis_debug_counters", "vis_batch_status", "vis_synth_canvas", "vis_synth_frame",
+    "vis_batch_get_pose", "vis_batch_get_inlier_mask", "vis_debug_counters", "vis_device_pci_bus_id", "vis_batch_status", "vis_synth_canvas", "vis_synth_frame",
     "vis_gradient_frame_elems", "vis_half_pyramid_dims", "vis_gradient_batch", "vis_compute_gradient", "vis_patch_points",
     "vis_image_list", "vis_image_time", "vis_pgm_info", "vis_image_read",
     "vis_feeder_create", "vis_feeder_destroy", "vis_feeder_host_buffer", "vis_feeder_submit", "vis_feeder_release",
@@ -212,6 +212,14 @@ def _strerror(code):
 
 def version():
     return lib.vis_version().decode()
+
+
+def device_pci_bus_id(device):
+    """PCI address of a HIP device ("" when the library cannot tell: no device / an older A/B build)"""
+    if not hasattr(lib, "vis_device_pci_bus_id"):
+        return ""
+    buf = C.create_string_buffer(32)
+    return buf.value.decode() if lib.vis_device_pci_bus_id(int(device), buf, 32) == 0 else ""
 
 
 def device_count():
