@@ -83,18 +83,21 @@ extern "C" int vis_create(int device, vis_ctx** out) {
     vis_default_params(&ctx->p);
     std::memset(&ctx->tm, 0, sizeof(ctx->tm));
     for (int i = 0; i < VIS_NSLOTS; i++) ctx->slot_valid[i] = 0;
-    // the detect chain is the critical path of the batch pipeline: it gets the high-priority queue, the
-    // overlapped matcher / pose streams the low-priority ones
+    // Stream priorities of the batch pipeline.  Rounds 2-4: detect chain high, everything beside it low.  Round 5: with the streaming k_fast the
+    // low-priority matcher / pose queues hardly got a turn (k_knn_mfma 1.4 ms of wall clock for 0.29 ms of work) and the detect stream ended
+    // up waiting for them at the start of every chain; matcher and pose at the detect stream's priority: 397.1 k -> 402.7 k frames/s (three
+    // alternations on one box; all four equal: 402.5 k).  Camera::Update's streaming side stream stays low.
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);            // lo = numerically largest = least urgent
     if (hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) { delete ctx; return VIS_E_HIP; }
     ctx->stream = ctx->own_stream;
-    if (hipStreamCreateWithPriority(&ctx->pose_stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+    const int prio_pose = prio_hi, prio_match = prio_hi;
+    if (hipStreamCreateWithPriority(&ctx->pose_stream, hipStreamNonBlocking, prio_pose) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_filter_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_pose_done, hipEventDefault) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_pose_start, hipEventDefault) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_results_done, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithPriority(&ctx->match_stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipStreamCreateWithPriority(&ctx->match_stream, hipStreamNonBlocking, prio_match) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_detect_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_match_start, hipEventDefault) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_match_done[0], hipEventDisableTiming) != hipSuccess ||

@@ -427,7 +427,7 @@ int launch_filter(vis_ctx* ctx, Plan* pl, int npairs) {
     int keys_cap = 2; while (keys_cap < pl->kcap) keys_cap <<= 1;
     const int nt = pl->kcap > 2048 ? 1024 : 256;
     const size_t lds = (size_t)keys_cap * 8 + (size_t)pl->root * pl->root * 4 + (size_t)nt * 4 + 16;
-    if (lds > 160 * 1024) return VIS_E_CAPACITY;
+    if (lds > 160 * 1024) { ctx->err = "the match filters sort up to 16384 keypoints per frame in LDS: keypoint capacity " + std::to_string(pl->kcap) + " is beyond that"; return VIS_E_CAPACITY; }
     auto kern = nt == 1024 ? k_filter<1024> : k_filter<256>;
     if (lds > 65536) HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(npairs), dim3(nt), lds, ctx->stream, pl->d_kps, pl->d_nkp, pl->kcap,
