@@ -489,6 +489,20 @@ __device__ __forceinline__ void fast_wave(const FastWave& V, const uint8_t* __re
             const uint32_t valid = colbits & (rb * 0x01010101u);
             maskD &= valid; maskB &= valid;
         }
+        // Skew the masks across the lanes of a 16-lane row: lane i takes the bits of score row r from lane (i - r) mod 16 (row_ror:r).
+        // Passers cluster around corners -- a 4 x 8 block of one lane holds a whole cluster, and the append below runs as many rounds as the
+        // fullest lane has bits (a timing build without the append: 0.574 -> 0.456 ms for the kernel, 38 % of it).  After the skew a lane
+        // holds ONE row of eight different 4-pixel columns: a cluster spreads over as many lanes as it has rows.  The queue entry keeps the
+        // consumer lane; the score phase undoes the rotation (src lane = (lane & 48) | ((lane - r) & 15)).
+        {
+            uint32_t sD = maskD & 0x01010101u, sB = maskB & 0x01010101u;
+#define FS_SKEW(R) { const uint32_t sel_ = 0x01010101u << (R);                                                                                        \
+                     sD = __builtin_amdgcn_bitop3_b32((uint32_t)__builtin_amdgcn_update_dpp(0, (int)maskD, 0x120 + (R), 0xF, 0xF, false), sel_, sD, 0xEA); \
+                     sB = __builtin_amdgcn_bitop3_b32((uint32_t)__builtin_amdgcn_update_dpp(0, (int)maskB, 0x120 + (R), 0xF, 0xF, false), sel_, sB, 0xEA); }
+            FS_SKEW(1) FS_SKEW(2) FS_SKEW(3) FS_SKEW(4) FS_SKEW(5) FS_SKEW(6) FS_SKEW(7)
+#undef FS_SKEW
+            maskD = sD; maskB = sB;
+        }
         // the score rows of this chunk (ring slots (8 c) mod 10 .. + 7, wrapping) start at zero: positions that are not scored read 0 in the NMS
         const int sc0 = sc_slot(8 * c);                                         // wave-uniform
         {
@@ -534,7 +548,16 @@ __device__ __forceinline__ void fast_wave(const FastWave& V, const uint8_t* __re
                 {
                     uint32_t a_idx = q_base + 2u * (uint32_t)(incl - n);
                     uint32_t dD = mD, dB = mB;
-                    while (__builtin_amdgcn_ballot_w64((dD | dB) != 0u)) {
+                    // rounds = the fullest lane's larger count, known before the loop (DPP max over the rows + four v_readlane): the loop
+                    // control is scalar -- a `while (ballot(bits left))` puts a vector compare -> vcc -> branch chain into every round
+                    int nmax = max(__popc(mD), __popc(mB));
+                    nmax = max(nmax, __builtin_amdgcn_update_dpp(0, nmax, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+                    nmax = max(nmax, __builtin_amdgcn_update_dpp(0, nmax, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+                    nmax = max(nmax, __builtin_amdgcn_update_dpp(0, nmax, 0x141, 0xF, 0xF, false));    // row_half_mirror
+                    nmax = max(nmax, __builtin_amdgcn_update_dpp(0, nmax, 0x140, 0xF, 0xF, false));    // row_mirror
+                    const int wmax = max(max(__builtin_amdgcn_readlane(nmax, 0), __builtin_amdgcn_readlane(nmax, 16)),
+                                         max(__builtin_amdgcn_readlane(nmax, 32), __builtin_amdgcn_readlane(nmax, 48)));
+                    for (int rnd = 0; rnd < wmax; rnd++) {
                         const bool hasD = dD != 0u, hasB = dB != 0u;
                         const uint32_t bD = (uint32_t)__builtin_ctz(dD | 0x80000000u), bB = (uint32_t)__builtin_ctz(dB | 0x80000000u);
                         dD &= dD - 1u; dB &= dB - 1u;
@@ -552,8 +575,10 @@ __device__ __forceinline__ void fast_wave(const FastWave& V, const uint8_t* __re
                     const int iA = i0 + lane, iB = i0 + 64 + lane;
                     const bool actA = iA < tot, actB = iB < tot;
                     const uint32_t eA = Q[actA ? iA : i0], eB = Q[actB ? iB : i0];
-                    const int xlA = (int)(eA >> 3) & 0xFF, qA = 8 * c + (int)(eA & 7u);
-                    const int xlB = (int)(eB >> 3) & 0xFF, qB = 8 * c + (int)(eB & 7u);
+                    // entry = polarity << 11 | consumer lane << 5 | j << 3 | r: the bits of row r came from lane (consumer - r) mod 16 of its row
+                    const int rA = (int)(eA & 7u), rB = (int)(eB & 7u), lcA = (int)(eA >> 5) & 63, lcB = (int)(eB >> 5) & 63;
+                    const int xlA = ((lcA & 48) | ((lcA - rA) & 15)) * 4 + ((int)(eA >> 3) & 3), qA = 8 * c + rA;
+                    const int xlB = ((lcB & 48) | ((lcB - rB) & 15)) * 4 + ((int)(eB >> 3) & 3), qB = 8 * c + rB;
                     // 7 x 7 window: ring rows q + 2 .. q + 8 (the centre is ring row q + 5), columns xl - 3 .. xl + 3
                     const uint8_t* a0 = pxb + (((qA + 2) & (FS_RING - 1)) * FS_ROWB + xlA - 3);
                     const uint8_t* b0 = pxb + (((qB + 2) & (FS_RING - 1)) * FS_ROWB + xlB - 3);
@@ -561,18 +586,18 @@ __device__ __forceinline__ void fast_wave(const FastWave& V, const uint8_t* __re
                     const pk16 sp = fast_score16_pair<FS_ROWB>(a0, b0, nsg, threshold);
                     const int sA = actA ? (int)sp.x : 0, sB = actB ? (int)sp.y : 0;
                     WAVE_SYNC();                                               // (every entry of this round has been read)
-                    const int slA = sc0 + (int)(eA & 7u), slB = sc0 + (int)(eB & 7u);      // (8 c + r) mod 10
+                    const int slA = sc0 + rA, slB = sc0 + rB;      // (8 c + r) mod 10
                     if (sA > 0) sc[(slA - (slA >= FS_SCR ? FS_SCR : 0)) * FS_ROWB + xlA] = (uint8_t)sA;
                     if (sB > 0) sc[(slB - (slB >= FS_SCR ? FS_SCR : 0)) * FS_ROWB + xlB] = (uint8_t)sB;
                     const bool cA = sA > 0 && qA == qlast, cB = sB > 0 && qB == qlast;
-                    const bool rA = sA > 0 && qA != qlast, rB = sB > 0 && qB != qlast;
-                    const unsigned long long bRA = __builtin_amdgcn_ballot_w64(rA), bRB = __builtin_amdgcn_ballot_w64(rB);
+                    const bool keepA = sA > 0 && qA != qlast, keepB = sB > 0 && qB != qlast;
+                    const unsigned long long bRA = __builtin_amdgcn_ballot_w64(keepA), bRB = __builtin_amdgcn_ballot_w64(keepB);
                     const unsigned long long bCA = __builtin_amdgcn_ballot_w64(cA), bCB = __builtin_amdgcn_ballot_w64(cB);
                     auto rank = [&](unsigned long long bm) -> int {
                         return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
                     };
-                    if (rA) Q[nR + rank(bRA)] = (uint16_t)eA;
-                    if (rB) Q[nR + __popcll(bRA) + rank(bRB)] = (uint16_t)eB;
+                    if (keepA) Q[nR + rank(bRA)] = (uint16_t)((xlA << 3) | rA);                       // (decoded: position << 3 | row, what the NMS reads)
+                    if (keepB) Q[nR + __popcll(bRA) + rank(bRB)] = (uint16_t)((xlB << 3) | rB);
                     nR += __popcll(bRA) + __popcll(bRB);
                     if (cA) car_wr[nnew + rank(bCA)] = (uint8_t)xlA;
                     if (cB) car_wr[nnew + __popcll(bCA) + rank(bCB)] = (uint8_t)xlB;
