@@ -34,4 +34,13 @@ for leg in f1000:fixed1000_probe.py c3:config3_probe.py; do
 done
 $R/vi-slam_amd/lib/f64_rates > $R/$OUT/f64_rates.log 2>&1
 python3 $R/tools/pmc_pose_summarize.py $R/$OUT/pose $COMMIT $R/$OUT/f64_rates.log > $R/$OUT/pmc_pose_summary.log 2>&1
+# 5. the bench record AFTER the counter files of this very run are in place (round 4's record quoted the previous run's counters beside new timings):
+#    the freshly written pmc_traffic.json / pmc_pose.json go into profiles/ of this box's copy, then the full default bench runs
+cp $R/$OUT/pipe/pmc_traffic.json $R/profiles/pmc_traffic.json
+cp $R/$OUT/pose/pmc_pose.json $R/profiles/pmc_pose.json
+(cd $R && python3 bench.py --steps 20 --warmup 3 > $R/$OUT/bench_full.json 2> $R/$OUT/bench_full.err)
+# 6. the instruction-rate microbenchmarks of the round
+[ -x $R/vi-slam_amd/lib/dpp_rates ] && $R/vi-slam_amd/lib/dpp_rates > $R/$OUT/dpp_rates.log 2>&1
+# the csv dumps are large: keep the stats summaries, the json summaries and the logs
+find $R/$OUT -name "*_kernel_trace.csv" -delete; find $R/$OUT -name "*counter_collection.csv" -delete; find $R/$OUT -name "*agent_info.csv" -delete
 echo final_profile done
