@@ -260,7 +260,11 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
     if (!pl) return VIS_E_NOMEM;
     pl->w = w; pl->h = h; pl->stride = stride; pl->B = B; pl->L = ctx->p.nlevels; pl->npairs = npairs;
     pl->nsets = nsets; pl->rec_per_set = nrec; nrec *= nsets; pl->nrec = nrec;
-    int rc = vis_compute_levels(ctx->p, w, h, stride, pl->lv);
+    // k_fast segment height: a wave marches 8 fs_nch - 2 emitting rows.  Long segments amortise the prologue and the halo rows of a wave --
+    // right for a batch, whose tens of thousands of waves fill the chip anyway; ONE frame has 68 such waves for 256 CUs and the kernel's
+    // latency is a wave's lifetime, so the single-frame plan (and small batches) cut the same frame into more, shorter waves
+    pl->fs_nch = B >= 32 ? VIS_FS_NCH : (B >= 8 ? 4 : 2);
+    int rc = vis_compute_levels(ctx->p, w, h, stride, pl->lv, pl->fs_nch);
     if (rc) { delete pl; return rc; }
     const int L = pl->L;
     int kcap = 0; for (int l = 0; l < L; l++) kcap += pl->lv[l].quota + pl->lv[l].quota / 8 + 32;      // default: every level's own slack

@@ -1286,6 +1286,7 @@ int build_fast_tiles(vis_ctx* ctx, Plan* pl) {
     std::vector<FastWave> t;
     const int e = ctx->p.edge_threshold;
     const int x00 = (e - 4) & ~3;                       // pixel column of lane 0 of the first strip (vis_compute_levels)
+    const int emit_h = 8 * pl->fs_nch - 2;             // emitting rows per segment of this plan
     for (int l = 0; l < pl->L; l++) {
         LevelInfo& V = pl->lv[l];
         const int items = V.tiles_x * V.tiles_y;
@@ -1301,9 +1302,9 @@ int build_fast_tiles(vis_ctx* ctx, Plan* pl) {
             for (int k = 0; k < 2; k++) {
                 const int i = std::min(2 * j + k, items - 1);          // (an idle second half repeats the first one's geometry: its loads stay inside the image)
                 const int seg = i / V.tiles_x, strip = i % V.tiles_x;
-                r.x0[k] = x00 + strip * VIS_FS_EMIT_W; r.y0[k] = e - 1 + seg * VIS_FS_EMIT_H; r.tile[k] = (uint32_t)i;
+                r.x0[k] = x00 + strip * VIS_FS_EMIT_W; r.y0[k] = e - 1 + seg * emit_h; r.tile[k] = (uint32_t)i;
                 // emitting rows of the segment -> chunks of 8 score rows (one halo row above and below)
-                const int rows = std::max(0, std::min(VIS_FS_EMIT_H, emit_rows - seg * VIS_FS_EMIT_H));
+                const int rows = std::max(0, std::min(emit_h, emit_rows - seg * emit_h));
                 nch[k] = 2 * j + k < items ? (uint32_t)std::max(1, (rows + 2 + 7) / 8) : 0u;
             }
             r.nl = nch[0] | (nch[1] << 8) | ((uint32_t)l << 16);

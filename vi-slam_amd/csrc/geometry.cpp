@@ -12,7 +12,9 @@
 
 static inline int round_half_even(double v) { return (int)std::lrint(v); }
 
-int vis_compute_levels(const vis_params& p, int w, int h, int stride0, LevelInfo* lv) {
+int vis_compute_levels(const vis_params& p, int w, int h, int stride0, LevelInfo* lv, int fs_nch) {
+    if (fs_nch < 1 || fs_nch > VIS_FS_NCH) return VIS_E_INVALID;
+    const int emit_h = 8 * fs_nch - 2;                 // emitting rows of a k_fast segment (a plan's choice: see plan_create)
     if (p.nlevels < 1 || p.nlevels > VIS_MAX_LEVELS || p.nfeatures < 1) return VIS_E_INVALID;
     if (w < 2 * p.edge_threshold + 8 || h < 2 * p.edge_threshold + 8 || w > 4095 || h > 4095) return VIS_E_INVALID;
     const double sf = (double)p.scale_factor;            // ORB keeps the float argument in a double member
@@ -24,12 +26,12 @@ int vis_compute_levels(const vis_params& p, int w, int h, int stride0, LevelInfo
         if (lv[l].w < 8 || lv[l].h < 8) return VIS_E_INVALID;
         lv[l].stride = (l == 0) ? stride0 : ((lv[l].w + 63) / 64) * 64;
         lv[l].frame_bytes = (size_t)lv[l].stride * lv[l].h;
-        // FAST items (k_fast, detect.hip): a strip segment of VIS_FS_EMIT_W x VIS_FS_EMIT_H emitting positions inside the region that can
+        // FAST items (k_fast, detect.hip): a strip segment of VIS_FS_EMIT_W x (8 fs_nch - 2) emitting positions inside the region that can
         // emit keypoints, [edge, w-edge) x [edge, h-edge); the pixel window of the first strip starts at a dword-aligned column
         // (edge - 4 rounded down to 4; its first emitting column is 4 pixels further).  tiles_x = strips, tiles_y = segments.
         const int e = p.edge_threshold, ex0 = ((e - 4) & ~3) + 4;
         lv[l].tiles_x = std::max(1, (lv[l].w - e - ex0 + VIS_FS_EMIT_W - 1) / VIS_FS_EMIT_W);
-        lv[l].tiles_y = std::max(1, (lv[l].h - 2 * e + VIS_FS_EMIT_H - 1) / VIS_FS_EMIT_H);
+        lv[l].tiles_y = std::max(1, (lv[l].h - 2 * e + emit_h - 1) / emit_h);
         lv[l].cand_cap = lv[l].tiles_x * lv[l].tiles_y * VIS_TILE_CAND_CAP;
         lv[l].tile_base = l == 0 ? 0 : lv[l - 1].tile_base + lv[l - 1].tiles_x * lv[l - 1].tiles_y;
     }

@@ -40,6 +40,7 @@ typedef vis_pose_result PoseOut;       // E, R, t (double) + n_inliers, n_pose_g
 
 struct Plan {
     int w = 0, h = 0, stride = 0, B = 0, L = 0;
+    int fs_nch = VIS_FS_NCH;     // chunks (8 score rows) per k_fast segment of this plan: 8 for batches, fewer for a handful of frames (more, shorter waves)
     int nrec = 0;                // keypoint/descriptor records (batch: B+1, single: VIS_NSLOTS)
     int kcap = 0;                // keypoints per record (sum of keep_cap)
     int npairs = 0;              // pair result capacity
@@ -230,7 +231,7 @@ struct HostStage {
 
 
 // ---- host-side geometry / tables (geometry.cpp) ----
-int  vis_compute_levels(const vis_params& p, int w, int h, int stride0, LevelInfo* lv);
+int  vis_compute_levels(const vis_params& p, int w, int h, int stride0, LevelInfo* lv, int fs_nch = VIS_FS_NCH);
 void vis_grid_limits(const vis_params& p, int* root, std::vector<float>& hf, std::vector<float>& wf);
 
 struct SynthOrigin;
