@@ -412,7 +412,10 @@ __device__ __forceinline__ void fast_wave(const FastWave& V, const uint8_t* __re
     static_assert(8 * VIS_FS_NCH < 1000, "range of the multiply-shift quotient");
     // rows: load chunk k = rows y0 - 5 + 8 k .. + 7 of the half (ring slots 8 (k & 1) ..).  Score row q of chunk c (q = 8 c + r) has its
     // centre in ring row q + 5, i.e. it needs load chunks c (last 6 rows) and c + 1.
-    const uint32_t voff_max = (uint32_t)((h - 1) * stride) + coff;
+    // the last row this half needs: ring row 8 nchunks + 7 (the lower row of its last score row; the image's last row at most).  The two
+    // load chunks requested behind it (the prefetch is unconditional) re-read THAT row instead of sixteen new ones: the first streaming
+    // build fetched 88 rows per 70 it used -- FETCH_SIZE 1.26 x the algorithmic bytes
+    const uint32_t voff_max = (uint32_t)(min(h - 1, y0 - 5 + 8 * nchunks + 7) * stride) + coff;
     uint32_t voff = (uint32_t)(max(y0 - 5, 0) * stride) + coff;
     auto ld = [&](uint32_t o) -> uint32_t {
         return *(const __attribute__((address_space(1))) uint32_t*)(uintptr_t)(base + (size_t)o);   // global, not flat: the level-0 select hides the address space
