@@ -1032,8 +1032,7 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
     int rc = VIS_OK;
     bool have_prev = pl->have_prev;
     if (detect) {
-        // this record set was last read by the matcher nsets batches ago
-        if (pl->match_pending[cur]) HIPCHK(ctx, hipStreamWaitEvent(sA, ctx->ev_match_done[cur], 0));
+        // this record set was last read by the matcher nsets batches ago: launch_detect waits for it where the chain first writes the set
         if (pl->carry_from > 0) have_prev = true;      // previous batch's last frame -> record 0 of this set: copied by launch_detect's first kernel
     }
     // Camera::Update (src/Camera.cpp:63-72): the half pyramid of every frame of the batch.  Nothing of the detect chain reads it
@@ -1041,7 +1040,8 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
     // stream joins it at the end of its chain, so "the detect stream is done" still means "d_frames may be reused".
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[0], sA);
     if (detect) { VisRange r_("vis: ORB detect + describe"); rc = launch_detect(ctx, pl, d_frames, n, base + 1, pl->carry_from > 0 ? pl->carry_from : -1,
-                                                                             (stages & (VIS_STAGE_UPDATE | VIS_STAGE_GRADIENT)) ? ctx->ev_update_fork : nullptr); if (rc) return rc; }
+                                                                             (stages & (VIS_STAGE_UPDATE | VIS_STAGE_GRADIENT)) ? ctx->ev_update_fork : nullptr,
+                                                                             pl->match_pending[cur] ? ctx->ev_match_done[cur] : nullptr); if (rc) return rc; }
     else if (ctx->ev_ok) for (int i = 1; i <= 4; i++) (void)hipEventRecord(ctx->ev[i], sA);
     hipStream_t sU = ctx->update_stream;
     pl->half_valid = false; pl->grad_valid = false;

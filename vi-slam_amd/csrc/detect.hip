@@ -1335,7 +1335,7 @@ __global__ __launch_bounds__(256) void k_small_ops(SmallOps J) {
     }
 }
 
-int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int rec0, int carry_rec, hipEvent_t after_resize) {
+int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int rec0, int carry_rec, hipEvent_t after_resize, hipEvent_t records_free) {
     hipStream_t st = ctx->stream;
     const int L = pl->L;
     {
@@ -1344,12 +1344,6 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
         job(pl->d_tile_cnt, nullptr, sizeof(int32_t) * (size_t)pl->B * pl->total_tiles);
         job(pl->d_seg_cnt, nullptr, sizeof(int32_t) * (size_t)pl->B * L);
         if (pl->speculate) job(pl->d_fix, nullptr, sizeof(int32_t));
-        if (carry_rec >= 0) {          // the previous batch's last frame -> the record in front of this batch's first (rec0 - 1)
-            const size_t d = (size_t)(rec0 - 1), c = (size_t)carry_rec;
-            job(pl->d_kps + d * pl->kcap, pl->d_kps + c * pl->kcap, (size_t)pl->kcap * sizeof(vis_keypoint));
-            job(pl->d_desc + d * pl->kcap * 32, pl->d_desc + c * pl->kcap * 32, (size_t)pl->kcap * 32);
-            job(pl->d_nkp + d, pl->d_nkp + c, 4);
-        }
         J.n = k;
         hipLaunchKernelGGL(k_small_ops, dim3((unsigned)std::min<uint32_t>(1024u, (e + 255u) / 256u)), dim3(256), 0, st, J);
         HIPCHK(ctx, hipGetLastError());
@@ -1422,6 +1416,21 @@ int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int re
         HIPCHK(ctx, hipGetLastError());
     }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[3], st);
+    // The records of this batch (k_describe writes them; the previous batch's last frame is copied in front of them) are the first thing
+    // of the chain that touches the record set the matcher of an earlier batch may still be reading: the detect stream waits for that
+    // matcher HERE, not at the start of the chain (round 5 timeline: a quarter of a millisecond of idle detect stream per step) -- the
+    // resize chain, k_fast and k_select of this batch run meanwhile.
+    if (records_free) HIPCHK(ctx, hipStreamWaitEvent(st, records_free, 0));
+    if (carry_rec >= 0) {              // the previous batch's last frame -> the record in front of this batch's first (rec0 - 1)
+        SmallOps J = {}; uint32_t e = 0; int k = 0;
+        auto job = [&](void* d, const void* s, size_t bytes) { J.dst[k] = (uint32_t*)d; J.src[k] = (const uint32_t*)s; e += (uint32_t)(bytes / 4); J.end[k] = e; k++; };
+        const size_t d = (size_t)(rec0 - 1), c = (size_t)carry_rec;
+        job(pl->d_kps + d * pl->kcap, pl->d_kps + c * pl->kcap, (size_t)pl->kcap * sizeof(vis_keypoint));
+        job(pl->d_desc + d * pl->kcap * 32, pl->d_desc + c * pl->kcap * 32, (size_t)pl->kcap * 32);
+        job(pl->d_nkp + d, pl->d_nkp + c, 4);
+        J.n = k;
+        hipLaunchKernelGGL(k_small_ops, dim3((unsigned)std::min<uint32_t>(1024u, (e + 255u) / 256u)), dim3(256), 0, st, J);
+    }
     // workgroups per frame: enough to fill the chip for small batches, a wave walks over many keypoints for large ones
     const int desc_groups = std::max(1, std::min((pl->kcap + 3) / 4, (16384 + n - 1) / n));
     hipLaunchKernelGGL(k_describe, dim3(8, desc_groups, (n + 7) / 8), dim3(256), 0, st, D, G, pl->d_seg_cnt,

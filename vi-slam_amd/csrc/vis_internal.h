@@ -242,7 +242,7 @@ int  plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int np
 void plan_destroy(Plan* pl);
 
 // ---- kernel launchers (each enqueues on ctx->stream) ----
-int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int rec0, int carry_rec = -1, hipEvent_t after_resize = nullptr);   // carry_rec >= 0: copy that record to rec0 - 1 first; after_resize: recorded behind the pyramid launches
+int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int rec0, int carry_rec = -1, hipEvent_t after_resize = nullptr, hipEvent_t records_free = nullptr);   // carry_rec >= 0: copy that record to rec0 - 1 before k_describe; after_resize: recorded behind the pyramid launches; records_free: waited for before the chain's first write to the record set
 int build_fast_tiles(vis_ctx* ctx, Plan* pl);
 int launch_expand(vis_ctx* ctx, Plan* pl, int rec_first, int rec_count);
 int launch_match(vis_ctx* ctx, Plan* pl, int npairs);
