@@ -1584,11 +1584,11 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
     }
     hipLaunchKernelGGL(k_pose_prep, dim3(npairs), dim3(256), 0, st, P, d_p1, d_p2, d_npts, d_n1, d_n2, d_samples, d_rstate);
     if (do_ransac) {
-        // per chunk of hypotheses: (A) minimal solver up to the degree-10 polynomial, lane = hypothesis, 118 KB LDS per wave;
+        // per chunk of hypotheses: (A) minimal solver up to the degree-10 polynomial, four lanes per hypothesis, 14.5 KB LDS per wave;
         // (B) its real roots, 16 lanes per hypothesis; (C) models + inlier counts, 256 threads per 16 hypotheses;
         // then the sequential accept/adaptive-bound rule is replayed by k_ransac_scan.
 #ifdef VIS_AB_KNOBS       // diagnostic build only (make EXTRA=-DVIS_AB_KNOBS): the shipped library reads no environment variable
-        static const int first_chunk = getenv("VIS_RANSAC_FIRST") ? std::max(4, std::min(16, atoi(getenv("VIS_RANSAC_FIRST")) & ~3)) : 16;
+        static const int first_chunk = getenv("VIS_RANSAC_FIRST") ? std::max(4, std::min(16, atoi(getenv("VIS_RANSAC_FIRST")) & ~3)) : 8;
         static const bool roots16 = getenv("VIS_ROOTS_16LANE") != nullptr;      // the 16-lanes-per-polynomial kernel for every chunk
 #else
         // 8: the headline's pairs mostly stop within 8 hypotheses (ms_pose 0.58 -> 0.52 per 512 pairs, + 2.7 % frames/s; same-box
