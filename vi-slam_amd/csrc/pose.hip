@@ -1588,13 +1588,14 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
         // (B) its real roots, 16 lanes per hypothesis; (C) models + inlier counts, 256 threads per 16 hypotheses;
         // then the sequential accept/adaptive-bound rule is replayed by k_ransac_scan.
 #ifdef VIS_AB_KNOBS       // diagnostic build only (make EXTRA=-DVIS_AB_KNOBS): the shipped library reads no environment variable
-        static const int first_chunk = getenv("VIS_RANSAC_FIRST") ? std::max(4, std::min(16, atoi(getenv("VIS_RANSAC_FIRST")) & ~3)) : 8;
+        static const int first_chunk = getenv("VIS_RANSAC_FIRST") ? std::max(4, std::min(16, atoi(getenv("VIS_RANSAC_FIRST")) & ~3)) : 16;
         static const bool roots16 = getenv("VIS_ROOTS_16LANE") != nullptr;      // the 16-lanes-per-polynomial kernel for every chunk
 #else
-        // 8: the headline's pairs mostly stop within 8 hypotheses (ms_pose 0.58 -> 0.52 per 512 pairs, + 2.7 % frames/s; same-box
-        // A/B 16 / 8 / 4: 410 / 421 / 424 k).  One value for every batch size: n_models (the work counter of the pose record)
-        // depends on it, and a stream's records must not depend on how it is cut into batches.
-        const int first_chunk = 8;
+        // 16: the headline's degenerate pairs stop within 4 hypotheses and would be as fast with 8 or 4, but S-752P's pairs need 8.7 on
+        // average and every pair past the first chunk costs a whole 64-hypothesis item of the list kernels (same-box A/B 16 / 8 / 4,
+        // tools/r5_first.sh: S-752 404 / 406 / 405 k frames/s, S-752P 386 / 342 / 298 k).  One value for every batch size: n_models (the
+        // work counter of the pose record) depends on it, and a stream's records must not depend on how it is cut into batches.
+        const int first_chunk = 16;
         const bool roots16 = false;
 #endif
         // adaptive runs: the first chunk of hypotheses of every pair, then only the pairs whose bound is still above it (work list): the
