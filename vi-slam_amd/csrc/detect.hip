@@ -1280,9 +1280,6 @@ static void fill_desc_args(const vis_params& p, DescArgs& G, std::vector<uint32_
     }
 }
 
-// (the phase stamps of the tiled k_fast of rounds 1-4 are gone with its workgroup phases; the entry point stays in the ABI)
-extern "C" int vis_debug_fast_stamps(unsigned long long out[16]) { (void)out; return VIS_E_STATE; }
-
 // the per-wave records of k_fast (levels >= 1 point into the plan's pyramid; level 0 is the batch of the call: img = nullptr).
 // Item i of a level = (segment i / strips, strip i % strips); a wave takes items 2 j and 2 j + 1 of ONE level.
 int build_fast_tiles(vis_ctx* ctx, Plan* pl) {
