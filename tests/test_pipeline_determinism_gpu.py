@@ -145,3 +145,49 @@ def test_work_list_item_counter_is_reset_when_pair_zero_has_no_model(vislam, can
     got = run(c, db)
     c.close()
     assert got[1] == want[1] and got[0] == want[0]
+
+
+def test_detect_chain_running_ahead_of_a_slow_matcher(vislam, canvas):
+    """Since round 5 the detect chain of step i + 2 waits for the record set that step i's matcher reads only in front of k_describe
+    (resize, FAST and select run ahead).  With 752x480 / 1000 keypoints the matcher is the faster stage and the wait rarely blocks; here
+    it is the slow one (640x480 frames at FAST threshold 7 with a quota of 12000: 8600 keypoints per frame, two 8600 x 8600 distance
+    matrices per pair -- 0.47 ms of k_knn_mfma + k_filter per step of 16 frames against 0.35 ms for the whole detect chain, measured),
+    steps are queued back to back without a host sync, and the results must equal the same stream run one step at a
+    time with a sync after every call (nothing overlaps there)."""
+    import torch
+    w, h, n_total, batch = 640, 480, 96, 16
+    frames = np.stack([vislam.synth_frame(canvas, t, w, h, parallax=True) for t in range(n_total)])
+    dev = torch.from_numpy(frames).cuda()
+    p = vislam.default_params(); p.fy = p.fx
+    p.nfeatures, p.w_size, p.h_size, p.fast_threshold = 12000, w, h, 7
+    root2 = int(np.floor(np.sqrt(p.n_cells))) ** 2
+
+    def run(serial):
+        c = vislam.Context(0, p)
+        c.batch_plan(w, h, w, batch)
+        bufs = []
+        for b0 in range(0, n_total, batch):
+            c.batch_run(dev.data_ptr() + b0 * w * h, batch)
+            hp = torch.zeros(batch * C.sizeof(vislam.PoseResult), dtype=torch.uint8).pin_memory()
+            hg = torch.zeros(batch * root2 * 16, dtype=torch.uint8).pin_memory()
+            hn = torch.zeros(batch, dtype=torch.int32).pin_memory()
+            c.batch_results_async(batch, hp.data_ptr(), hg.data_ptr(), hn.data_ptr())
+            if serial:
+                c.batch_sync()
+            bufs.append((hp, hg, hn))
+        c.batch_sync()
+        assert c.batch_status() == 0
+        kp_last = c.batch_keypoints(batch - 1)
+        c.close()
+        pose = np.concatenate([np.frombuffer(b[0].numpy().tobytes(), vislam.POSE_RESULT_DTYPE) for b in bufs])
+        ng = np.concatenate([b[2].numpy() for b in bufs])
+        good = np.concatenate([np.frombuffer(b[1].numpy().tobytes(), vislam.DMATCH_DTYPE).reshape(batch, root2) for b in bufs])
+        return pose, ng, good, kp_last
+
+    ref = run(True)
+    got = run(False)
+    assert got[0].tobytes() == ref[0].tobytes() and got[1].tobytes() == ref[1].tobytes()
+    for t in range(n_total):
+        assert got[2][t, :ref[1][t]].tobytes() == ref[2][t, :ref[1][t]].tobytes(), t
+    assert got[3][0].tobytes() == ref[3][0].tobytes() and got[3][1].tobytes() == ref[3][1].tobytes()
+    assert (ref[0]["n_points"][1:] > 5).all()
