@@ -282,8 +282,8 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
 //     three-input packed half-precision min / max (fast_score16_pair) into a 10-row score ring; entries that score move on to the 3x3 NMS
 //     + border cull, which runs one row behind the scores (the scored entries of a pass's last row are carried to the next pass).
 // 10 KB of LDS and 88 VGPRs per wave: 16 one-wave workgroups per CU.  Measured against the tiled kernel of rounds 1-4 (512 frames of
-// S-752 at the predicted thresholds, last dispatch, tools/pmc_kernel.sh): vector instructions 213 M -> 180 M, scalar 107 M -> 29 M,
-// 376 -> 330 us alone; at 13 waves per CU (12 KB) 366 us, at 9 waves 440 us -- the kernel is a chain of LDS / global round trips per wave,
+// S-752 at the predicted thresholds, last dispatch, tools/pmc_kernel.sh): vector instructions 213 M -> 172.5 M, scalar 107 M -> 29 M,
+// 376 -> 313 us alone (330 before the pass masks were skewed across the lanes); at 13 waves per CU (12 KB) 366 us, at 9 waves 440 us -- the kernel is a chain of LDS / global round trips per wave,
 // occupancy is what hides them.
 // Results are the tiled kernel's: the pretest is the same necessary condition, cornerScore and the NMS are unchanged, candidate
 // order inside a slot is irrelevant (k_select sorts).
@@ -332,7 +332,7 @@ __device__ __forceinline__ pk16 fast_score16_pair(const uint8_t* a0, const uint8
     uint32_t X[16], m3[16], m9[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const uint32_t pk = (uint32_t)a0[off[k]] | ((uint32_t)b0[off[k]] << 16);
+        const uint32_t pk = (uint32_t)a0[off[k]] | ((uint32_t)b0[off[k]] << 16);     // (no ds_read_u8_d16_hi: with SRAM ECC on, gfx950's d16 loads do not preserve the other half)
         asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(X[k]) : "v"(pk), "v"(nsg), "v"(__builtin_bit_cast(uint32_t, SV)));
     }
 #pragma unroll
