@@ -21,3 +21,13 @@ def test_stress_slice(built, tool, seconds, seed):
     assert " 0 failures" in last and f"seed {seed}" in last, last
     n = int(last.split(":")[1].split()[0])
     assert n >= 3, last                                            # the slice did run cases
+
+
+def test_soak_slice(built):
+    """tools/soak_pipeline.py for a few seconds: every pass over a ring of resident frames (launches queued back to back, results into
+    pinned memory behind each launch) reproduces pass 0's records byte for byte (minutes of it: DESIGN, randomised parity runs)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_pipeline.py"), "5", "64", "6", "parallax"], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-1500:]
+    last = [l for l in r.stdout.splitlines() if l.startswith("soak_pipeline:")][-1]
+    assert " 0 passes differ" in last, last
+    assert int(last.split(":")[1].split()[0]) >= 3, last
