@@ -330,6 +330,9 @@ def main():
                          "frames with --ring 2): the driver's --steps 20 is then 400 launches = 1 s of steady state that an outside sampler (rocm-smi) can see "
                          "(4 launches per step in round 4: 0.2 s, every busy sample read 0 %)")
     ap.add_argument("--ring", type=int, default=2, help="distinct steps' worth of frames resident in HBM")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="REHEARSAL of the N > 1 code path on a box with ONE GPU: every rank uses device 0 and the ranks talk over gloo (RCCL refuses "
+                         "two ranks on one device).  The line says so (\"rehearsal\") and is not a scaling measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the side legs (profiling runs)")
     ap.add_argument("--stages", type=int, default=vislam.STAGE_FRAME, help="debug: bitmask of stages (1 detect, 2 match, 4 pose, 8 Camera::Update); the reported metric needs all 15")
@@ -343,18 +346,21 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if a.rehearse_on_one_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", world_size=world, rank=rank)   # "nccl" == RCCL on ROCm
+        dist.init_process_group(backend="gloo" if a.rehearse_on_one_gpu else "nccl", world_size=world, rank=rank)   # "nccl" == RCCL on ROCm
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
+    ddev = torch.device("cpu") if (world > 1 and a.rehearse_on_one_gpu) else dev      # where the collectives' tensors live
 
     # ---- parameters: rank 0 owns them; one RCCL broadcast of the POD struct ("intrinsics only")
     p = vislam.default_params()
     if rank == 0:
         p.nfeatures, p.nlevels, p.w_size, p.h_size = NFEAT, LEVELS, W, H
         p.fy = p.fx
-    p = vdist.broadcast_params(p, dist, dev, rank)
+    p = vdist.broadcast_params(p, dist, ddev, rank)
 
     ctx = vislam.Context(local_rank if world > 1 else 0, p)
     B, R, Q = a.batch, a.ring, max(1, a.launches_per_step)
@@ -363,12 +369,13 @@ def main():
     ctx.batch_plan(W, H, W, B)
     dt, step_q = timed_steps(ctx, stream, B, R, a.stages, a.steps, a.warmup, dist, dev, q=Q)
     dt_rank = dt
-    dt = vdist.max_over_ranks(dt, dist, dev)
+    dt = vdist.max_over_ranks(dt, dist, ddev)
     # who ran where: one all_gather of a small POD per rank behind the timed region (N ranks must sit on N different devices)
     dev_index = local_rank if world > 1 else 0
     ranks = vdist.gather_rank_records(vdist.pack_rank_record(rank, dev_index, a.steps * B * Q / dt_rank, dt_rank, vislam.device_pci_bus_id(dev_index)),
-                                      dist, dev, world)
-    vdist.check_distinct_devices(ranks)
+                                      dist, ddev, world)
+    if not a.rehearse_on_one_gpu:
+        vdist.check_distinct_devices(ranks)
 
     def step(i):                                          # ONE launch (per-kernel timings, pose load: per launch of B frames)
         ctx.batch_run(stream.ptr((i % (R * Q)) * B), B, a.stages)
@@ -725,7 +732,7 @@ def main():
         out = {
             "metric": "frames/sec detect+match+pose, 752x480 mono8", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "ranks": ranks,
+            "ranks": ranks, **({"rehearsal": "N ranks on ONE device over gloo: exercises the N > 1 code path, not a scaling measurement"} if a.rehearse_on_one_gpu else {}),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "S-752: synthetic 752x480 mono8 EuRoC-shaped stream (frames resident in HBM), 1000 ORB kps x 8 levels, BF-Hamming k=2 "
                                    "both directions + ratio/sym/grid filter, essential RANSAC (adaptive, max 1000) + recoverPose.  S-752 is a planar "
