@@ -403,7 +403,7 @@ int vis_ensure_scratch(vis_ctx* ctx, size_t bytes) {
 }
 static inline int ensure_scratch(vis_ctx* ctx, size_t bytes) { return vis_ensure_scratch(ctx, bytes); }
 
-unsigned long long vis_g_launches = 0;
+std::atomic<unsigned long long> vis_g_launches{0};
 
 // ---- host staging of the single-frame entry points --------------------------------------------------------------------------------
 // The reference's main hands over pageable host memory (cv::Mat, std::vector) once per camera frame (src/main_vi_slamGPU.cpp:118-123).  A
@@ -425,7 +425,7 @@ int vis_ensure_pin(vis_ctx* ctx, size_t bytes) {
 // out[2] = asynchronous copies it queued (bench.py `single_frame_api`: launches and round trips per frame)
 extern "C" int vis_debug_counters(vis_ctx* ctx, unsigned long long out[4]) {
     if (!ctx || !out) return VIS_E_INVALID;
-    out[0] = vis_g_launches; out[1] = ctx->n_host_waits; out[2] = ctx->n_copies; out[3] = 0;
+    out[0] = vis_g_launches.load(std::memory_order_relaxed); out[1] = ctx->n_host_waits; out[2] = ctx->n_copies; out[3] = 0;
     return VIS_OK;
 }
 

@@ -3,6 +3,7 @@
 #ifndef VIS_INTERNAL_H_
 #define VIS_INTERNAL_H_
 
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
@@ -160,11 +161,12 @@ struct VisRange { explicit VisRange(const char*) {} };
 #endif
 
 // every kernel launch of the library is counted (vis_debug_counters: launches per frame of the single-frame path, bench.py's
-// single_frame_api leg): one increment of a plain global beside a launch that costs microseconds
-extern unsigned long long vis_g_launches;
+// single_frame_api leg): one relaxed atomic increment beside a launch that costs microseconds (contexts of different host threads
+// launch concurrently: a plain global would be a data race)
+extern std::atomic<unsigned long long> vis_g_launches;
 #undef hipLaunchKernelGGL
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
-    do { ++vis_g_launches; kernel<<<(grid), (block), (lds), (stream)>>>(__VA_ARGS__); } while (0)
+    do { vis_g_launches.fetch_add(1, std::memory_order_relaxed); kernel<<<(grid), (block), (lds), (stream)>>>(__VA_ARGS__); } while (0)
 
 #define HIPCHK(ctx, call)                                                          \
     do { hipError_t e_ = (call);                                                   \
