@@ -110,3 +110,18 @@ def test_the_product_library_needs_no_profiler_component(vislam):
     lib = os.path.join(ROOT, "vi-slam_amd", "lib", "libvislam_hip.so")
     needed = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True, check=True).stdout
     assert "roctx" not in needed and "rocprofiler" not in needed, needed
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/vislam_hip.h is the drop-in boundary: it must compile as C99 and as C++11 with nothing but the standard headers
+    (-pedantic: no torch / HIP types in the signatures), and the two PODs keep cv::KeyPoint's / cv::DMatch's sizes."""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "vislam_hip.h"\n'
+                   'typedef char kp_is_28[sizeof(vis_keypoint) == 28 ? 1 : -1];\n'
+                   'typedef char dm_is_16[sizeof(vis_dmatch) == 16 ? 1 : -1];\n'
+                   'int main(void) { vis_params p; (void)p; return 0; }\n')
+    inc = os.path.join(ROOT, "include")
+    for cmd in (["gcc", "-std=c99"], ["g++", "-std=c++11", "-x", "c++"]):
+        r = subprocess.run(cmd + ["-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-1500:]
