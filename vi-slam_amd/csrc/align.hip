@@ -581,9 +581,10 @@ extern "C" int vis_batch_align(vis_ctx* ctx, const vis_align_params* ap, const u
     Plan* pl = ctx->batch;
     if (!pl || pl->last_n < 1 || n != pl->last_n) return VIS_E_STATE;
     if (ctx->p.pose_input != VIS_POSE_GOOD) return VIS_E_STATE;                       // needs the grid-filtered matches in d_p1
+    bool plan_set = false;
     if (!d_gray && !d_gx && !d_gy) {                                                   // the plan's own gradients (VIS_STAGE_GRADIENT of the last vis_batch_run)
         if (!pl->grad_valid) { ctx->err = "vis_batch_align: no gradient buffers given and the last vis_batch_run had no VIS_STAGE_GRADIENT"; return VIS_E_STATE; }
-        d_gray = pl->d_half; d_gx = pl->d_gx; d_gy = pl->d_gy;
+        d_gray = pl->d_half; d_gx = pl->d_gx; d_gy = pl->d_gy; plan_set = true;
     }
     // One persistent workgroup per pair, a chain of dependent iterations: latency-bound work that fits beside the next batch's
     // detect chain.  It runs on the pose stream, behind (a) everything queued on the context's stream so far -- the gradients of
@@ -599,7 +600,10 @@ extern "C" int vis_batch_align(vis_ctx* ctx, const vis_align_params* ap, const u
     const int rc = vis_align_batch(ctx, ap, d_frames, pl->w, pl->h, pl->stride, n, d_gray, d_gx, d_gy, pl->d_p1, pl->d_ngood, pl->root * pl->root, d_init, d_out);
     ctx->stream = sA;
     if (rc) return rc;
+    ctx->align_k ^= 1;
+    ctx->ev_align_done = ctx->ev_align_done2[ctx->align_k];                           // (two events in turn: the one before stays valid for the set it guards)
     HIPCHK(ctx, hipEventRecord(ctx->ev_align_done, sP));
     ctx->align_pending = true;
+    if (plan_set) pl->grad_reader[pl->grad_set] = ctx->ev_align_done;                 // the side stream refills this set two steps on
     return VIS_OK;
 }

@@ -106,7 +106,9 @@ extern "C" int vis_create(int device, vis_ctx** out) {
         hipEventCreateWithFlags(&ctx->ev_update_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_update_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_align_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_align_done, hipEventDisableTiming) != hipSuccess) { delete ctx; return VIS_E_HIP; }
+        hipEventCreateWithFlags(&ctx->ev_align_done2[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_align_done2[1], hipEventDisableTiming) != hipSuccess) { delete ctx; return VIS_E_HIP; }
+    ctx->ev_align_done = ctx->ev_align_done2[0];
     ctx->ev_ok = true;
     for (int i = 0; i < 12; i++) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) ctx->ev_ok = false;
     *out = ctx;
@@ -130,7 +132,7 @@ extern "C" void vis_destroy(vis_ctx* ctx) {
     if (ctx->ev_pose_start) (void)hipEventDestroy(ctx->ev_pose_start);
     if (ctx->ev_results_done) (void)hipEventDestroy(ctx->ev_results_done);
     if (ctx->ev_align_fork) (void)hipEventDestroy(ctx->ev_align_fork);
-    if (ctx->ev_align_done) (void)hipEventDestroy(ctx->ev_align_done);
+    for (int i = 0; i < 2; i++) if (ctx->ev_align_done2[i]) (void)hipEventDestroy(ctx->ev_align_done2[i]);
     if (ctx->match_stream) { (void)hipStreamSynchronize(ctx->match_stream); (void)hipStreamDestroy(ctx->match_stream); }
     if (ctx->ev_detect_done) (void)hipEventDestroy(ctx->ev_detect_done);
     if (ctx->ev_match_start) (void)hipEventDestroy(ctx->ev_match_start);
@@ -148,7 +150,7 @@ static void sync_all(vis_ctx* ctx) {
     if (ctx->match_stream) (void)hipStreamSynchronize(ctx->match_stream);
     if (ctx->pose_stream) (void)hipStreamSynchronize(ctx->pose_stream);
     ctx->pose_pending = false; ctx->results_pending = false; ctx->align_pending = false;
-    if (ctx->batch) for (int i = 0; i < VIS_BATCH_SETS; i++) ctx->batch->match_pending[i] = false;
+    if (ctx->batch) { for (int i = 0; i < VIS_BATCH_SETS; i++) ctx->batch->match_pending[i] = false; ctx->batch->grad_reader[0] = ctx->batch->grad_reader[1] = nullptr; }
 }
 
 extern "C" const char* vis_last_error(vis_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -244,7 +246,7 @@ void plan_destroy(Plan* pl) {
         F(pl->d_pyr[l]); F(pl->d_rs_tab[l]);
         F(pl->d_cand[l]); F(pl->d_seg_kp[l]);
     }
-    F(pl->d_fast_tiles); F(pl->d_tile_cnt); F(pl->d_seg_cnt); F(pl->d_flags); F(pl->d_angle_tab); F(pl->d_half); F(pl->d_gx); F(pl->d_gy); F(pl->d_g); F(pl->d_tau); F(pl->d_seg_cut); F(pl->d_fix);
+    F(pl->d_fast_tiles); F(pl->d_tile_cnt); F(pl->d_seg_cnt); F(pl->d_flags); F(pl->d_angle_tab); for (int i = 0; i < 2; i++) { F(pl->d_half_set[i]); F(pl->d_gx_set[i]); F(pl->d_gy_set[i]); F(pl->d_g_set[i]); } F(pl->d_tau); F(pl->d_seg_cut); F(pl->d_fix);
     F(pl->d_kps); F(pl->d_desc); F(pl->d_nkp); F(pl->d_descx);
     for (int i = 0; i < VIS_BATCH_SETS; i++) { F(pl->d_pq[i]); F(pl->d_pt[i]); F(pl->d_pqn[i]); }
     F(pl->d_knn12); F(pl->d_knn21);
@@ -1048,21 +1050,24 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
     bool update_queued = false;
     if (stages & (VIS_STAGE_UPDATE | VIS_STAGE_GRADIENT)) {
         VisRange r_("vis: Camera::Update half pyramid");
-        if (!pl->d_half) HIPCHK(ctx, hipMalloc((void**)&pl->d_half, (size_t)pl->B * vis_grad_frame_elems(pl->w, pl->h)));
+        const int gs = (pl->grad_set ^= 1);                            // this step's half pyramid / gradient set
+        if (!pl->d_half_set[gs]) HIPCHK(ctx, hipMalloc((void**)&pl->d_half_set[gs], (size_t)pl->B * vis_grad_frame_elems(pl->w, pl->h)));
+        pl->d_half = pl->d_half_set[gs];
         // the frames were produced on the detect stream (or before the call): the side stream is ordered behind it -- behind the
         // PYRAMID launches of this batch's detect chain (launch_detect recorded the event there): the resize chain streams at HBM
         // speed itself, the kernels after it are vector-ALU bound, and that is where streaming work fits beside them
         if (!detect) HIPCHK(ctx, hipEventRecord(ctx->ev_update_fork, sA));
         HIPCHK(ctx, hipStreamWaitEvent(sU, ctx->ev_update_fork, 0));
-        // the previous batch's alignment (vis_batch_align on the pose stream) may still read the half pyramid / the gradients
-        if (ctx->align_pending) HIPCHK(ctx, hipStreamWaitEvent(sU, ctx->ev_align_done, 0));
+        // an alignment two steps back (vis_batch_align on the pose stream) may still read THIS set's half pyramid / gradients
+        if (pl->grad_reader[gs]) HIPCHK(ctx, hipStreamWaitEvent(sU, pl->grad_reader[gs], 0));
         if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[10], sU);
         ctx->stream = sU;
         rc = launch_half_pyramid_batch(ctx, d_frames, pl->w, pl->h, pl->stride, (size_t)pl->stride * pl->h, n, pl->d_half);
         ctx->stream = sA;
         if (!rc && (stages & VIS_STAGE_GRADIENT)) {
             const size_t fe = vis_grad_frame_elems(pl->w, pl->h);
-            if (!pl->d_gx) { HIPCHK(ctx, hipMalloc((void**)&pl->d_gx, (size_t)pl->B * fe * 2)); HIPCHK(ctx, hipMalloc((void**)&pl->d_gy, (size_t)pl->B * fe * 2)); HIPCHK(ctx, hipMalloc((void**)&pl->d_g, (size_t)pl->B * fe)); }
+            if (!pl->d_gx_set[gs]) { HIPCHK(ctx, hipMalloc((void**)&pl->d_gx_set[gs], (size_t)pl->B * fe * 2)); HIPCHK(ctx, hipMalloc((void**)&pl->d_gy_set[gs], (size_t)pl->B * fe * 2)); HIPCHK(ctx, hipMalloc((void**)&pl->d_g_set[gs], (size_t)pl->B * fe)); }
+            pl->d_gx = pl->d_gx_set[gs]; pl->d_gy = pl->d_gy_set[gs]; pl->d_g = pl->d_g_set[gs];
             ctx->stream = sU;
             rc = launch_gradient(ctx, d_frames, pl->w, pl->h, pl->stride, (size_t)pl->stride * pl->h, n, pl->d_half, 3 /* the reference's Scharr scale, src/Camera.cpp:172 */, pl->d_gx, pl->d_gy, pl->d_g);
             ctx->stream = sA;
@@ -1079,8 +1084,10 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
         update_queued = true;
         pl->half_valid = true;
     }
-    if (update_queued) HIPCHK(ctx, hipStreamWaitEvent(sA, ctx->ev_update_done, 0));
+    // the matcher needs the records (detect chain), not the side stream's half pyramid / gradients: its event comes BEFORE the join (with
+    // the join in front, the matcher -- and through it the alignment and the next step's gradients -- waited for the gradient stage)
     HIPCHK(ctx, hipEventRecord(ctx->ev_detect_done, sA));
+    if (update_queued) HIPCHK(ctx, hipStreamWaitEvent(sA, ctx->ev_update_done, 0));
     if (stages & (VIS_STAGE_MATCH | VIS_STAGE_POSE)) HIPCHK(ctx, hipStreamWaitEvent(sM, ctx->ev_detect_done, 0));
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev_match_start, sM);
     // pair i: query = record base+i (frame i-1, or the carried frame for i = 0), train = record base+i+1 (frame i)
@@ -1131,7 +1138,7 @@ extern "C" int vis_batch_sync(vis_ctx* ctx) {
     const bool had_pose = ctx->pose_pending;
     if (ctx->pose_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->pose_stream));
     ctx->pose_pending = false; ctx->results_pending = false; ctx->align_pending = false;
-    if (ctx->batch) for (int i = 0; i < VIS_BATCH_SETS; i++) ctx->batch->match_pending[i] = false;
+    if (ctx->batch) { for (int i = 0; i < VIS_BATCH_SETS; i++) ctx->batch->match_pending[i] = false; ctx->batch->grad_reader[0] = ctx->batch->grad_reader[1] = nullptr; }
     if (ctx->ev_ok) {
         collect_detect_timings(ctx);
         float a = 0;

@@ -67,9 +67,17 @@ struct Plan {
     int32_t* d_tau = nullptr;                // L
     int32_t* d_seg_cut = nullptr;            // B x L
     int32_t* d_fix = nullptr;                // 1 + B x L
-    uint8_t* d_half = nullptr;               // VIS_STAGE_UPDATE: B x vis_grad_frame_elems(w, h) half pyramids (allocated on first use)
+    // VIS_STAGE_UPDATE: B x vis_grad_frame_elems(w, h) half pyramids; VIS_STAGE_GRADIENT: the Scharr gradients of the batch
+    // (Camera::computeGradient) beside the detect chain.  Plan-owned, allocated on first use, TWO sets used in turn: vis_batch_align of
+    // step i reads set i & 1 on the pose stream while the side stream of step i + 1 fills the other one (with one set the alignment, the
+    // next step's gradients and -- through the detect stream's join -- the next matcher formed a serial chain as long as the step).
+    // d_half / d_gx / d_gy / d_g = the set the last vis_batch_run wrote (not owned); grad_reader[s] = the event of the last alignment
+    // that read set s (nullptr: none pending).
+    uint8_t* d_half_set[2] = {nullptr, nullptr}; int16_t* d_gx_set[2] = {nullptr, nullptr}; int16_t* d_gy_set[2] = {nullptr, nullptr}; uint8_t* d_g_set[2] = {nullptr, nullptr};
+    int grad_set = 0;
+    hipEvent_t grad_reader[2] = {nullptr, nullptr};
+    uint8_t* d_half = nullptr;
     bool half_valid = false;
-    // VIS_STAGE_GRADIENT: Scharr gradients of the batch (Camera::computeGradient) beside the detect chain, plan-owned, allocated on first use
     int16_t* d_gx = nullptr; int16_t* d_gy = nullptr; uint8_t* d_g = nullptr;
     bool grad_valid = false;
     // records
@@ -128,7 +136,8 @@ struct vis_ctx {
     hipEvent_t ev_update_fork = nullptr, ev_update_done = nullptr;
     bool pose_pending = false;
     // vis_batch_align runs on the pose stream (beside the next batch's detect chain): what may not overtake it waits for this event
-    hipEvent_t ev_align_fork = nullptr, ev_align_done = nullptr; bool align_pending = false;
+    // (ev_align_done = the event of the LAST alignment, one of ev_align_done2[] used in turn, so that a gradient set can wait for its own reader)
+    hipEvent_t ev_align_fork = nullptr, ev_align_done = nullptr, ev_align_done2[2] = {nullptr, nullptr}; int align_k = 0; bool align_pending = false;
     bool pose_attr_set = false;              // > 64 KiB LDS opt-in of the RANSAC solver kernels done on this context's device
     bool pose_grids_set = false; int pose_grid[4] = {0, 0, 0, 0};   // resident-workgroup grids of the work-list pose kernels on this device (pose.hip pose_grids)
     hipEvent_t ev_results_done = nullptr; bool results_pending = false;   // D2H of the last batch's results (vis_batch_results_async)
