@@ -335,8 +335,9 @@ int  vis_batch_sync(vis_ctx* ctx);
 int  vis_batch_half_pyramid(vis_ctx* ctx, const uint8_t** d_half, size_t* frame_elems);
 /* the gradients the last vis_batch_run(... | VIS_STAGE_GRADIENT) wrote: DEVICE pointers laid out like the outputs of
  * vis_gradient_batch (d_gray = the half pyramid of vis_batch_half_pyramid); any pointer may be NULL.  VIS_E_STATE if the
- * stage has not run.  Valid until the next vis_batch_run / vis_batch_plan.  vis_batch_align takes them when its three
- * gradient arguments are NULL. */
+ * stage has not run.  Valid until the next vis_batch_run / vis_batch_plan (the plan owns two sets and fills them in turn, so
+ * that a vis_batch_align still reading one does not hold up the next step's gradients).  vis_batch_align takes them when its
+ * three gradient arguments are NULL. */
 int  vis_batch_gradients(vis_ctx* ctx, const uint8_t** d_gray, const int16_t** d_gx, const int16_t** d_gy, const uint8_t** d_g,
                          size_t* frame_elems);
 /* copy results of the last batch to host (synchronises). Any pointer may be NULL. */

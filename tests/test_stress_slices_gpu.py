@@ -23,10 +23,12 @@ def test_stress_slice(built, tool, seconds, seed):
     assert n >= 3, last                                            # the slice did run cases
 
 
-def test_soak_slice(built):
+@pytest.mark.parametrize("mode", ["parallax", "main"])
+def test_soak_slice(built, mode):
     """tools/soak_pipeline.py for a few seconds: every pass over a ring of resident frames (launches queued back to back, results into
-    pinned memory behind each launch) reproduces pass 0's records byte for byte (minutes of it: DESIGN, randomised parity runs)."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_pipeline.py"), "5", "64", "6", "parallax"], capture_output=True, text=True, timeout=240)
+    pinned memory behind each launch) reproduces pass 0's records byte for byte (minutes of it: DESIGN, randomised parity runs).
+    "main" = the GPU main's sequence: gradients on the side stream into the plan's two sets in turn, vis_batch_align on the pose stream."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_pipeline.py"), "5", "64", "6", mode], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, (r.stdout + r.stderr)[-1500:]
     last = [l for l in r.stdout.splitlines() if l.startswith("soak_pipeline:")][-1]
     assert " 0 passes differ" in last, last
