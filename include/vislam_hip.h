@@ -366,7 +366,8 @@ typedef struct vis_pose_result {
 } vis_pose_result;
 /* Queue the device-to-host copy of the last batch's results -- n pose records, the good matches (n x root^2, dense
  * rows) and their counts -- behind the batch's own work; any pointer may be NULL; pinned host memory makes the copy
- * overlap the next vis_batch_run.  n_cap = the number of frames the caller's buffers hold: VIS_E_CAPACITY (nothing is
+ * overlap the next vis_batch_run (pinned = device-accessible, e.g. hipHostMalloc: such destinations are written by one
+ * small kernel of the library, which costs the pipeline nothing; anything else goes through hipMemcpyAsync).  n_cap = the number of frames the caller's buffers hold: VIS_E_CAPACITY (nothing is
  * copied) if the last batch had more.  The reference downloads its results every frame (src/CameraGPU.cpp:103, the
  * DMatch vectors of src/MatcherGPU.cpp:54-56).  The copies are only QUEUED: the host may read the buffers after
  * vis_batch_sync() (or after waiting for an event recorded behind this call); a later vis_batch_results_async is

@@ -605,5 +605,6 @@ extern "C" int vis_batch_align(vis_ctx* ctx, const vis_align_params* ap, const u
     HIPCHK(ctx, hipEventRecord(ctx->ev_align_done, sP));
     ctx->align_pending = true;
     if (plan_set) pl->grad_reader[pl->grad_set] = ctx->ev_align_done;                 // the side stream refills this set two steps on
+    pl->mo_align[pl->last_cur] = ctx->ev_align_done;                                 // it read the matched points of the last step's matcher-output set
     return VIS_OK;
 }

@@ -97,6 +97,10 @@ extern "C" int vis_create(int device, vis_ctx** out) {
         hipEventCreateWithFlags(&ctx->ev_pose_done, hipEventDefault) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_pose_start, hipEventDefault) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_results_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_pose_done_set[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_pose_done_set[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_results_done_set[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_results_done_set[1], hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->match_stream, hipStreamNonBlocking, prio_match) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_detect_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_match_start, hipEventDefault) != hipSuccess ||
@@ -131,6 +135,7 @@ extern "C" void vis_destroy(vis_ctx* ctx) {
     if (ctx->ev_pose_done) (void)hipEventDestroy(ctx->ev_pose_done);
     if (ctx->ev_pose_start) (void)hipEventDestroy(ctx->ev_pose_start);
     if (ctx->ev_results_done) (void)hipEventDestroy(ctx->ev_results_done);
+    for (int i = 0; i < 2; i++) { if (ctx->ev_pose_done_set[i]) (void)hipEventDestroy(ctx->ev_pose_done_set[i]); if (ctx->ev_results_done_set[i]) (void)hipEventDestroy(ctx->ev_results_done_set[i]); }
     if (ctx->ev_align_fork) (void)hipEventDestroy(ctx->ev_align_fork);
     for (int i = 0; i < 2; i++) if (ctx->ev_align_done2[i]) (void)hipEventDestroy(ctx->ev_align_done2[i]);
     if (ctx->match_stream) { (void)hipStreamSynchronize(ctx->match_stream); (void)hipStreamDestroy(ctx->match_stream); }
@@ -150,7 +155,8 @@ static void sync_all(vis_ctx* ctx) {
     if (ctx->match_stream) (void)hipStreamSynchronize(ctx->match_stream);
     if (ctx->pose_stream) (void)hipStreamSynchronize(ctx->pose_stream);
     ctx->pose_pending = false; ctx->results_pending = false; ctx->align_pending = false;
-    if (ctx->batch) { for (int i = 0; i < VIS_BATCH_SETS; i++) ctx->batch->match_pending[i] = false; ctx->batch->grad_reader[0] = ctx->batch->grad_reader[1] = nullptr; }
+    if (ctx->batch) { for (int i = 0; i < VIS_BATCH_SETS; i++) ctx->batch->match_pending[i] = false; ctx->batch->grad_reader[0] = ctx->batch->grad_reader[1] = nullptr;
+                      for (int i = 0; i < 2; i++) ctx->batch->mo_pose[i] = ctx->batch->mo_results[i] = ctx->batch->mo_align[i] = nullptr; }
 }
 
 extern "C" const char* vis_last_error(vis_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -250,7 +256,9 @@ void plan_destroy(Plan* pl) {
     F(pl->d_kps); F(pl->d_desc); F(pl->d_nkp); F(pl->d_descx);
     for (int i = 0; i < VIS_BATCH_SETS; i++) { F(pl->d_pq[i]); F(pl->d_pt[i]); F(pl->d_pqn[i]); }
     F(pl->d_knn12); F(pl->d_knn21);
-    F(pl->d_sym); F(pl->d_nsym); F(pl->d_good); F(pl->d_ngood); F(pl->d_p1); F(pl->d_p2); F(pl->d_hf); F(pl->d_wf);
+    if (pl->mo_set[0][0] || pl->mo_set[1][0]) { for (int s_ = 0; s_ < 2; s_++) for (int k = 0; k < 6; k++) F(pl->mo_set[s_][k]); }    // (d_sym ... d_p2 alias one of the sets)
+    else { F(pl->d_sym); F(pl->d_nsym); F(pl->d_good); F(pl->d_ngood); F(pl->d_p1); F(pl->d_p2); }                                  // a plan that failed before the sets were registered
+    F(pl->d_hf); F(pl->d_wf);
     F(pl->d_n1); F(pl->d_n2); F(pl->d_mask); F(pl->d_samples); F(pl->d_models); F(pl->d_counts); F(pl->d_rstate); F(pl->d_pose); F(pl->d_worklist); F(pl->d_hyp);
     delete pl;
 }
@@ -344,6 +352,26 @@ int plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int npa
     HIPCHK(ctx, hipMemset(pl->d_knn21, 0xFF, (size_t)npairs * kcap * 2 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMemset(pl->d_p1, 0, (size_t)npairs * mcap * 2 * sizeof(float)));
     HIPCHK(ctx, hipMemset(pl->d_p2, 0, (size_t)npairs * mcap * 2 * sizeof(float)));
+    {   // the matcher-output sets (vis_internal.h): set 0 = the arrays above; a second one for plans that pipeline steps (nsets > 1)
+        void* s0[6] = {pl->d_sym, pl->d_nsym, pl->d_good, pl->d_ngood, pl->d_p1, pl->d_p2};
+        for (int k = 0; k < 6; k++) pl->mo_set[0][k] = s0[k];
+#ifndef VIS_MO_SETS
+#define VIS_MO_SETS 2
+#endif
+        if (pl->nsets > 1 && VIS_MO_SETS > 1) {
+            vis_dmatch* sym2 = nullptr; int32_t* nsym2 = nullptr; vis_dmatch* good2 = nullptr; int32_t* ngood2 = nullptr; float* p12 = nullptr; float* p22 = nullptr;
+            DALLOC(sym2, (size_t)npairs * kcap); pl->mo_set[1][0] = sym2;
+            DALLOC(nsym2, npairs); pl->mo_set[1][1] = nsym2;
+            DALLOC(good2, (size_t)npairs * ncell); pl->mo_set[1][2] = good2;
+            DALLOC(ngood2, npairs); pl->mo_set[1][3] = ngood2;
+            DALLOC(p12, (size_t)npairs * mcap * 2); pl->mo_set[1][4] = p12;
+            DALLOC(p22, (size_t)npairs * mcap * 2); pl->mo_set[1][5] = p22;
+            HIPCHK(ctx, hipMemset(nsym2, 0, (size_t)npairs * 4));
+            HIPCHK(ctx, hipMemset(ngood2, 0, (size_t)npairs * 4));
+            HIPCHK(ctx, hipMemset(p12, 0, (size_t)npairs * mcap * 2 * sizeof(float)));
+            HIPCHK(ctx, hipMemset(p22, 0, (size_t)npairs * mcap * 2 * sizeof(float)));
+        }
+    }
     HIPCHK(ctx, hipMemset(pl->d_pose, 0, (size_t)npairs * sizeof(PoseOut)));
     // cv::RNG sample tables only for small M (the reference pipeline: M <= root^2); larger M replays the stream on the device
     { int rc2 = vis_build_sample_table(ctx, std::min(mcap, 8192)); if (rc2) { plan_destroy(pl); return rc2; } }
@@ -1093,6 +1121,13 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
     // pair i: query = record base+i (frame i-1, or the carried frame for i = 0), train = record base+i+1 (frame i)
     pl->d_pair_q = have_prev ? pl->d_pq[cur] : pl->d_pqn[cur];
     pl->d_pair_t = pl->d_pt[cur];
+    // the matcher-output set of this step: a step that runs the matcher takes the next one, a pose-only step reads the last one
+    const int mo = pl->mo_set[1][0] ? ((stages & VIS_STAGE_MATCH) ? (pl->last_cur ^ 1) : pl->last_cur) : 0;
+    auto use_mo = [&](int s_) {
+        pl->d_sym = (vis_dmatch*)pl->mo_set[s_][0]; pl->d_nsym = (int32_t*)pl->mo_set[s_][1]; pl->d_good = (vis_dmatch*)pl->mo_set[s_][2];
+        pl->d_ngood = (int32_t*)pl->mo_set[s_][3]; pl->d_p1 = (float*)pl->mo_set[s_][4]; pl->d_p2 = (float*)pl->mo_set[s_][5];
+    };
+    use_mo(mo);
     ctx->stream = sM;
     if (stages & VIS_STAGE_MATCH) {
         VisRange r_("vis: knn + match filters");
@@ -1100,12 +1135,11 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
         if (!rc) rc = launch_match(ctx, pl, n);
         if (!rc) {
             if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[5], sM);
-            // the filter rewrites the pose inputs of the previous batch: wait until its pose work is done
-            if (ctx->pose_pending) { hipError_t e = hipStreamWaitEvent(sM, ctx->ev_pose_done, 0); if (e != hipSuccess) rc = VIS_E_HIP; }
-            // ... and the previous batch's alignment (vis_batch_align reads the matched points on the pose stream)
-            if (!rc && ctx->align_pending) { hipError_t e = hipStreamWaitEvent(sM, ctx->ev_align_done, 0); if (e != hipSuccess) rc = VIS_E_HIP; }
-            // ... and until the previous batch's results have left the device
-            if (!rc && ctx->results_pending) { hipError_t e = hipStreamWaitEvent(sM, ctx->ev_results_done, 0); if (e != hipSuccess) rc = VIS_E_HIP; }
+            // the filter writes matcher-output set `mo` (sets in turn, like the records): wait for what still reads THAT set -- the pose
+            // stage, the alignment and the results download of the step before last; those of the last step read the other set
+            if (pl->mo_pose[mo]) { hipError_t e = hipStreamWaitEvent(sM, pl->mo_pose[mo], 0); if (e != hipSuccess) rc = VIS_E_HIP; }
+            if (!rc && pl->mo_align[mo]) { hipError_t e = hipStreamWaitEvent(sM, pl->mo_align[mo], 0); if (e != hipSuccess) rc = VIS_E_HIP; }
+            if (!rc && pl->mo_results[mo]) { hipError_t e = hipStreamWaitEvent(sM, pl->mo_results[mo], 0); if (e != hipSuccess) rc = VIS_E_HIP; }
             if (!rc) rc = launch_filter(ctx, pl, n);
         }
         if (!rc && ctx->ev_ok) (void)hipEventRecord(ctx->ev[6], sM);
@@ -1120,13 +1154,14 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
         rc = launch_pose(ctx, pl, n);
         (void)hipEventRecord(ctx->ev_pose_done, sP);
         ctx->pose_pending = true;
+        if (hipEventRecord(ctx->ev_pose_done_set[mo], sP) == hipSuccess) pl->mo_pose[mo] = ctx->ev_pose_done_set[mo];
     }
     ctx->stream = sA;
-    if (rc) return rc;            // nothing of the stream state (carried frame, record set) has been committed
+    if (rc) { use_mo(pl->last_cur); return rc; }            // nothing of the stream state (carried frame, record set, matcher-output set) has been committed
     pl->have_prev = have_prev; pl->pair0_valid = have_prev;
     if (detect) { pl->run_count++; pl->carry_from = base + n; }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[8], sA);
-    pl->last_n = n; pl->last_base = base;
+    pl->last_n = n; pl->last_base = base; pl->last_cur = mo;
     return VIS_OK;
 }
 
@@ -1138,7 +1173,8 @@ extern "C" int vis_batch_sync(vis_ctx* ctx) {
     const bool had_pose = ctx->pose_pending;
     if (ctx->pose_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->pose_stream));
     ctx->pose_pending = false; ctx->results_pending = false; ctx->align_pending = false;
-    if (ctx->batch) { for (int i = 0; i < VIS_BATCH_SETS; i++) ctx->batch->match_pending[i] = false; ctx->batch->grad_reader[0] = ctx->batch->grad_reader[1] = nullptr; }
+    if (ctx->batch) { for (int i = 0; i < VIS_BATCH_SETS; i++) ctx->batch->match_pending[i] = false; ctx->batch->grad_reader[0] = ctx->batch->grad_reader[1] = nullptr;
+                      for (int i = 0; i < 2; i++) ctx->batch->mo_pose[i] = ctx->batch->mo_results[i] = ctx->batch->mo_align[i] = nullptr; }
     if (ctx->ev_ok) {
         collect_detect_timings(ctx);
         float a = 0;
@@ -1188,11 +1224,33 @@ extern "C" int vis_batch_results_async(vis_ctx* ctx, vis_pose_result* h_pose, vi
     // the pose stream is ordered behind the matcher of the same batch (ev_filter_done); without a pose stage the matcher's own stream
     hipStream_t s = ctx->pose_pending ? ctx->pose_stream : ctx->match_stream;
     const int ncell = pl->root * pl->root;
-    if (h_pose) HIPCHK(ctx, hipMemcpyAsync(h_pose, pl->d_pose, (size_t)n * sizeof(vis_pose_result), hipMemcpyDeviceToHost, s));
-    if (h_good) HIPCHK(ctx, hipMemcpyAsync(h_good, pl->d_good, (size_t)n * ncell * sizeof(vis_dmatch), hipMemcpyDeviceToHost, s));
-    if (h_ngood) HIPCHK(ctx, hipMemcpyAsync(h_ngood, pl->d_ngood, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    // Pinned (device-accessible) destinations are written by ONE small kernel of the library instead of three hipMemcpyAsync: every
+    // device-to-host copy of the runtime ends in a system-scope release, and with one per step the whole pipeline lost 8 % (round 5:
+    // 402 k -> 371 k frames/s with a single 196 KB copy per step).  The host reads after vis_batch_sync, which orders it.  Anything
+    // else (pageable memory, unaligned pointers) goes through the runtime's copies as before.
+    void* dsts[3]; const void* srcs[3]; size_t bytes[3]; int nj = 0; bool mapped = true;
+    auto add = [&](void* h, const void* d, size_t b) {
+        if (!h) return;
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, h) != hipSuccess) { (void)hipGetLastError(); mapped = false; }
+        else if (at.type != hipMemoryTypeHost || !at.devicePointer || ((uintptr_t)at.devicePointer & 3)) mapped = false;
+        else { dsts[nj] = at.devicePointer; }
+        if (!mapped) dsts[nj] = h;
+        srcs[nj] = d; bytes[nj] = b; nj++;
+    };
+    add(h_pose, pl->d_pose, (size_t)n * sizeof(vis_pose_result));
+    add(h_good, pl->d_good, (size_t)n * ncell * sizeof(vis_dmatch));
+    add(h_ngood, pl->d_ngood, (size_t)n * sizeof(int32_t));
+    if (nj && mapped) { const int rc = launch_copy_jobs(ctx, s, nj, dsts, srcs, bytes); if (rc) return rc; ctx->n_copies++; }
+    else {
+        if (h_pose) HIPCHK(ctx, hipMemcpyAsync(h_pose, pl->d_pose, (size_t)n * sizeof(vis_pose_result), hipMemcpyDeviceToHost, s));
+        if (h_good) HIPCHK(ctx, hipMemcpyAsync(h_good, pl->d_good, (size_t)n * ncell * sizeof(vis_dmatch), hipMemcpyDeviceToHost, s));
+        if (h_ngood) HIPCHK(ctx, hipMemcpyAsync(h_ngood, pl->d_ngood, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    }
     HIPCHK(ctx, hipEventRecord(ctx->ev_results_done, s));
     ctx->results_pending = true;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_results_done_set[pl->last_cur], s));
+    pl->mo_results[pl->last_cur] = ctx->ev_results_done_set[pl->last_cur];
     return VIS_OK;
 }
 

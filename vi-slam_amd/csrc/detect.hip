@@ -1332,6 +1332,18 @@ __global__ __launch_bounds__(256) void k_small_ops(SmallOps J) {
     }
 }
 
+// up to six dword-granular copies (src == nullptr: clear) in ONE launch on `st`; the destinations may be device-accessible host memory
+int launch_copy_jobs(vis_ctx* ctx, hipStream_t st, int njobs, void* const* dst, const void* const* src, const size_t* bytes) {
+    if (njobs < 1 || njobs > 6) return VIS_E_INVALID;
+    SmallOps J = {}; uint32_t e = 0;
+    for (int k = 0; k < njobs; k++) { J.dst[k] = (uint32_t*)dst[k]; J.src[k] = (const uint32_t*)src[k]; e += (uint32_t)(bytes[k] / 4); J.end[k] = e; }
+    J.n = njobs;
+    if (!e) return VIS_OK;
+    hipLaunchKernelGGL(k_small_ops, dim3((unsigned)std::min<uint32_t>(1024u, (e + 255u) / 256u)), dim3(256), 0, st, J);
+    HIPCHK(ctx, hipGetLastError());
+    return VIS_OK;
+}
+
 int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int rec0, int carry_rec, hipEvent_t after_resize, hipEvent_t records_free) {
     hipStream_t st = ctx->stream;
     const int L = pl->L;

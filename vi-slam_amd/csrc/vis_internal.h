@@ -96,6 +96,15 @@ struct Plan {
     int32_t* d_ngood = nullptr;
     float* d_p1 = nullptr;                   // npairs x root^2 x 2
     float* d_p2 = nullptr;
+    // The six arrays above are what k_filter writes and the pose stage / vis_batch_align / the results download read.  A batch plan
+    // owns TWO sets of them, used in turn like the record sets: with one set the filter of step i + 1 had to wait for the pose stage and
+    // the download of step i, and the pose stage of step i + 1 for that filter -- a serial loop (pose chain + download + filter) that
+    // set the step's period as soon as it grew longer than the detect chain (results download: - 8 %).  d_sym ... d_p2 = the set of
+    // the last vis_batch_run (not owned); mo_set[s] = {sym, nsym, good, ngood, p1, p2} of set s (set 0 only for single-frame plans);
+    // mo_pose / mo_results / mo_align[s] = the event behind the last reader of set s on the pose stream (nullptr: none pending).
+    void* mo_set[2][6] = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
+    hipEvent_t mo_pose[2] = {nullptr, nullptr}, mo_results[2] = {nullptr, nullptr}, mo_align[2] = {nullptr, nullptr};
+    int last_cur = 0;
     float* d_hf = nullptr;                   // root band limits (float accumulation on host)
     float* d_wf = nullptr;
     // pose
@@ -140,6 +149,7 @@ struct vis_ctx {
     hipEvent_t ev_align_fork = nullptr, ev_align_done = nullptr, ev_align_done2[2] = {nullptr, nullptr}; int align_k = 0; bool align_pending = false;
     bool pose_attr_set = false;              // > 64 KiB LDS opt-in of the RANSAC solver kernels done on this context's device
     bool pose_grids_set = false; int pose_grid[4] = {0, 0, 0, 0};   // resident-workgroup grids of the work-list pose kernels on this device (pose.hip pose_grids)
+    hipEvent_t ev_pose_done_set[2] = {nullptr, nullptr}, ev_results_done_set[2] = {nullptr, nullptr};   // per match-output set (Plan::mo_set)
     hipEvent_t ev_results_done = nullptr; bool results_pending = false;   // D2H of the last batch's results (vis_batch_results_async)
     vis_params p;
     std::string err;
@@ -253,6 +263,7 @@ int  plan_create(vis_ctx* ctx, int w, int h, int stride, int B, int nrec, int np
 void plan_destroy(Plan* pl);
 
 // ---- kernel launchers (each enqueues on ctx->stream) ----
+int launch_copy_jobs(vis_ctx* ctx, hipStream_t st, int njobs, void* const* dst, const void* const* src, const size_t* bytes);   // detect.hip: <= 6 dword-granular copies in one launch
 int launch_detect(vis_ctx* ctx, Plan* pl, const uint8_t* d_frames, int n, int rec0, int carry_rec = -1, hipEvent_t after_resize = nullptr, hipEvent_t records_free = nullptr);   // carry_rec >= 0: copy that record to rec0 - 1 before k_describe; after_resize: recorded behind the pyramid launches; records_free: waited for before the chain's first write to the record set
 int build_fast_tiles(vis_ctx* ctx, Plan* pl);
 int launch_expand(vis_ctx* ctx, Plan* pl, int rec_first, int rec_count);
