@@ -549,7 +549,12 @@ extern "C" int vis_align_batch(vis_ctx* ctx, const vis_align_params* ap, const u
     if (stride < w || n < 1 || max_pts < 1) { ctx->err = "vis_align_batch: stride >= w, n >= 1, max_pts >= 1"; return VIS_E_INVALID; }
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
-    HIPCHK(ctx, hipMemsetAsync(d_out, 0, sizeof(vis_align_result), st));            // frame 0 has no predecessor in this batch
+    {   // frame 0 has no predecessor in this batch: its record is cleared (by a kernel of the library, not by the runtime's fill)
+        static_assert(sizeof(vis_align_result) % 4 == 0, "cleared in dwords");
+        void* dsts[1] = {d_out}; const void* srcs[1] = {nullptr}; const size_t bytes[1] = {sizeof(vis_align_result)};
+        const int rc0 = launch_copy_jobs(ctx, st, 1, dsts, srcs, bytes);
+        if (rc0) return rc0;
+    }
     if (n < 2) return VIS_OK;
     AlignArgs G; std::memset(&G, 0, sizeof(G));
     fill_level_intrinsics(*ap, G);

@@ -218,8 +218,11 @@ DEV void draw_subset(CvRng& rng, int M, int* idx) {
 
 __global__ __launch_bounds__(256) void k_pose_prep(PoseParams P, const float* __restrict__ p1, const float* __restrict__ p2,
                                                    const int32_t* __restrict__ npts, double* __restrict__ n1, double* __restrict__ n2,
-                                                   int32_t* __restrict__ samples, int32_t* __restrict__ rstate) {
+                                                   int32_t* __restrict__ samples, int32_t* __restrict__ rstate, int32_t* __restrict__ worklist) {
     const int pair = blockIdx.x, tid = threadIdx.x;
+    // the work list starts empty (here instead of a hipMemsetAsync in front of the RANSAC kernels: one launch less on the pose stream,
+    // and the runtime's fill kernel is not an ordinary launch -- see vis_batch_results_async on what its copies cost the pipeline)
+    if (worklist && pair == 0 && tid == 0) worklist[0] = 0;
     const int M = min(npts[pair], P.mcap);
     const float* a = p1 + (size_t)pair * P.mcap * 2;
     const float* b = p2 + (size_t)pair * P.mcap * 2;
@@ -1582,7 +1585,7 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
         HIPCHK(ctx, hipFuncSetAttribute((const void*)k_ransac_hyp_list, hipFuncAttributeMaxDynamicSharedMemorySize, HYP_LDS_BYTES));
         ctx->pose_attr_set = true;
     }
-    hipLaunchKernelGGL(k_pose_prep, dim3(npairs), dim3(256), 0, st, P, d_p1, d_p2, d_npts, d_n1, d_n2, d_samples, d_rstate);
+    hipLaunchKernelGGL(k_pose_prep, dim3(npairs), dim3(256), 0, st, P, d_p1, d_p2, d_npts, d_n1, d_n2, d_samples, d_rstate, do_ransac ? d_worklist : (int32_t*)nullptr);
     if (do_ransac) {
         // per chunk of hypotheses: (A) minimal solver up to the degree-10 polynomial, four lanes per hypothesis, 14.5 KB LDS per wave;
         // (B) its real roots, 16 lanes per hypothesis; (C) models + inlier counts, 256 threads per 16 hypotheses;
@@ -1603,7 +1606,6 @@ int pose_run(vis_ctx* ctx, int npairs, int mcap, int max_iters, const float* d_p
         // With the adaptive stop off every pair needs every hypothesis: no first chunk, the first scan (hi = 0) only builds the work list.
         const int first = ctx->p.ransac_adaptive ? std::min(first_chunk, std::max(max_iters, 1)) : 0;
         const size_t S = (size_t)npairs * max_iters;
-        HIPCHK(ctx, hipMemsetAsync(d_worklist, 0, sizeof(int32_t), st));
         if (first > 0) {
             hipLaunchKernelGGL(k_ransac_hyp, dim3((first + QH - 1) / QH, npairs), dim3(64), HYP_LDS_BYTES, st, P, 0, first, npairs, d_n1, d_n2,
                                d_samples, d_rstate, d_hyp, S);
