@@ -513,11 +513,11 @@ def main():
             except Exception as e:
                 legs[name] = {"error": repr(e)}
         q1 = p.copy(); q1.ransac_adaptive = 0
-        guarded("s752_fixed1000", lambda: dict(run_leg(dev, W, H, B, R, q1, vdist.SINGLE_SEED, 4096, 6, 2), pose_kernels=pose_kernels("f1000"),
+        guarded("s752_fixed1000", lambda: dict(run_leg(dev, W, H, B, R, q1, vdist.SINGLE_SEED, 4096, 24, 3), pose_kernels=pose_kernels("f1000"),
                 what="headline step with ransac_adaptive = 0: 1000 five-point hypotheses per frame pair, every candidate E scored on every match"))
-        guarded("s752_parallax", lambda: dict(run_leg(dev, W, H, B, R, p, vdist.SINGLE_SEED, 4096, 20, 3, parallax=True),
+        guarded("s752_parallax", lambda: dict(run_leg(dev, W, H, B, R, p, vdist.SINGLE_SEED, 4096, 60, 3, parallax=True),
                 what="S-752P: two depth layers (1.5x parallax) + independently moving objects; adaptive RANSAC, same parameters as the headline"))
-        guarded("s752_results_d2h", lambda: dict(run_leg(dev, W, H, B, R, p, vdist.SINGLE_SEED, 4096, 20, 3, d2h=True, want_pose=False),
+        guarded("s752_results_d2h", lambda: dict(run_leg(dev, W, H, B, R, p, vdist.SINGLE_SEED, 4096, 60, 3, d2h=True, want_pose=False),
                 what="headline step + D2H of 1024 pose records (192 B), good matches (49 x 16 B) and counts into pinned memory every step, overlapped with the next step"))
         def leg_mispredict():
             """the cost of a WRONG threshold prediction (the headline stream is the most coherent input there is: 0 pairs redone).  Three
@@ -624,14 +624,14 @@ def main():
         q3.nfeatures, q3.nlevels, q3.w_size, q3.h_size = 4000, 4, 1920, 1080
         q3.fy = q3.fx
         q3.ransac_adaptive, q3.ransac_max_iters, q3.pose_input = 0, 2000, 1
-        guarded("config3_s1080", lambda: dict(run_leg(dev, 1920, 1080, 128, 2, q3, 0xE0C00003, 8192, 5, 2), pose_kernels=pose_kernels("c3"),
+        guarded("config3_s1080", lambda: dict(run_leg(dev, 1920, 1080, 128, 2, q3, 0xE0C00003, 8192, 24, 2), pose_kernels=pose_kernels("c3"),
                 what="BASELINE configs[2]: 1920x1080, 4-level pyramid, 4000 kps/frame, 4000x4000 knn both directions, essential RANSAC with a FIXED "
                      "2000 iterations on the un-gridded symmetric matches (pose_input = SYM) + recoverPose; 128 frames per step"))
         q5 = vislam.default_params()
         q5.nfeatures, q5.nlevels, q5.w_size, q5.h_size = 8000, 8, 3840, 2160
         q5.fy = q5.fx
         def leg5():
-            r = run_leg(dev, 3840, 2160, 32, 2, q5, 0xE0C00005, 8192, 5, 2)
+            r = run_leg(dev, 3840, 2160, 32, 2, q5, 0xE0C00005, 8192, 40, 2)
             n5 = 8000
             kn = r["kernels_ms_per_step"]["ms_knn"]
             r["matcher"] = {"pairs_per_distance_matrix": n5 * n5, "valu_lane_ops_per_matrix": 16 * n5 * n5,
