@@ -528,6 +528,7 @@ extern "C" int vis_estimate_pose_features(vis_ctx* ctx, const vis_align_params* 
     }
     vis_se3f* d_init = nullptr;
     if (init) { d_init = cv.take<vis_se3f>(1); hs.up(d_init, init, sizeof(vis_se3f)); }
+    hs.flush_ups();
     vis_align_result* d_out = cv.take<vis_align_result>(1);
     G.init = d_init; G.out = d_out; G.f1_off = 0; G.f2_off = 0; G.out_off = 0;
     hipLaunchKernelGGL(k_align<false>, dim3(1), dim3(AL_THREADS), 0, st, G);

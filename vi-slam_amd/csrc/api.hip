@@ -445,10 +445,11 @@ int vis_ensure_pin(vis_ctx* ctx, size_t bytes) {
     if (ctx->h_pin_bytes >= bytes) return VIS_OK;
     (void)hipStreamSynchronize(ctx->stream);                       // nothing queued may still use the old block
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
-    ctx->h_pin = nullptr; ctx->h_pin_bytes = 0;
+    ctx->h_pin = nullptr; ctx->h_pin_bytes = 0; ctx->h_pin_dev = nullptr;
     const size_t want = std::max(bytes + bytes / 4, (size_t)1 << 20);
     if (hipHostMalloc(&ctx->h_pin, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->err = "hipHostMalloc of the staging block failed"; return VIS_E_NOMEM; }
     ctx->h_pin_bytes = want;
+    if (hipHostGetDevicePointer(&ctx->h_pin_dev, ctx->h_pin, 0) != hipSuccess) { (void)hipGetLastError(); ctx->h_pin_dev = nullptr; }   // (downloads then go through the runtime's copies)
     return VIS_OK;
 }
 // diagnostics: out[0] = kernel launches of this process, out[1] = times a single-frame entry point of this context blocked on the device,
@@ -544,6 +545,7 @@ extern "C" int vis_camera_update(vis_ctx* ctx, const uint8_t* img, int w, int h,
     for (int l = 0; l < 5; l++) d[l] = cv.take<uint8_t>(lvl_bytes[l]);
     HostStage hs(ctx);
     hs.up2d(d[0], w, img, stride, w, h);
+    hs.flush_ups();
     rc = launch_half_pyramid(ctx, d[0], w, h, w, d);
     if (rc) return rc;
     const void* got[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -590,6 +592,7 @@ extern "C" int vis_compute_gradient(vis_ctx* ctx, const uint8_t* img, int w, int
     if (rc) return rc;
     HostStage hs(ctx);
     hs.up2d(d_img, ws, img, stride, w, h);
+    hs.flush_ups();
     rc = vis_gradient_batch(ctx, d_img, w, h, ws, 1, scale, d_gray, d_gx, d_gy, d_g);
     if (rc) return rc;
     int lw[5], lh[5]; vis_half_dims(w, h, lw, lh);
@@ -626,6 +629,7 @@ extern "C" int vis_patch_points(vis_ctx* ctx, const vis_keypoint* good, int n, i
     if (rc) return rc;
     HostStage hs(ctx);
     hs.up(d_good, good, (size_t)m * sizeof(vis_keypoint));
+    hs.flush_ups();
     rc = launch_patch_points(ctx, d_good, m, ctx->p.w_size, ctx->p.h_size, d_patch, d_debug, cap, d_cnt);
     if (rc) return rc;
     // counts and both point lists of all five levels behind the kernels (list lengths are not known before the wait: the caller's
@@ -678,6 +682,7 @@ extern "C" int vis_orb_detect_compute(vis_ctx* ctx, const uint8_t* img, int w, i
     std::memset(&ctx->tm, 0, sizeof(ctx->tm));
     HostStage hs(ctx);
     hs.up2d(pl->d_stage, pl->stride, img, stride, w, h);
+    hs.flush_ups();
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[0], ctx->stream);
     rc = launch_detect(ctx, pl, pl->d_stage, 1, frame_slot);
     if (rc) return rc;
@@ -773,6 +778,7 @@ extern "C" int vis_bf_knn2_hamming_host(vis_ctx* ctx, const uint8_t* desc_q, int
     hs.up(tp.d_desc, desc_q, (size_t)n_q * 32);
     hs.up(tp.d_desc + (size_t)kcap * 32, desc_t, (size_t)n_t * 32);
     hs.up(tp.d_nkp, nk, 8);
+    hs.flush_ups();
     hipLaunchKernelGGL(k_set_pair, dim3(1), dim3(1), 0, ctx->stream, tp.d_pair_q, tp.d_pair_t, 0, 1);
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[4], ctx->stream);
     rc = launch_expand(ctx, &tp, 0, 2);
@@ -881,11 +887,13 @@ extern "C" int vis_good_matches_host(vis_ctx* ctx, const vis_keypoint* kps1, int
     hs.up(tp.d_kps, kps1, (size_t)n1 * sizeof(vis_keypoint));
     hs.up(tp.d_kps + kcap, kps2, (size_t)n2 * sizeof(vis_keypoint));
     hs.up(tp.d_nkp, nk, 8);
+    hs.flush_ups();
     hipLaunchKernelGGL(k_set_pair, dim3(1), dim3(1), 0, ctx->stream, tp.d_pair_q, tp.d_pair_t, 0, 1);
     hs.up(tp.d_knn12, k12.data(), k12.size() * 4);
     hs.up(tp.d_knn21, k21.data(), k21.size() * 4);
     hs.up(tp.d_hf, hf.data(), (size_t)root * 4);
     hs.up(tp.d_wf, wf.data(), (size_t)root * 4);
+    hs.flush_ups();
     rc = launch_filter(ctx, &tp, 1);
     if (rc) { (void)hipStreamSynchronize(ctx->stream); tp = Plan(); return rc; }
     const MatchFetch f = fetch_matches(hs, &tp, 0, good != nullptr, cap, sym_out != nullptr, sym_cap);
@@ -926,6 +934,7 @@ static int pose_host(vis_ctx* ctx, const float* p1xy, const float* p2xy, int m, 
     const int32_t mm = m;
     hs.up(d_npts, &mm, 4);
     if (E_in) hs.up(d_E, E_in, 72);
+    hs.flush_ups();
     rc = vis_build_sample_table(ctx, std::min(m, 64));
     if (rc) return rc;
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[6], ctx->stream);

@@ -162,7 +162,7 @@ struct vis_ctx {
     void* d_scratch = nullptr; size_t scratch_bytes = 0;
     // grow-only PINNED host block of the single-frame entry points: a caller's pageable buffer is copied through it, so that every
     // upload / download of a call is an asynchronous copy on the context's stream and the call blocks ONCE, at its end (HostStage, api.hip)
-    void* h_pin = nullptr; size_t h_pin_bytes = 0;
+    void* h_pin = nullptr; size_t h_pin_bytes = 0; void* h_pin_dev = nullptr;   // (h_pin_dev: the block's device address; nullptr = not device-accessible)
     // diagnostics of the single-frame path (vis_debug_counters): times the host blocked on the device / copies queued since the context was made
     unsigned long long n_host_waits = 0, n_copies = 0;
     int slot_valid[VIS_NSLOTS];
@@ -203,6 +203,7 @@ int vis_ensure_scratch(vis_ctx* ctx, size_t bytes);
 #include <cstring>
 #include <algorithm>
 int vis_ensure_pin(vis_ctx* ctx, size_t bytes);
+int launch_copy_jobs(vis_ctx* ctx, hipStream_t st, int njobs, void* const* dst, const void* const* src, const size_t* bytes);
 struct HostStage {
     vis_ctx* ctx; char* base; size_t off = 0; hipError_t err = hipSuccess; bool overflow = false;
     explicit HostStage(vis_ctx* c) : ctx(c), base((char*)c->h_pin) {}
@@ -211,12 +212,28 @@ struct HostStage {
         if (off + bytes > ctx->h_pin_bytes) { overflow = true; return nullptr; }
         void* p = base + off; off += bytes; return p;
     }
-    // host (pageable) -> device, asynchronous: through the pinned block
+    // host (pageable) -> device, asynchronous: through the pinned block.  Dword-granular uploads are collected like the downloads and
+    // read out of the block by one kernel of the library per six of them -- at flush_ups(), which every entry point calls behind its
+    // last upload, in front of its first kernel (down() and wait() flush too, so a forgotten call shows as a wrong result in the parity
+    // tests, not as a missing transfer).
+    void* up_dst[6]; const void* up_src[6]; size_t up_bytes[6]; int up_n = 0;
+    void flush_ups() {
+        if (!up_n) return;
+        if (launch_copy_jobs(ctx, ctx->stream, up_n, up_dst, up_src, up_bytes) != VIS_OK && err == hipSuccess) err = hipErrorLaunchFailure;
+        ctx->n_copies++;
+        up_n = 0;
+    }
     void up(void* d, const void* h, size_t bytes) {
         if (!bytes) return;
         void* p = take(bytes);
         if (!p) return;
         std::memcpy(p, h, bytes);
+        if (!(bytes & 3) && !((uintptr_t)d & 3) && ctx->h_pin_dev) {
+            if (up_n == 6) flush_ups();
+            up_dst[up_n] = d; up_src[up_n] = (const char*)ctx->h_pin_dev + ((char*)p - base); up_bytes[up_n] = bytes; up_n++;
+            return;
+        }
+        flush_ups();                                               // (stream order among the uploads)
         const hipError_t e = hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess && err == hipSuccess) err = e;
         ctx->n_copies++;
@@ -226,14 +243,35 @@ struct HostStage {
         char* p = (char*)take(width * height);
         if (!p) return;
         for (size_t y = 0; y < height; y++) std::memcpy(p + y * width, (const char*)h + y * hpitch, width);
+        if (dpitch == width && !((width * height) & 3) && !((uintptr_t)d & 3) && ctx->h_pin_dev) {      // dense on the device: one copy job
+            if (up_n == 6) flush_ups();
+            up_dst[up_n] = d; up_src[up_n] = (const char*)ctx->h_pin_dev + (p - base); up_bytes[up_n] = width * height; up_n++;
+            return;
+        }
+        flush_ups();
         const hipError_t e = hipMemcpy2DAsync(d, dpitch, p, width, width, height, hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess && err == hipSuccess) err = e;
         ctx->n_copies++;
     }
-    // device -> the pinned block, asynchronous; valid after wait()
+    // device -> the pinned block, asynchronous; valid after wait().  Dword-granular downloads are collected and written by ONE kernel of
+    // the library per six of them (launch_copy_jobs; the block is device-accessible) when wait() is called -- every call site requests
+    // its downloads right in front of its wait(), behind the kernels that produce them -- instead of one runtime copy each.
+    void* dn_dst[6]; const void* dn_src[6]; size_t dn_bytes[6]; int dn_n = 0;
+    void flush_downs() {
+        if (!dn_n) return;
+        if (launch_copy_jobs(ctx, ctx->stream, dn_n, dn_dst, dn_src, dn_bytes) != VIS_OK && err == hipSuccess) err = hipErrorLaunchFailure;
+        ctx->n_copies++;
+        dn_n = 0;
+    }
     void* down(const void* d, size_t bytes) {
+        flush_ups();
         void* p = take(std::max(bytes, (size_t)4));
         if (!p || !bytes) return p;
+        if (!(bytes & 3) && !((uintptr_t)d & 3) && ctx->h_pin_dev) {
+            if (dn_n == 6) flush_downs();
+            dn_dst[dn_n] = (char*)ctx->h_pin_dev + ((char*)p - base); dn_src[dn_n] = d; dn_bytes[dn_n] = bytes; dn_n++;
+            return p;
+        }
         const hipError_t e = hipMemcpyAsync(p, d, bytes, hipMemcpyDeviceToHost, ctx->stream);
         if (e != hipSuccess && err == hipSuccess) err = e;
         ctx->n_copies++;
@@ -242,6 +280,7 @@ struct HostStage {
     // the one place a single-frame entry point blocks
     int wait() {
         if (overflow) { ctx->err = "host staging block too small (internal)"; return VIS_E_NOMEM; }
+        flush_ups(); flush_downs();
         if (err != hipSuccess) { ctx->err = std::string("staged copy: ") + hipGetErrorString(err); return VIS_E_HIP; }
         ctx->n_host_waits++;
         const hipError_t e = hipStreamSynchronize(ctx->stream);
