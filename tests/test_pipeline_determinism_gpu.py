@@ -191,3 +191,28 @@ def test_detect_chain_running_ahead_of_a_slow_matcher(vislam, canvas):
         assert got[2][t, :ref[1][t]].tobytes() == ref[2][t, :ref[1][t]].tobytes(), t
     assert got[3][0].tobytes() == ref[3][0].tobytes() and got[3][1].tobytes() == ref[3][1].tobytes()
     assert (ref[0]["n_points"][1:] > 5).all()
+
+
+def test_results_download_pinned_kernel_path_equals_runtime_copy_path(vislam, canvas):
+    """vis_batch_results_async writes pinned (device-accessible) destinations with one kernel of the library and everything else with
+    hipMemcpyAsync: the same batch through both must give the same bytes (pose records, counts, the dense part of the match rows)."""
+    import torch
+    n = 48
+    frames = np.stack([vislam.synth_frame(canvas, t, W, H, parallax=True) for t in range(n)])
+    dev = torch.from_numpy(frames).cuda()
+    p = vislam.default_params(); p.fy = p.fx
+    c = vislam.Context(0, p); c.batch_plan(W, H, W, n)
+    root2 = 49
+    c.batch_run(dev.data_ptr(), n)
+    hp = torch.zeros(n * C.sizeof(vislam.PoseResult), dtype=torch.uint8).pin_memory()
+    hg = torch.zeros(n * root2 * 16, dtype=torch.uint8).pin_memory()
+    hn = torch.zeros(n, dtype=torch.int32).pin_memory()
+    c.batch_results_async(n, hp.data_ptr(), hg.data_ptr(), hn.data_ptr())          # pinned: the kernel path
+    c.batch_sync()
+    pose, good, ng = c.batch_results(n)                                             # pageable numpy arrays: the runtime's copies
+    c.close()
+    assert hp.numpy().tobytes() == pose.tobytes() and hn.numpy().tobytes() == ng.tobytes()
+    g1 = np.frombuffer(hg.numpy().tobytes(), vislam.DMATCH_DTYPE).reshape(n, root2)
+    for t in range(n):
+        assert g1[t, :ng[t]].tobytes() == good[t, :ng[t]].tobytes(), t
+    assert (ng[1:] > 5).all()
