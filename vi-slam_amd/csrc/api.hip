@@ -632,20 +632,28 @@ extern "C" int vis_patch_points(vis_ctx* ctx, const vis_keypoint* good, int n, i
     hs.flush_ups();
     rc = launch_patch_points(ctx, d_good, m, ctx->p.w_size, ctx->p.h_size, d_patch, d_debug, cap, d_cnt);
     if (rc) return rc;
-    // counts and both point lists of all five levels behind the kernels (list lengths are not known before the wait: the caller's
-    // capacity is fetched; the builders emit at most 200 keypoints x patch^2 points)
+    // counts and both point lists of all five levels behind the kernels.  The list lengths are not known before the wait, but their
+    // bounds are: min(m, 200) keypoints x at most (2 sp + 2)^2 points of a level's window (sp = 5, 3, 2, 5, 5: k_patch_points) and one
+    // debug point per keypoint -- that much of every level is fetched, not the caller's whole capacity (200 x 121 x 16 B x 5 levels x 2
+    // lists = 3.9 MB per call for 49 good matches; the GPU main calls this twice per frame)
     const int32_t* cnt = (const int32_t*)hs.down(d_cnt, 40);
-    const float* h_patch = cap ? (const float*)hs.down(d_patch, (size_t)5 * cap * 16) : nullptr;
-    const float* h_debug = cap ? (const float*)hs.down(d_debug, (size_t)5 * cap * 16) : nullptr;
+    const float* h_patch[5]; const float* h_debug[5]; int bp[5], bd[5];
+    const int mk = std::min(m, 200);
+    for (int l = 0; l < 5; l++) {
+        const int sp = l == 1 ? 3 : (l == 2 ? 2 : 5);
+        bp[l] = (int)std::min<long long>(cap, (long long)mk * (2 * sp + 2) * (2 * sp + 2)); bd[l] = std::min(cap, mk);
+        h_patch[l] = bp[l] ? (const float*)hs.down(d_patch + (size_t)l * cap * 4, (size_t)bp[l] * 16) : nullptr;
+        h_debug[l] = bd[l] ? (const float*)hs.down(d_debug + (size_t)l * cap * 4, (size_t)bd[l] * 16) : nullptr;
+    }
     rc = hs.wait();
     if (rc) return rc;
     bool over = false;
     for (int l = 0; l < 5; l++) {
         n_patch[l] = cnt[l]; n_debug[l] = cnt[5 + l];
         over = over || cnt[l] > cap || cnt[5 + l] > cap;
-        const int np = std::min(cnt[l], cap), nd = std::min(cnt[5 + l], cap);
-        if (patch[l] && np) std::memcpy(patch[l], h_patch + (size_t)l * cap * 4, (size_t)np * 16);
-        if (debug[l] && nd) std::memcpy(debug[l], h_debug + (size_t)l * cap * 4, (size_t)nd * 16);
+        const int np = std::min(cnt[l], bp[l]), nd = std::min(cnt[5 + l], bd[l]);         // (the bounds hold by construction; never read past what was fetched)
+        if (patch[l] && np) std::memcpy(patch[l], h_patch[l], (size_t)np * 16);
+        if (debug[l] && nd) std::memcpy(debug[l], h_debug[l], (size_t)nd * 16);
     }
     return over ? VIS_E_CAPACITY : VIS_OK;
 }
