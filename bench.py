@@ -113,6 +113,60 @@ class Stream:
         return self.frames[:n].cpu().numpy()
 
 
+class ClockSampler:
+    """shader clock / memory clock / package power of ONE device, sampled from sysfs by a side thread WHILE the timed region runs
+    (the HBM-bound stages have two bandwidth states from lease to lease; the record now says which clocks a run saw).
+    sysfs (pp_dpm_sclk / pp_dpm_mclk: the level marked '*'; hwmon power1_average or power1_input in microwatts) costs a few file reads
+    per sample; no subprocess, no HIP call.  Missing files give nulls, never an exception."""
+
+    def __init__(self, pci_bus_id, period_s=0.05):
+        import threading
+        self.base = f"/sys/bus/pci/devices/{(pci_bus_id or '').lower()}"
+        self.period = period_s
+        self.samples = []
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _level(path):
+        try:
+            for line in open(path):
+                if "*" in line:
+                    return float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except Exception:
+            pass
+        return None
+
+    def _power(self):
+        import glob
+        for pat in ("hwmon/hwmon*/power1_average", "hwmon/hwmon*/power1_input"):
+            for f in glob.glob(os.path.join(self.base, pat)):
+                try:
+                    return float(open(f).read()) / 1e6
+                except Exception:
+                    continue
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            self.samples.append((self._level(os.path.join(self.base, "pp_dpm_sclk")), self._level(os.path.join(self.base, "pp_dpm_mclk")), self._power()))
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._th.join(timeout=2)
+
+    def summary(self):
+        med = lambda v: float(np.median(v)) if v else None                       # noqa: E731
+        cols = [[x[i] for x in self.samples if x[i] is not None] for i in range(3)]
+        return {"sclk_mhz": med(cols[0]), "mclk_mhz": med(cols[1]), "watts": med(cols[2]), "samples": len(self.samples),
+                "source": f"sysfs {self.base} (median over the timed region)"}
+
+
 def timed_steps(ctx, stream, B, R, stages, steps, warmup, dist=None, dev=None, after_step=None, q=1):
     """a step = q consecutive launches of the pipeline over q * B consecutive frames of the stream (q = 1 for the legs)"""
     def step(i):
@@ -182,35 +236,69 @@ def kernel_rooflines(fam, launches_fast, px, nfeat, B, nlevels):
 MFMA_FP4_PEAK_PFLOPS = 10.0      # MI355X_MICROARCH.md "Matrix cores": FP6/FP4 dense ~10 PFLOP/s (the 20 PF headline figure includes 2:1 sparsity)
 
 
-def matcher_roofline(ms_knn, n_desc, pairs, pmc_path=None):
+def matcher_roofline(ms_knn, n_desc, pairs, counters="headline", pmc_path=None):
     """north_star: 'L2-hit / VALU utilisation for the matcher against the chip's roofline'.  The matcher is k_expand + k_knn_mfma
     (v_mfma_scale_f32_32x32x64_f8f6f4 on FP4 +-1 operands, exact).  Per frame pair the kernel computes TWO n x n distance matrices
     (query->train and its transpose: the grid has a direction dimension, each direction keeps the row-wise top-2 of its own matrix),
     256 multiply-accumulates per distance.  `achieved` = those MACs x 2 FLOP / ms_knn of THIS run (HIP events, k_expand included);
-    busy / hit fractions come from the committed counter passes (profiles/pmc_traffic.json, other run, same kernels)."""
+    busy / hit / traffic figures come from the committed counter passes of the SAME workload (profiles/pmc_traffic.json: the headline
+    set at the top level, the other configurations under legs.<name>, each stamped with its descriptors per frame) -- a set taken on
+    another workload is never quoted: the fields are null and `counters_from` says why."""
     if not ms_knn or ms_knn <= 0:
         return None
     macs = 2.0 * n_desc * n_desc * 256 * pairs
     pf = macs * 2 / (ms_knn * 1e-3) / 1e15
     out = {"bound": "mfma-fp4", "kernel": "k_expand + k_knn_mfma", "achieved_PFLOPs": pf, "achieved_PMACs": pf / 2, "peak": MFMA_FP4_PEAK_PFLOPS, "unit": "PFLOP/s",
            "frac": pf / MFMA_FP4_PEAK_PFLOPS, "ms_knn": ms_knn, "descriptors_per_frame": n_desc, "pairs_per_step": pairs,
-           "distance_matrices_per_pair": 2, "macs_per_step": macs, "mfma_busy_frac": None, "l2_hit": None}
+           "distance_matrices_per_pair": 2, "macs_per_step": macs, "mfma_busy_frac": None, "l2_hit": None, "traffic_over_algorithmic": None}
     try:
-        raw = json.load(open(pmc_path or os.path.join(ROOT, "profiles", "pmc_traffic.json")))["raw"]["k_knn_mfma"]
+        pj = json.load(open(pmc_path or os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        cs = pj if counters == "headline" else (pj.get("legs") or {}).get(counters)
+        if cs is None:
+            out["counters_from"] = f"not measured for this workload (profiles/pmc_traffic.json has no legs.{counters})"
+            return out
+        if int(cs.get("n_desc", 1000 if counters == "headline" else -1)) != int(n_desc):
+            out["counters_from"] = f"not measured for this workload (the committed set is for {cs.get('n_desc')} descriptors per frame, this leg has {n_desc})"
+            return out
+        raw = cs["raw"]["k_knn_mfma"]
         hit, miss = raw["TCC_HIT_sum"]["mean"], raw["TCC_MISS_sum"]["mean"]
         out["l2_hit"] = hit / (hit + miss)
         # SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD; GRBM_GUI_ACTIVE is summed over the 8 XCDs: cycles x 1024 SIMDs
         out["mfma_busy_frac"] = raw["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (raw["GRBM_GUI_ACTIVE"]["mean"] / 8 * 1024)
-        out["counters_from"] = "profiles/pmc_traffic.json raw.k_knn_mfma (TCC_HIT_sum, TCC_MISS_sum, SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE; 512 frames per launch)"
+        out["counters_from"] = (f"profiles/pmc_traffic.json {'top level' if counters == 'headline' else 'legs.' + counters} raw.k_knn_mfma (TCC_HIT_sum, TCC_MISS_sum, "
+                                f"SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE; {cs['batch_frames']} frames of {n_desc} descriptors per launch, commit {cs.get('measured_at_commit')})")
         # HBM traffic of k_knn_mfma against what it must read: the expanded descriptors (128 B each) of both frames of every pair
-        pj = json.load(open(pmc_path or os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        alg_b = 2.0 * n_desc * 128 * pj["batch_frames"]
-        out["hbm_traffic_bytes_per_launch_at_pmc_batch"] = pj["k_knn_mfma"]["hbm_bytes_per_launch"]
+        alg_b = 2.0 * n_desc * 128 * cs["batch_frames"]
+        out["hbm_traffic_bytes_per_launch_at_pmc_batch"] = cs["k_knn_mfma"]["hbm_bytes_per_launch"]
         out["algorithmic_bytes_per_launch_at_pmc_batch"] = alg_b
-        out["traffic_over_algorithmic"] = pj["k_knn_mfma"]["hbm_bytes_per_launch"] / alg_b
+        out["traffic_over_algorithmic"] = cs["k_knn_mfma"]["hbm_bytes_per_launch"] / alg_b
     except Exception as e:
         out["counters_error"] = repr(e)
     return out
+
+
+def leg_detect_counters(label, leg, B):
+    """counter figures of a side leg's OWN workload (profiles/pmc_traffic.json legs.<label>, written by tools/final_profile.sh from counter
+    passes at that leg's image size and keypoint count): HBM traffic against the algorithmic bytes of SURVEY 8(d) per detect/describe kernel."""
+    try:
+        cs = (json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("legs") or {}).get(label)
+        if cs is None:
+            return {"counters_from": f"not measured for this workload (no legs.{label} in profiles/pmc_traffic.json)"}
+        out = {"counters_from": f"profiles/pmc_traffic.json legs.{label} ({cs['batch_frames']} frames per launch, commit {cs.get('measured_at_commit')})"}
+        for k in ("k_fast", "k_resize", "k_describe", "k_select"):
+            if k not in cs:
+                continue
+            calls = cs["raw"][k]["FETCH_SIZE"]["calls"] / max(1, cs.get("steps_counted", 1))          # launches of the family per step
+            hbm = cs[k]["hbm_bytes_per_launch"] * calls                                             # per step of batch_frames frames
+            d = {"hbm_traffic_bytes_per_frame": hbm / cs["batch_frames"], "lds_busy_frac": cs[k].get("lds_busy_frac"),
+                 "valu_wave_insts_per_frame": (cs[k].get("valu_wave_insts_per_launch") or 0) * calls / cs["batch_frames"]}
+            ab = ((leg.get("kernels") or {}).get(k) or {}).get("algorithmic_bytes_per_frame")
+            if ab:
+                d["traffic_over_algorithmic"] = d["hbm_traffic_bytes_per_frame"] / ab
+            out[k] = d
+        return out
+    except Exception as e:
+        return {"counters_error": repr(e)}
 
 
 def run_leg(dev, w, h, B, R, params, seed, canvas_dim, steps, warmup, stages=None, parallax=False, want_pose=True, d2h=False):
@@ -314,7 +402,7 @@ def cpu_baseline(p, frames, budget_s, what):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port", "sample_short": f"{n} S-752 frames, oracle pipeline_frame, g++ -O2, 1 thread",
             "sample": f"{n} consecutive S-752 frames ({what}), oracle pipeline_frame: Camera::Update + ORB + knn x2 + filters + essential RANSAC + "
                       f"recoverPose, g++ -O2, 1 thread; host has {os.cpu_count()} logical CPUs"}
 
@@ -335,6 +423,8 @@ def main():
                          "two ranks on one device).  The line says so (\"rehearsal\") and is not a scaling measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the side legs (profiling runs)")
+    ap.add_argument("--full-out", default=None, help="where the FULL record (legs, counter tables, prose) is written; default gpurun_out/bench_full.json. stdout carries "
+                                                     "only the compact line (benchline.py)")
     ap.add_argument("--stages", type=int, default=vislam.STAGE_FRAME, help="debug: bitmask of stages (1 detect, 2 match, 4 pose, 8 Camera::Update); the reported metric needs all 15")
     a = ap.parse_args()
 
@@ -367,7 +457,9 @@ def main():
     seed = vdist.stream_seed(rank, world)
     stream = Stream(ctx, dev, W, H, B * Q * R, seed)      # generated on the device: no host synthesis, no H2D
     ctx.batch_plan(W, H, W, B)
-    dt, step_q = timed_steps(ctx, stream, B, R, a.stages, a.steps, a.warmup, dist, dev, q=Q)
+    clocks = ClockSampler(vislam.device_pci_bus_id(local_rank if world > 1 else 0))
+    with clocks:
+        dt, step_q = timed_steps(ctx, stream, B, R, a.stages, a.steps, a.warmup, dist, dev, q=Q)
     dt_rank = dt
     dt = vdist.max_over_ranks(dt, dist, ddev)
     # who ran where: one all_gather of a small POD per rank behind the timed region (N ranks must sit on N different devices)
@@ -597,7 +689,10 @@ def main():
                                "(knn both directions + filters) + vis_essential_ransac + vis_recover_pose, 752x480 / N = 1000, 200 consecutive S-752 frames; every "
                                "call returns its results to the host.  Includes the ctypes / numpy wrapper (result arrays are allocated per call).  A 20 Hz camera "
                                "leaves 50 ms per frame; the CPU oracle needs 1000 / cpu_baseline.value ms",
-                       "frames": n, "ms_per_frame_p50": pct(tot, 50), "ms_per_frame_p95": pct(tot, 95), "ms_per_frame_mean": float(np.mean(tot)),
+                       "frames": n, "ms_per_frame_p50": pct(tot, 50), "ms_per_frame_p95": pct(tot, 95), "ms_per_frame_p99": pct(tot, 99),
+                       "ms_per_frame_max": float(np.max(tot)), "slowest_frame_index": int(np.argmax(tot)), "ms_per_frame_mean": float(np.mean(tot)),
+                       "ms_max_per_entry_point": {k: float(np.max(v)) for k, v in per.items()},
+                       "slowest_call_index_per_entry_point": {k: int(np.argmax(v)) for k, v in per.items()},
                        "frames_per_s_one_at_a_time": 1e3 / float(np.mean(tot)),
                        "ms_p50_per_entry_point": {k: pct(v, 50) for k, v in per.items()}, "ms_p95_per_entry_point": {k: pct(v, 95) for k, v in per.items()},
                        "kernel_launches_per_frame": (c1[0] - c0[0]) / n, "host_waits_per_frame": (c1[1] - c0[1]) / n, "async_copies_per_frame": (c1[2] - c0[2]) / n,
@@ -640,7 +735,8 @@ def main():
                             "note": "the kernel computes TWO 8000 x 8000 matrices per pair (query->train and the transposed one, each reduced row-wise to its "
                                     "top-2), as the reference's two knnMatch calls do; the RATE reported here counts one matrix per pair, the unit SURVEY 8(d) "
                                     "prices (16 N1 N2 xor+popcount lane-ops); computed on the FP4 matrix cores (e2m1 +-1, exact)"}
-            r["matcher_roofline"] = matcher_roofline(kn, n5, 31)
+            r["matcher_roofline"] = matcher_roofline(kn, n5, 31, counters="c5")
+            r["detect_counters"] = leg_detect_counters("c5", r, 32)
             r["what"] = "BASELINE configs[4]: 3840x2160, 8 levels, 8000 kps/frame, 8000x8000 BF-Hamming all-pairs, filters, pose; 32 frames per step"
             return r
         guarded("config5_s2160", leg5)
@@ -732,9 +828,11 @@ def main():
         out = {
             "metric": "frames/sec detect+match+pose, 752x480 mono8", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "clocks": clocks.summary(),
             "ranks": ranks, **({"rehearsal": "N ranks on ONE device over gloo: exercises the N > 1 code path, not a scaling measurement"} if a.rehearse_on_one_gpu else {}),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "S-752: synthetic 752x480 mono8 EuRoC-shaped stream (frames resident in HBM), 1000 ORB kps x 8 levels, BF-Hamming k=2 "
+            "config": {"workload_short": "S-752 synthetic 752x480 mono8 resident in HBM; ORB 1000 kps x 8 levels, knn2 both ways + filters, essential RANSAC + recoverPose",
+                       "workload": "S-752: synthetic 752x480 mono8 EuRoC-shaped stream (frames resident in HBM), 1000 ORB kps x 8 levels, BF-Hamming k=2 "
                                    "both directions + ratio/sym/grid filter, essential RANSAC (adaptive, max 1000) + recoverPose.  S-752 is a planar "
                                    "crop under pure image translation: every grid match is an exact inlier, the adaptive stop ends RANSAC after "
                                    "<= 4 hypotheses (see pose_load) and the recovered pose is degenerate; legs.s752_fixed1000 / legs.s752_parallax load "
@@ -787,7 +885,25 @@ def main():
                 out["cpu_baseline_multicore"] = best
             except Exception as e:
                 out["cpu_baseline_multicore"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+        # the full record goes to a FILE (and nowhere on stdout: BENCH_r05.json could not parse the 23 KB line of round 5); the LAST line of
+        # stdout is the compact strict-JSON line of benchline.py, numbers only, < 1900 bytes
+        full_path = a.full_out
+        if full_path is None:
+            d_ = os.path.join(ROOT, "gpurun_out")
+            try:
+                os.makedirs(d_, exist_ok=True)
+                full_path = os.path.join(d_, "bench_full.json")
+            except OSError:
+                full_path = os.path.join(ROOT, "bench_full.json")
+        try:
+            with open(full_path, "w") as f:
+                json.dump(out, f, indent=1)
+                f.write("\n")
+        except OSError as e:
+            print(f"bench.py: could not write the full record to {full_path}: {e!r}", file=sys.stderr)
+            full_path = None
+        import benchline
+        print(benchline.compact_line(out, os.path.relpath(full_path, ROOT) if full_path else None), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

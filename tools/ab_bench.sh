@@ -6,7 +6,7 @@ for r in $(seq $REPS); do
   for L in $A $B; do
     VISLAM_HIP_LIB=$L timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --steps 60 2>/dev/null | python -c "
 import json,sys
-j=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); k=j['kernels_ms_per_step']
-print('$L'.split('/')[-1].ljust(24), round(j['value']), ' '.join(f'{a[3:]}={b:.3f}' for a,b in k.items()))"
+j=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); k=j['ms']
+print('$L'.split('/')[-1].ljust(24), round(j['value']), ' '.join(f'{a}={b:.3f}' for a,b in k.items()))"
   done
 done

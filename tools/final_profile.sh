@@ -38,7 +38,7 @@ python3 $R/tools/pmc_pose_summarize.py $R/$OUT/pose $COMMIT $R/$OUT/f64_rates.lo
 #    the freshly written pmc_traffic.json / pmc_pose.json go into profiles/ of this box's copy, then the full default bench runs
 cp $R/$OUT/pipe/pmc_traffic.json $R/profiles/pmc_traffic.json
 cp $R/$OUT/pose/pmc_pose.json $R/profiles/pmc_pose.json
-(cd $R && python3 bench.py --steps 20 --warmup 3 > $R/$OUT/bench_full.json 2> $R/$OUT/bench_full.err)
+(cd $R && python3 bench.py --steps 20 --warmup 3 --full-out $R/$OUT/bench_full.json > $R/$OUT/bench_line.json 2> $R/$OUT/bench_full.err)
 # 6. the instruction-rate microbenchmarks of the round
 [ -x $R/vi-slam_amd/lib/dpp_rates ] && $R/vi-slam_amd/lib/dpp_rates > $R/$OUT/dpp_rates.log 2>&1
 # the csv dumps are large: keep the stats summaries, the json summaries and the logs
