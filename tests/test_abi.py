@@ -125,3 +125,12 @@ def test_public_header_is_plain_c(tmp_path):
     for cmd in (["gcc", "-std=c99"], ["g++", "-std=c++11", "-x", "c++"]):
         r = subprocess.run(cmd + ["-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-1500:]
+
+
+def test_staging_block_refusals_on_the_cpu(built):
+    """csrc/vis_internal.h HostStage / vis_ensure_pin: an undersized staging block yields VIS_E_NOMEM (no copy past its end) and a block is
+    never replaced under a live stage (VIS_E_STATE) -- host/stage_selftest.cpp, host code against the product library, no device needed"""
+    import subprocess
+    exe = os.path.join(ROOT, "vi-slam_amd", "lib", "stage_selftest")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "stage_selftest passed" in r.stdout and "FAIL" not in r.stdout, r.stdout + r.stderr

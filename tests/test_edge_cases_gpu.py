@@ -241,3 +241,31 @@ def test_saturated_and_periodic_image_returns_every_tie(vislam, orc, ctx):
     with pytest.raises(vislam.VisError) as ei:
         ctx.orb_detect_compute(img, slot=0, cap=3000)
     assert ei.value.code == -4
+
+
+def test_staging_block_grows_between_calls_of_different_sizes(vislam, orc):
+    """The pinned staging block of the frame-at-a-time entry points is grow-only and is REPLACED when it grows (csrc/api.hip vis_ensure_pin).
+    Small frame, then the largest configured frame, then the small one again, on ONE fresh context, through the three entry points that
+    stage a whole image (vis_camera_update, vis_orb_detect_compute, vis_compute_gradient): every result against the oracle.  Round 5's
+    host SIGSEGV (gpurun_out/r5r_gdb.log) was a stage that kept the address of a block freed by a later growth; run once like any other test."""
+    c = vislam.Context(0)
+    try:
+        cv = vislam.synth_canvas(4096, 0xE0C00005)
+        frames = [vislam.synth_frame(cv, 0, 160, 120, 0xE0C00005), vislam.synth_frame(cv, 1, 3840, 2160, 0xE0C00005), vislam.synth_frame(cv, 2, 160, 120, 0xE0C00005),
+                  vislam.synth_frame(cv, 3, 752, 480, 0xE0C00005)]
+        p = vislam.default_params()
+        p.nfeatures = 500
+        c.set_params(p)
+        for rep in range(2):                                        # second round: the block is already at its largest
+            for img in frames:
+                for l, (a, b) in enumerate(zip(c.camera_update(img), orc.half_pyramid(img))):
+                    assert (a == b).all(), ("camera_update", img.shape, l, rep)
+                k, d = c.orb_detect_compute(img, slot=0)
+                ok, od = orc.orb_detect_compute(p, img)
+                assert k.tobytes() == ok.tobytes() and d.tobytes() == od.tobytes(), ("orb", img.shape, rep)
+                gx, gy, gg = c.compute_gradient(img, 3)
+                for l, lv in enumerate(orc.half_pyramid(img)):
+                    ox, oy, og = orc.scharr_gradient(lv, 3)
+                    assert (gx[l] == ox).all() and (gy[l] == oy).all() and (gg[l] == og).all(), ("gradient", img.shape, l, rep)
+    finally:
+        c.close()

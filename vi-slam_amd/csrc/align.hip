@@ -610,7 +610,13 @@ extern "C" int vis_batch_align(vis_ctx* ctx, const vis_align_params* ap, const u
     ctx->ev_align_done = ctx->ev_align_done2[ctx->align_k];                           // (two events in turn: the one before stays valid for the set it guards)
     HIPCHK(ctx, hipEventRecord(ctx->ev_align_done, sP));
     ctx->align_pending = true;
-    if (plan_set) pl->grad_reader[pl->grad_set] = ctx->ev_align_done;                 // the side stream refills this set two steps on
+    // the side stream refills a gradient set two steps on: it waits for the last alignment that read THAT set.  Decided by pointer
+    // identity, not by how the caller got the pointers: the ones vis_batch_gradients() / vis_batch_half_pyramid() hand out are the
+    // plan's sets too (valid until the next vis_batch_run), and a caller passing them explicitly needs the same ordering
+    (void)plan_set;
+    for (int s_ = 0; s_ < 2; s_++)
+        if ((pl->d_half_set[s_] && d_gray == pl->d_half_set[s_]) || (pl->d_gx_set[s_] && d_gx == pl->d_gx_set[s_]) || (pl->d_gy_set[s_] && d_gy == pl->d_gy_set[s_]))
+            pl->grad_reader[s_] = ctx->ev_align_done;
     pl->mo_align[pl->last_cur] = ctx->ev_align_done;                                 // it read the matched points of the last step's matcher-output set
     return VIS_OK;
 }

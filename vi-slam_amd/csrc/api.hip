@@ -443,6 +443,7 @@ std::atomic<unsigned long long> vis_g_launches{0};
 // once (twice when a result decides what else to fetch).
 int vis_ensure_pin(vis_ctx* ctx, size_t bytes) {
     if (ctx->h_pin_bytes >= bytes) return VIS_OK;
+    if (ctx->stage_live > 0) { ctx->err = "staging block would be replaced under a live HostStage (internal: size the block before building the stage)"; return VIS_E_STATE; }
     (void)hipStreamSynchronize(ctx->stream);                       // nothing queued may still use the old block
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     ctx->h_pin = nullptr; ctx->h_pin_bytes = 0; ctx->h_pin_dev = nullptr;
@@ -1095,9 +1096,15 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
     bool update_queued = false;
     if (stages & (VIS_STAGE_UPDATE | VIS_STAGE_GRADIENT)) {
         VisRange r_("vis: Camera::Update half pyramid");
-        const int gs = (pl->grad_set ^= 1);                            // this step's half pyramid / gradient set
-        if (!pl->d_half_set[gs]) HIPCHK(ctx, hipMalloc((void**)&pl->d_half_set[gs], (size_t)pl->B * vis_grad_frame_elems(pl->w, pl->h)));
-        pl->d_half = pl->d_half_set[gs];
+        // this step's half pyramid / gradient set: the one the step before last used.  The plan's view of it (grad_set, d_half ... d_g) is
+        // switched only once every launch of the stage has been queued; a failure leaves the last step's set and pointers in place
+        const int gs = pl->grad_set ^ 1;
+        const size_t fe = vis_grad_frame_elems(pl->w, pl->h);
+        if (!pl->d_half_set[gs]) HIPCHK(ctx, hipMalloc((void**)&pl->d_half_set[gs], (size_t)pl->B * fe));
+        if ((stages & VIS_STAGE_GRADIENT) && !pl->d_gx_set[gs]) {
+            HIPCHK(ctx, hipMalloc((void**)&pl->d_gx_set[gs], (size_t)pl->B * fe * 2)); HIPCHK(ctx, hipMalloc((void**)&pl->d_gy_set[gs], (size_t)pl->B * fe * 2));
+            HIPCHK(ctx, hipMalloc((void**)&pl->d_g_set[gs], (size_t)pl->B * fe));
+        }
         // the frames were produced on the detect stream (or before the call): the side stream is ordered behind it -- behind the
         // PYRAMID launches of this batch's detect chain (launch_detect recorded the event there): the resize chain streams at HBM
         // speed itself, the kernels after it are vector-ALU bound, and that is where streaming work fits beside them
@@ -1107,23 +1114,19 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
         if (pl->grad_reader[gs]) HIPCHK(ctx, hipStreamWaitEvent(sU, pl->grad_reader[gs], 0));
         if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[10], sU);
         ctx->stream = sU;
-        rc = launch_half_pyramid_batch(ctx, d_frames, pl->w, pl->h, pl->stride, (size_t)pl->stride * pl->h, n, pl->d_half);
+        rc = launch_half_pyramid_batch(ctx, d_frames, pl->w, pl->h, pl->stride, (size_t)pl->stride * pl->h, n, pl->d_half_set[gs]);
+        if (!rc && (stages & VIS_STAGE_GRADIENT))
+            rc = launch_gradient(ctx, d_frames, pl->w, pl->h, pl->stride, (size_t)pl->stride * pl->h, n, pl->d_half_set[gs], 3 /* the reference's Scharr scale, src/Camera.cpp:172 */,
+                                 pl->d_gx_set[gs], pl->d_gy_set[gs], pl->d_g_set[gs]);
         ctx->stream = sA;
-        if (!rc && (stages & VIS_STAGE_GRADIENT)) {
-            const size_t fe = vis_grad_frame_elems(pl->w, pl->h);
-            if (!pl->d_gx_set[gs]) { HIPCHK(ctx, hipMalloc((void**)&pl->d_gx_set[gs], (size_t)pl->B * fe * 2)); HIPCHK(ctx, hipMalloc((void**)&pl->d_gy_set[gs], (size_t)pl->B * fe * 2)); HIPCHK(ctx, hipMalloc((void**)&pl->d_g_set[gs], (size_t)pl->B * fe)); }
-            pl->d_gx = pl->d_gx_set[gs]; pl->d_gy = pl->d_gy_set[gs]; pl->d_g = pl->d_g_set[gs];
-            ctx->stream = sU;
-            rc = launch_gradient(ctx, d_frames, pl->w, pl->h, pl->stride, (size_t)pl->stride * pl->h, n, pl->d_half, 3 /* the reference's Scharr scale, src/Camera.cpp:172 */, pl->d_gx, pl->d_gy, pl->d_g);
-            ctx->stream = sA;
-            if (!rc) pl->grad_valid = true;
-        }
         if (rc) {
-            // whatever was queued on the side stream before the failure still reads d_frames / writes the plan's buffers: the detect
-            // stream joins it before this call returns, so "ctx->stream is done" keeps meaning "the batch's buffers are free"
+            // whatever was queued on the side stream before the failure still reads d_frames / writes set gs: the detect stream joins
+            // it before this call returns, so "ctx->stream is done" keeps meaning "the batch's buffers are free"
             if (hipEventRecord(ctx->ev_update_done, sU) == hipSuccess) (void)hipStreamWaitEvent(sA, ctx->ev_update_done, 0);
             return rc;
         }
+        pl->grad_set = gs; pl->d_half = pl->d_half_set[gs];
+        if (stages & VIS_STAGE_GRADIENT) { pl->d_gx = pl->d_gx_set[gs]; pl->d_gy = pl->d_gy_set[gs]; pl->d_g = pl->d_g_set[gs]; pl->grad_valid = true; }
         if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[11], sU);
         HIPCHK(ctx, hipEventRecord(ctx->ev_update_done, sU));
         update_queued = true;
@@ -1174,7 +1177,7 @@ extern "C" int vis_batch_run(vis_ctx* ctx, const uint8_t* d_frames, int n, int s
         if (hipEventRecord(ctx->ev_pose_done_set[mo], sP) == hipSuccess) pl->mo_pose[mo] = ctx->ev_pose_done_set[mo];
     }
     ctx->stream = sA;
-    if (rc) { use_mo(pl->last_cur); return rc; }            // nothing of the stream state (carried frame, record set, matcher-output set) has been committed
+    if (rc) { use_mo(pl->last_cur); pl->half_valid = pl->grad_valid = false; return rc; }   // nothing of the stream state (carried frame, record set, matcher-output set) has been committed
     pl->have_prev = have_prev; pl->pair0_valid = have_prev;
     if (detect) { pl->run_count++; pl->carry_from = base + n; }
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[8], sA);

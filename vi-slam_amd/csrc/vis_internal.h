@@ -163,6 +163,7 @@ struct vis_ctx {
     // grow-only PINNED host block of the single-frame entry points: a caller's pageable buffer is copied through it, so that every
     // upload / download of a call is an asynchronous copy on the context's stream and the call blocks ONCE, at its end (HostStage, api.hip)
     void* h_pin = nullptr; size_t h_pin_bytes = 0; void* h_pin_dev = nullptr;   // (h_pin_dev: the block's device address; nullptr = not device-accessible)
+    int stage_live = 0;                      // HostStage objects alive on this context: vis_ensure_pin refuses to replace the block under one (VIS_E_STATE)
     // diagnostics of the single-frame path (vis_debug_counters): times the host blocked on the device / copies queued since the context was made
     unsigned long long n_host_waits = 0, n_copies = 0;
     int slot_valid[VIS_NSLOTS];
@@ -204,13 +205,23 @@ int vis_ensure_scratch(vis_ctx* ctx, size_t bytes);
 #include <algorithm>
 int vis_ensure_pin(vis_ctx* ctx, size_t bytes);
 int launch_copy_jobs(vis_ctx* ctx, hipStream_t st, int njobs, void* const* dst, const void* const* src, const size_t* bytes);
+// The block may only be replaced (vis_ensure_pin frees and re-allocates it when it grows) while NO HostStage is alive: a stage hands out
+// addresses inside the block (take / down) that the caller reads after wait().  Round 5's host SIGSEGV (gpurun_out/r5r_gdb.log: libc's copy
+// faulting on its first destination byte, 0x7ff600c00000 = 2 MiB-aligned, unmapped, 360 960 bytes = the first up2d of a call, i.e. offset 0 of
+// a block that was no longer there) was a stage built on a block that a later vis_ensure_pin of the same call freed; every entry point sizes
+// the block BEFORE it builds its stage since f950f5e, and since round 6 the rule is enforced instead of kept by convention: the stage reads
+// the block's address from the context at every use, counts itself in ctx->stage_live, and vis_ensure_pin answers VIS_E_STATE instead of
+// freeing a block under a live stage (vi-slam_amd/host/stage_selftest.cpp drives both refusals on the CPU).
 struct HostStage {
-    vis_ctx* ctx; char* base; size_t off = 0; hipError_t err = hipSuccess; bool overflow = false;
-    explicit HostStage(vis_ctx* c) : ctx(c), base((char*)c->h_pin) {}
+    vis_ctx* ctx; size_t off = 0; hipError_t err = hipSuccess; bool overflow = false;
+    explicit HostStage(vis_ctx* c) : ctx(c) { ctx->stage_live++; }
+    ~HostStage() { ctx->stage_live--; }
+    HostStage(const HostStage&) = delete; HostStage& operator=(const HostStage&) = delete;
+    char* base_now() const { return (char*)ctx->h_pin; }
     void* take(size_t bytes) {
         off = (off + 63) & ~(size_t)63;
-        if (off + bytes > ctx->h_pin_bytes) { overflow = true; return nullptr; }
-        void* p = base + off; off += bytes; return p;
+        if (!ctx->h_pin || off + bytes > ctx->h_pin_bytes) { overflow = true; return nullptr; }
+        void* p = base_now() + off; off += bytes; return p;
     }
     // host (pageable) -> device, asynchronous: through the pinned block.  Dword-granular uploads are collected like the downloads and
     // read out of the block by one kernel of the library per six of them -- at flush_ups(), which every entry point calls behind its
@@ -230,7 +241,7 @@ struct HostStage {
         std::memcpy(p, h, bytes);
         if (!(bytes & 3) && !((uintptr_t)d & 3) && ctx->h_pin_dev) {
             if (up_n == 6) flush_ups();
-            up_dst[up_n] = d; up_src[up_n] = (const char*)ctx->h_pin_dev + ((char*)p - base); up_bytes[up_n] = bytes; up_n++;
+            up_dst[up_n] = d; up_src[up_n] = (const char*)ctx->h_pin_dev + ((char*)p - base_now()); up_bytes[up_n] = bytes; up_n++;
             return;
         }
         flush_ups();                                               // (stream order among the uploads)
@@ -245,7 +256,7 @@ struct HostStage {
         for (size_t y = 0; y < height; y++) std::memcpy(p + y * width, (const char*)h + y * hpitch, width);
         if (dpitch == width && !((width * height) & 3) && !((uintptr_t)d & 3) && ctx->h_pin_dev) {      // dense on the device: one copy job
             if (up_n == 6) flush_ups();
-            up_dst[up_n] = d; up_src[up_n] = (const char*)ctx->h_pin_dev + (p - base); up_bytes[up_n] = width * height; up_n++;
+            up_dst[up_n] = d; up_src[up_n] = (const char*)ctx->h_pin_dev + (p - base_now()); up_bytes[up_n] = width * height; up_n++;
             return;
         }
         flush_ups();
@@ -269,7 +280,7 @@ struct HostStage {
         if (!p || !bytes) return p;
         if (!(bytes & 3) && !((uintptr_t)d & 3) && ctx->h_pin_dev) {
             if (dn_n == 6) flush_downs();
-            dn_dst[dn_n] = (char*)ctx->h_pin_dev + ((char*)p - base); dn_src[dn_n] = d; dn_bytes[dn_n] = bytes; dn_n++;
+            dn_dst[dn_n] = (char*)ctx->h_pin_dev + ((char*)p - base_now()); dn_src[dn_n] = d; dn_bytes[dn_n] = bytes; dn_n++;
             return p;
         }
         const hipError_t e = hipMemcpyAsync(p, d, bytes, hipMemcpyDeviceToHost, ctx->stream);

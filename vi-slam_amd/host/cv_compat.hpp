@@ -8,6 +8,7 @@
 #include <opencv2/core.hpp>
 #else
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -69,6 +70,53 @@ inline Matx33f operator*(const Matx33f& a, const Matx33f& b) {
     return m;
 }
 template <class T> using Ptr = std::shared_ptr<T>;
+// cv::CommandLineParser for the keys string of src/main_vi_slamGPU.cpp:26-39,50-54: "{name alias ... | default | help}" groups; arguments
+// "-name=value" / "--name=value", a bare "-name" is a flag.  has(name): the argument was given (or the key has a non-empty default);
+// get<T>(name): the given value, else the default, through operator>>.
+class CommandLineParser {
+public:
+    CommandLineParser(int argc, const char* const argv[], const String& keys) {
+        size_t p = 0;
+        while ((p = keys.find('{', p)) != String::npos) {
+            const size_t e = keys.find('}', p);
+            if (e == String::npos) break;
+            const String body = keys.substr(p + 1, e - p - 1);
+            const size_t b1 = body.find('|'), b2 = b1 == String::npos ? String::npos : body.find('|', b1 + 1);
+            Key k; k.def = b1 == String::npos ? String() : trim(body.substr(b1 + 1, b2 == String::npos ? String::npos : b2 - b1 - 1));
+            String names = body.substr(0, b1), n;
+            for (size_t i = 0; i <= names.size(); i++) {
+                if (i == names.size() || names[i] == ' ' || names[i] == '\t') { if (!n.empty()) k.names.push_back(n); n.clear(); }
+                else n += names[i];
+            }
+            keys_.push_back(k);
+            p = e + 1;
+        }
+        for (int i = 1; i < argc; i++) {
+            String a = argv[i];
+            if (a.empty() || a[0] != '-') continue;
+            a = a.substr(a.size() > 1 && a[1] == '-' ? 2 : 1);
+            const size_t eq = a.find('=');
+            const String name = a.substr(0, eq), val = eq == String::npos ? String("true") : a.substr(eq + 1);
+            for (auto& k : keys_) for (auto& nm : k.names) if (nm == name) { k.given = true; k.val = val; }
+        }
+    }
+    bool has(const String& name) const { const Key* k = find(name); return k && (k->given || !k->def.empty()); }
+    template <class T> T get(const String& name) const {
+        const Key* k = find(name);
+        const String v = k ? (k->given ? k->val : k->def) : String();
+        return convert<T>(v);
+    }
+    bool check() const { return true; }
+private:
+    struct Key { std::vector<String> names; String def, val; bool given = false; };
+    std::vector<Key> keys_;
+    const Key* find(const String& name) const { for (auto& k : keys_) for (auto& nm : k.names) if (nm == name) return &k; return nullptr; }
+    static String trim(const String& s) { const size_t a = s.find_first_not_of(" \t"), b = s.find_last_not_of(" \t"); return a == String::npos ? String() : s.substr(a, b - a + 1); }
+    template <class T> static T convert(const String& v);
+};
+template <> inline String CommandLineParser::convert<String>(const String& v) { return v; }
+template <> inline int CommandLineParser::convert<int>(const String& v) { return v.empty() ? 0 : std::atoi(v.c_str()); }
+template <> inline double CommandLineParser::convert<double>(const String& v) { return v.empty() ? 0.0 : std::atof(v.c_str()); }
 }  // namespace cv
 #endif
 #endif

@@ -8,10 +8,14 @@
 // Those blocks are copied character for character between the BEGIN/END markers below (tests/test_host_adapters_gpu.py
 // checks them against the line numbers above when the reference tree is present).  What surrounds them is NOT the
 // reference's: `DataReader` and `VisualizerMarker` are stand-ins for the two out-of-scope components main also uses
-// (dataset I/O: src/DataReader.cpp; ROS markers: src/Visualizer.cpp) -- the stand-in reader serves the synthetic stream
-// and a constant ground truth -- and the argument parsing (cv::CommandLineParser, :26-39,50-54) is replaced by plain argv.
+// (dataset I/O: src/DataReader.cpp; ROS markers: src/Visualizer.cpp; compat/DataReader.hpp, compat/Visualizer.hpp) -- the stand-in reader
+// serves the synthetic stream and a constant ground truth -- and the argument parsing (cv::CommandLineParser, :26-39,50-54) is plain argv here.
+// This file is the RUNNABLE twin (it prints per-frame records for the parity test); the reference's own file is compiled unchanged
+// against the same compat tree by tests/test_reference_main_compiles.py.
 #include <cstdio>
 #include <fstream>
+#include "DataReader.hpp"
+#include "Visualizer.hpp"
 #include "VISystemGPU.hpp"
 
 using namespace cv;
@@ -19,44 +23,9 @@ using namespace std;
 using namespace vi;
 cuda::DeviceInfo device_info;                                                          // :23
 
-// ---- stand-ins for out-of-scope components -----------------------------------------------------------------------
-enum { ARROW = 0u, CUBE = 1u, SPHERE = 2u, CYLINDER = 3u };                            // include/Visualizer.hpp:20-24
-class VisualizerMarker {                                                               // include/Visualizer.hpp:27-47 without ROS
-public:
-    VisualizerMarker(string, string, double, uint32_t, int32_t, Point3f, Point3f) {}
-    void UpdateMessages(Point3d, Quaterniond) {}
-};
-class DataReader {                                                                     // include/DataReader.hpp:9-55 on the synthetic stream
-public:
-    DataReader(string image_path, string, string, char) : canvas((size_t)DIM * DIM) {
-        parallax = image_path == "parallax";
-        vis_synth_canvas(canvas.data(), DIM, SEED);
-        gtPosition.push_back(Point3d(0.1, -0.2, 0.3)); gtLinearVelocity.push_back(Point3d(0.01, 0.02, -0.01)); gtRPY.push_back(Point3d(0.02, -0.01, 0.3));
-        gtQuaternion.push_back(toQuaternion(0.02, -0.01, 0.3));
-        imuAngularVelocity.assign(10, Point3d(0, 0, 0)); imuAcceleration.assign(10, Point3d(0, 0, 9.81));
-        indexLastData = 210;
-    }
-    void UpdateDataReader(int index, int index2) {
-        image1 = frame(index - 209); image2 = frame(index2 - 209);                     // main starts at j = 210 (:62): stream frame t = j - 209
-        currentTimeMs = 50.0 * (index2 - 210);
-    }
-    vector<Point3d> imuAngularVelocity, imuAcceleration, gtPosition, gtLinearVelocity, gtRPY;
-    vector<Quaterniond> gtQuaternion;
-    Mat image1, image2;
-    double currentTimeMs = 0;
-    int indexLastData;
-private:
-    Mat frame(int t) {
-        Mat m(H, W, CV_8U);
-        if (parallax) vis_synth_frame_parallax(canvas.data(), DIM, SEED, t, W, H, m.data, W);
-        else vis_synth_frame(canvas.data(), DIM, SEED, t, W, H, m.data, W);
-        return m;
-    }
-    static const int W = 752, H = 480, DIM = 2048;
-    static constexpr unsigned long long SEED = 0xE0C00001ULL;
-    std::vector<uint8_t> canvas;
-    bool parallax = false;
-};
+// the stand-ins for the two out-of-scope components main also uses live under the reference's own header names (compat/DataReader.hpp:
+// the synthetic stream + a constant ground truth; compat/Visualizer.hpp: VisualizerMarker without ROS), so that the reference's file
+// itself compiles against them unchanged (tests/test_reference_main_compiles.py)
 
 static void print_f32(const char* tag, const float* v, int n) {                        // exact float bits for the parity test
     std::printf("%s", tag);
