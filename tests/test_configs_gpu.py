@@ -246,3 +246,75 @@ def test_config5_8000x8000_both_directions_and_exact_filters(vislam, orc, big_ca
     assert sym.tobytes() == osym.tobytes() and good.tobytes() == og.tobytes()
     assert len(sym) > 2000 and 0 < len(good) <= 49
     c.close()
+
+
+def test_config5_batched_path_that_the_bench_times(vislam, orc, big_canvas):
+    """bench.py's config-5 leg: a BATCH of 3840x2160 frames, 8 levels, 8000 keypoints through vis_batch_run(STAGE_FRAME) -- the launch
+    sequence the leg times (multi-frame indexing at that size: ~26 M pyramid pixels per frame, k_select_1024, k_filter<1024>, the carried
+    frame), not the single-frame entry points.  Keypoints + descriptors of the first, the second-to-last and the last frame exact against
+    the oracle; Camera::Update's half pyramid of the last frame exact; both 2-NN tables of the last pair on >= 100 sampled rows against a
+    numpy popcount over all train descriptors; symmetric / good matches exact (the oracle's filter chain on the GPU's own tables); the
+    pose record against the oracle's essential RANSAC + recoverPose on those good matches (E <= 1e-9, R <= 1e-7: DESIGN section 1).
+    A second launch continues the stream: its frame 0 is matched against the carried last frame of the first launch."""
+    import torch
+    p = vislam.default_params()
+    p.nfeatures, p.nlevels, p.w_size, p.h_size = 8000, 8, 3840, 2160
+    p.fy = p.fx
+    c = vislam.Context(0, p)
+    n = 5
+    frames = np.stack([vislam.synth_frame(big_canvas, t, 3840, 2160, 0xE0C00003) for t in range(n + 1)])
+    dev = torch.from_numpy(frames).cuda()
+    c.batch_plan(3840, 2160, 3840, n)
+    c.batch_run(dev.data_ptr(), n, vislam.STAGE_FRAME)
+    c.batch_sync()
+    assert c.batch_status() == 0
+    ref = {}
+    for t in (0, n - 2, n - 1):
+        ref[t] = orc.orb_detect_compute(p, frames[t], cap=16384)
+        k, d = c.batch_keypoints(t, cap=16384)
+        assert len(k) >= 7900 and k.tobytes() == ref[t][0].tobytes() and (d == ref[t][1]).all(), t
+    dptr, fe = c.batch_half_pyramid()
+    class _Dev:
+        __cuda_array_interface__ = {"data": (dptr, False), "shape": (n * fe,), "typestr": "|u1", "version": 2}
+    half = torch.as_tensor(_Dev(), device="cuda")[(n - 1) * fe:n * fe].cpu().numpy()
+    off = 3840 * 2160
+    for l, lv in enumerate(orc.half_pyramid(frames[n - 1])):
+        if l:
+            assert np.array_equal(half[off:off + lv.size].reshape(lv.shape), lv), l
+            off += lv.size
+
+    def check_pair(t, kq, dq, kt, dt):
+        g12, g21 = c.batch_knn(t, cap=16384)
+        assert len(g12) == len(kq) and len(g21) == len(kt)
+        bq, bt = np.unpackbits(dq, axis=1), np.unpackbits(dt, axis=1)
+        rng = np.random.default_rng(50 + t)
+        for tab, qb, tb, nq in ((g12, bq, bt, len(kq)), (g21, bt, bq, len(kt))):
+            rows = np.unique(np.concatenate([[0, 1, nq - 1, nq - 2], rng.integers(0, nq, 100)]))
+            dist = (qb[rows][:, None, :] != tb[None, :, :]).sum(2)
+            order = np.argsort(dist, axis=1, kind="stable")                       # ties: lower train index first (BFMatcher's scan order)
+            for i, r in enumerate(rows):
+                assert tab["trainIdx"][r, 0] == order[i, 0] and tab["trainIdx"][r, 1] == order[i, 1], (t, r)
+                assert tab["distance"][r, 0] == dist[i, order[i, 0]] and tab["distance"][r, 1] == dist[i, order[i, 1]], (t, r)
+        og, osym = orc.good_matches(p, kq, kt, g12, g21)                          # the oracle's filters on the GPU's tables
+        g, nsym = c.batch_matches(t)
+        assert nsym == len(osym) > 2000 and g.tobytes() == og.tobytes() and 0 < len(g) <= 49, t
+        p1 = np.stack([kq["x"][og["queryIdx"]], kq["y"][og["queryIdx"]]], 1)
+        p2 = np.stack([kt["x"][og["trainIdx"]], kt["y"][og["trainIdx"]]], 1)
+        oE, omask, oninl, oiters = orc.essential_ransac(p, p1, p2)
+        pose = c.batch_pose(t)
+        assert pose["iters_run"] == oiters and pose["n_inliers"] == oninl, t
+        if oninl:
+            s = 1.0 if float((pose["E"] * oE).sum()) >= 0 else -1.0
+            assert np.abs(pose["E"] - s * oE).max() <= 1e-9, t
+            oR, ot, ong = orc.recover_pose(p, oE, p1, p2)
+            assert pose["n_pose_good"] == ong and np.abs(pose["R"] - oR).max() <= 1e-7, t
+    check_pair(n - 1, ref[n - 2][0], ref[n - 2][1], ref[n - 1][0], ref[n - 1][1])
+    # the stream goes on: one more frame in a second launch, matched against the carried frame n - 1
+    c.batch_run(dev.data_ptr() + n * 3840 * 2160, 1, vislam.STAGE_FRAME)
+    c.batch_sync()
+    assert c.batch_status() == 0
+    kn, dn = c.batch_keypoints(0, cap=16384)
+    okn, odn = orc.orb_detect_compute(p, frames[n], cap=16384)
+    assert kn.tobytes() == okn.tobytes() and (dn == odn).all()
+    check_pair(0, ref[n - 1][0], ref[n - 1][1], okn, odn)
+    c.close()

@@ -28,6 +28,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 Q = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 parallax = len(sys.argv) > 4 and sys.argv[4] == "parallax"
 main_seq = len(sys.argv) > 4 and sys.argv[4] == "main"
+max_passes = int(sys.argv[5]) if len(sys.argv) > 5 else None     # a PASS COUNT bounds the run; the seconds are then only a guard
 
 p = vislam.default_params(); p.fy = p.fx
 ctx = vislam.Context(0, p)
@@ -83,7 +84,7 @@ def one_pass():
 ref = one_pass()
 t_end = time.time() + seconds
 passes, bad, t_print = 1, 0, time.time()
-while time.time() < t_end:
+while time.time() < t_end and (max_passes is None or passes < max_passes):
     d = one_pass()
     passes += 1
     if d != ref:

@@ -18,12 +18,13 @@ import align_cases  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 99
+max_cases = int(sys.argv[3]) if len(sys.argv) > 3 else None     # a CASE COUNT bounds the run (the same cases on every box); the seconds are then only a guard
 rng = np.random.default_rng(seed0)
 ctx = vislam.Context(0)
 canvas = vislam.synth_canvas(2048, 0xE0C00001)
 t_end = time.time() + budget
 runs = fails = 0
-while time.time() < t_end:
+while time.time() < t_end and (max_cases is None or runs < max_cases):
     w = int(rng.choice([752, 752, 320, 641, 500, 270, 1080, 150])); h = int(rng.choice([480, 480, 240, 479, 375, 150, 540, 110]))
     dx, dy = int(rng.integers(-8, 9)), int(rng.integers(-6, 7))
     n = int(rng.choice([5, 12, 30, 49, 49, 120]))

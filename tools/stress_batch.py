@@ -19,11 +19,12 @@ from test_pose_gpu import _cmpE  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 777
+max_cases = int(sys.argv[3]) if len(sys.argv) > 3 else None     # a CASE COUNT bounds the run (the same cases on every box); the seconds are then only a guard
 rng = np.random.default_rng(seed0)
 canvas = vislam.synth_canvas(2048, 0xE0C00001)
 t_end = time.time() + budget
 runs = fails = frames_total = 0
-while time.time() < t_end:
+while time.time() < t_end and (max_cases is None or runs < max_cases):
     w, h = [(752, 480), (752, 480), (320, 240), (641, 479), (500, 375)][int(rng.integers(0, 5))]
     p = vislam.default_params()
     p.w_size, p.h_size = w, h

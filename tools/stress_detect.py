@@ -17,6 +17,7 @@ import oracle_bind as orc  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 4321
+max_cases = int(sys.argv[3]) if len(sys.argv) > 3 else None     # a CASE COUNT bounds the run (the same cases on every box); the seconds are then only a guard
 rng = np.random.default_rng(seed0)
 ctx = vislam.Context(0)
 canvas = vislam.synth_canvas(2048, 0xE0C00001)
@@ -56,7 +57,7 @@ def content(w, h):
 
 t_end = time.time() + budget
 runs = fails = ncap = 0
-while time.time() < t_end:
+while time.time() < t_end and (max_cases is None or runs < max_cases):
     w = int(rng.choice([96, 150, 188, 320, 321, 500, 641, 752, 1000])); h = int(rng.choice([64, 110, 120, 240, 243, 375, 479, 480, 600]))
     p = vislam.default_params()
     p.w_size, p.h_size = w, h

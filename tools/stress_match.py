@@ -17,6 +17,7 @@ from test_pose_gpu import _f2f_inputs  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 31
+max_cases = int(sys.argv[3]) if len(sys.argv) > 3 else None     # a CASE COUNT bounds the run (the same cases on every box); the seconds are then only a guard
 rng = np.random.default_rng(seed0)
 ctx = vislam.Context(0)
 KP = vislam.KEYPOINT_DTYPE
@@ -38,7 +39,7 @@ def descs(n):
 t_end = time.time() + budget
 runs = fails = 0
 per_kind = [0, 0, 0]
-while time.time() < t_end:
+while time.time() < t_end and (max_cases is None or runs < max_cases):
     kind = int(rng.integers(0, 3))
     per_kind[kind] += 1
     what = "?"

@@ -17,12 +17,13 @@ from test_pose_gpu import two_view, _cmpE  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+max_cases = int(sys.argv[3]) if len(sys.argv) > 3 else None     # a CASE COUNT bounds the run (the same cases on every box); the seconds are then only a guard
 rng = np.random.default_rng(seed0)
 ctx = vislam.Context(0)
 t_end = time.time() + budget
 runs = fails = 0
 big = 0
-while time.time() < t_end:
+while time.time() < t_end and (max_cases is None or runs < max_cases):
     p = vislam.default_params()
     p.fx = float(rng.choice([150.0, 458.654, 458.654, 900.0])); p.fy = p.fx
     p.ransac_threshold = float(rng.choice([0.25, 1.0, 1.0, 3.0]))
