@@ -664,12 +664,13 @@ def main():
                 fr = [vislam.synth_frame(cvs, t, W, H, vdist.SINGLE_SEED) for t in range(n + warm + 1)]     # numpy arrays: pageable host memory
                 names = ("vis_camera_update", "vis_orb_detect_compute", "vis_good_matches", "vis_essential_ransac", "vis_recover_pose")
                 per = {k: [] for k in names}
-                tot = []
+                tot, trace = [], []
                 k_prev, _ = ctx.orb_detect_compute(fr[0], slot=0)
                 c0 = None
                 for t in range(1, n + warm + 1):
                     if t == warm + 1:
-                        per = {k: [] for k in names}; tot = []; c0 = ctx.debug_counters()
+                        per = {k: [] for k in names}; tot = []; trace = []; c0 = ctx.debug_counters()
+                    cc0 = ctx.debug_counters()
                     ts = [time.perf_counter()]
                     ctx.camera_update(fr[t]); ts.append(time.perf_counter())
                     k_cur, _d = ctx.orb_detect_compute(fr[t], slot=t & 1); ts.append(time.perf_counter())
@@ -682,6 +683,8 @@ def main():
                     for k, dt_ in zip(names, (ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], te - tb, tr - te)):
                         per[k].append(dt_ * 1e3)
                     tot.append((ts[3] - ts[0] + tr - tb) * 1e3)
+                    cc1 = ctx.debug_counters()
+                    trace.append((len(tot) - 1, tot[-1], [per[k][-1] for k in names], cc1[0] - cc0[0], cc1[1] - cc0[1], cc1[2] - cc0[2], len(g)))
                     k_prev = k_cur
                 c1 = ctx.debug_counters()
                 pct = lambda v, q: float(np.percentile(np.array(v), q))
@@ -693,6 +696,10 @@ def main():
                        "ms_per_frame_max": float(np.max(tot)), "slowest_frame_index": int(np.argmax(tot)), "ms_per_frame_mean": float(np.mean(tot)),
                        "ms_max_per_entry_point": {k: float(np.max(v)) for k, v in per.items()},
                        "slowest_call_index_per_entry_point": {k: int(np.argmax(v)) for k, v in per.items()},
+                       # the five slowest frames: which entry point the time went to and what the frame did (launches / host waits / copies)
+                       "slowest_frames": [{"index": i_, "ms": round(m_, 4), "ms_per_entry_point": {k: round(x, 4) for k, x in zip(names, e_)}, "launches": int(l_),
+                                           "host_waits": int(w_), "copies": int(c_), "good_matches": int(g_)}
+                                          for i_, m_, e_, l_, w_, c_, g_ in sorted(trace, key=lambda r_: -r_[1])[:5]],
                        "frames_per_s_one_at_a_time": 1e3 / float(np.mean(tot)),
                        "ms_p50_per_entry_point": {k: pct(v, 50) for k, v in per.items()}, "ms_p95_per_entry_point": {k: pct(v, 95) for k, v in per.items()},
                        "kernel_launches_per_frame": (c1[0] - c0[0]) / n, "host_waits_per_frame": (c1[1] - c0[1]) / n, "async_copies_per_frame": (c1[2] - c0[2]) / n,

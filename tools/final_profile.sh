@@ -20,6 +20,20 @@ done
 # the measured VALU issue ceilings of this box, same lease (vi-slam_amd/lib/valu_peak is built by `make -C vi-slam_amd/csrc tools`)
 $R/vi-slam_amd/lib/valu_peak > $R/$OUT/valu_peak.log 2>&1
 python3 $R/tools/pmc_summarize.py $R/$OUT/pipe 512 $COMMIT $R/$OUT/valu_peak.log > $R/$OUT/pmc_summary.log 2>&1
+# 3b. configs 3 and 5 on their OWN workload (1920x1080 / 4000 kps / 64 frames; 3840x2160 / 8000 kps / 16 frames per launch): traffic, L2 hit,
+#     MFMA busy, instruction counts and LDS activity of every kernel; merged into pmc_traffic.json under legs.c3 / legs.c5
+cp $R/$OUT/pipe/pmc_traffic.json $R/$OUT/pmc_traffic_merged.json
+for leg in c3:64:4000 c5:16:8000; do
+  L=${leg%%:*}; rest=${leg#*:}; LB=${rest%%:*}; ND=${rest#*:}
+  export VIS_PROFILE_CONFIG=$L VIS_PROFILE_BATCH=$LB VIS_PROFILE_N_DESC=$ND VIS_PROFILE_STEPS=3 VIS_PROFILE_WARM=2
+  for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum SQ_INSTS_VALU_MFMA_MOPS_F6F4 SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"; do
+    n=$(echo $c | cut -d' ' -f1)
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/pipe_$L/pass_$n -- python3 $R/tools/profile_workload.py > $R/$OUT/pipe_${L}_$n.log 2>&1
+  done
+  PMC_LEG=$L PMC_MERGE_INTO=$R/$OUT/pmc_traffic_merged.json python3 $R/tools/pmc_summarize.py $R/$OUT/pipe_$L $LB $COMMIT > $R/$OUT/pmc_summary_$L.log 2>&1
+done
+unset VIS_PROFILE_CONFIG VIS_PROFILE_N_DESC
+cp $R/$OUT/pmc_traffic_merged.json $R/$OUT/pipe/pmc_traffic.json
 export VIS_PROFILE_BATCH=1024 VIS_PROFILE_STEPS=3 VIS_PROFILE_WARM=0
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
   n=$(echo $c | cut -d' ' -f1)

@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc CSVs (one directory per counter pass) into profiles/pmc_traffic.json.
-usage: pmc_summarize.py OUTDIR B  where OUTDIR holds pass_*/**/*counter_collection.csv"""
+usage: pmc_summarize.py OUTDIR B [COMMIT [VALU_PEAK_LOG]]      where OUTDIR holds pass_*/**/*counter_collection.csv
+Environment: VIS_PROFILE_WARM / VIS_PROFILE_STEPS as the workload ran; VIS_PROFILE_N_DESC = descriptors per frame of the workload (1000);
+PMC_LEG=<name> + PMC_MERGE_INTO=<pmc_traffic.json>: the set belongs to another configuration (c3, c5: tools/profile_workload.py with
+VIS_PROFILE_CONFIG) and is stored under legs.<name> of that file instead of replacing its top level (bench.py quotes a leg's counters only
+from the set taken on that leg's own workload)."""
 import csv
 import glob
 import json
@@ -35,7 +39,8 @@ for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recur
     for r in csv.DictReader(open(f)):
         if "copyBuffer" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             cal[r["Counter_Name"]] = max(cal.get(r["Counter_Name"], 0.0), float(r["Counter_Value"]))
-res = {"batch_frames": B, "measured_at_commit": commit, "raw": summary,
+res = {"batch_frames": B, "n_desc": int(os.environ.get("VIS_PROFILE_N_DESC", "1000")), "workload": os.environ.get("VIS_PROFILE_CONFIG", "headline"),
+       "steps_counted": steps, "measured_at_commit": commit, "raw": summary,
        "calibration": {"known_bytes_each_way": known, "FETCH_SIZE_units": cal.get("FETCH_SIZE"), "WRITE_SIZE_units": cal.get("WRITE_SIZE"),
                        "fetch_bytes_per_unit": known / cal["FETCH_SIZE"] if cal.get("FETCH_SIZE") else None,
                        "write_bytes_per_unit": known / cal["WRITE_SIZE"] if cal.get("WRITE_SIZE") else None,
@@ -77,5 +82,12 @@ for k, cs in summary.items():
     per_kernel[k] = round(per_step)
 res["step"] = {"what": "sum over every kernel of one pipelined step (all launches of the step), counter means x launches per step",
                "valu_wave_insts_per_step": step_valu, "salu_wave_insts_per_step": step_salu, "valu_wave_insts_per_kernel": per_kernel, "steps_counted": steps}
-json.dump(res, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1)
+leg, target = os.environ.get("PMC_LEG"), os.environ.get("PMC_MERGE_INTO")
+if leg and target:
+    tj = json.load(open(target))
+    tj.setdefault("legs", {})[leg] = {k: v for k, v in res.items() if k not in ("valu_peak_measured",)}
+    json.dump(tj, open(target, "w"), indent=1)
+    json.dump(res, open(os.path.join(out_dir, f"pmc_leg_{leg}.json"), "w"), indent=1)
+else:
+    json.dump(res, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "raw"}, indent=1))

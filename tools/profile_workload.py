@@ -16,15 +16,29 @@ import vislam  # noqa: E402
 
 B = int(os.environ.get("VIS_PROFILE_BATCH", "256"))
 STEPS = int(os.environ.get("VIS_PROFILE_STEPS", "3"))
-W, H = 752, 480
+# VIS_PROFILE_CONFIG: headline (BASELINE configs[1]) | c3 (configs[2]: 1920x1080, 4 levels, 4000 kps, 2000 fixed RANSAC iterations on the
+# symmetric matches) | c5 (configs[4]: 3840x2160, 8 levels, 8000 kps) -- the same parameters bench.py's legs run (every
+# configuration is quoted with counters of ITS OWN workload)
+CFG = os.environ.get("VIS_PROFILE_CONFIG", "headline")
 p = vislam.default_params()
+W, H, DIM, SEED = 752, 480, 4096, 0xE0C00001
+if CFG == "c3":
+    W, H, DIM, SEED = 1920, 1080, 8192, 0xE0C00003
+    p.nfeatures, p.nlevels, p.w_size, p.h_size = 4000, 4, W, H
+    p.ransac_adaptive, p.ransac_max_iters, p.pose_input = 0, 2000, 1
+elif CFG == "c5":
+    W, H, DIM, SEED = 3840, 2160, 8192, 0xE0C00005
+    p.nfeatures, p.nlevels, p.w_size, p.h_size = 8000, 8, W, H
+elif CFG != "headline":
+    raise SystemExit(f"unknown VIS_PROFILE_CONFIG {CFG}")
 p.fy = p.fx
 ctx = vislam.Context(0, p)
-cv = vislam.synth_canvas(4096, 0xE0C00001)
+cv = vislam.synth_canvas(DIM, SEED)
 dcv = torch.from_numpy(cv).cuda()
 d = torch.empty((B, H, W), dtype=torch.uint8, device="cuda")
-for t0 in range(0, B, 256):            # device-side generator: byte-identical to the host one (tests/test_synth_gpu.py)
-    ctx.synth_frames_device(dcv.data_ptr(), 4096, 0xE0C00001, t0, min(256, B - t0), W, H, W, d.data_ptr() + t0 * W * H)
+GEN = max(1, min(256, (256 * 752 * 480) // (W * H)))
+for t0 in range(0, B, GEN):            # device-side generator: byte-identical to the host one (tests/test_synth_gpu.py)
+    ctx.synth_frames_device(dcv.data_ptr(), DIM, SEED, t0, min(GEN, B - t0), W, H, W, d.data_ptr() + t0 * W * H)
 torch.cuda.synchronize()
 ctx.batch_plan(W, H, W, B)
 # flush the 256 MiB Infinity Cache between steps with a 1 GiB fill so every step reads its frames from HBM
@@ -44,5 +58,5 @@ junk.fill_(7)
 torch.cuda.synchronize()
 cal_dst.copy_(cal_src)          # calibration: 256 MiB read + 256 MiB written
 torch.cuda.synchronize()
-print("status", ctx.batch_status(), "B", B)
+print("status", ctx.batch_status(), "B", B, "config", CFG)
 ctx.close()

@@ -34,19 +34,34 @@ int main(int argc, char** argv) {
     for (int t = 1; t <= warm; t++) visystem.AddFrameGPU(frames[t], gyro, acc);
     unsigned long long c0[4], c1[4];
     vis_debug_counters(VisDevice::get(), c0);
-    std::vector<double> ms;
+    // per call: wall clock + what the call did (kernel launches, host waits, copies: vis_debug_counters deltas) -- the worst frame is the
+    // figure that matters for a 20 Hz camera, and the deltas tell a slow wait from extra work (a keyframe insertion, a buffer growing)
+    struct Call { double ms; int index; unsigned long long launches, waits, copies; int keyframes; };
+    std::vector<Call> calls;
+    unsigned long long ca[4], cb[4];
     for (int t = warm + 1; t <= warm + n; t++) {
+        vis_debug_counters(VisDevice::get(), ca);
         const auto a = std::chrono::steady_clock::now();
         visystem.AddFrameGPU(frames[t], gyro, acc);
-        ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count());
+        const double d = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+        vis_debug_counters(VisDevice::get(), cb);
+        calls.push_back({d, t - warm - 1, cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2], (int)visystem.cameraGPU.frameList.size()});
     }
     vis_debug_counters(VisDevice::get(), c1);
     std::cout.rdbuf(quiet);
+    std::vector<double> ms; for (auto& c : calls) ms.push_back(c.ms);
     std::sort(ms.begin(), ms.end());
     double mean = 0; for (double v : ms) mean += v; mean /= ms.size();
-    std::printf("{\"frames\": %d, \"ms_p50\": %.4f, \"ms_p95\": %.4f, \"ms_mean\": %.4f, \"ms_min\": %.4f, \"launches_per_frame\": %.1f, "
-                "\"host_waits_per_frame\": %.2f, \"async_copies_per_frame\": %.1f, \"keyframes\": %d}\n",
-                n, ms[ms.size() / 2], ms[std::min(ms.size() - 1, (size_t)(ms.size() * 0.95))], mean, ms[0],
+    auto pct = [&](double q) { return ms[std::min(ms.size() - 1, (size_t)(ms.size() * q))]; };
+    std::vector<Call> slow = calls;
+    std::sort(slow.begin(), slow.end(), [](const Call& x, const Call& y) { return x.ms > y.ms; });
+    std::printf("{\"frames\": %d, \"ms_p50\": %.4f, \"ms_p95\": %.4f, \"ms_p99\": %.4f, \"ms_max\": %.4f, \"slowest_frame_index\": %d, \"ms_mean\": %.4f, \"ms_min\": %.4f, "
+                "\"launches_per_frame\": %.1f, \"host_waits_per_frame\": %.2f, \"async_copies_per_frame\": %.1f, \"keyframes\": %d, \"slowest_calls\": [",
+                n, pct(0.5), pct(0.95), pct(0.99), ms.back(), slow[0].index, mean, ms[0],
                 (double)(c1[0] - c0[0]) / n, (double)(c1[1] - c0[1]) / n, (double)(c1[2] - c0[2]) / n, (int)visystem.cameraGPU.frameList.size());
+    for (size_t i = 0; i < std::min<size_t>(5, slow.size()); i++)
+        std::printf("%s{\"index\": %d, \"ms\": %.4f, \"launches\": %llu, \"host_waits\": %llu, \"copies\": %llu, \"keyframes\": %d}", i ? ", " : "",
+                    slow[i].index, slow[i].ms, slow[i].launches, slow[i].waits, slow[i].copies, slow[i].keyframes);
+    std::printf("]}\n");
     return 0;
 }
