@@ -181,6 +181,12 @@ extern "C" int vis_set_params(vis_ctx* ctx, const vis_params* p) {
     ctx->p = *p;
     plan_destroy(ctx->batch); ctx->batch = nullptr;
     ctx->single = nullptr;
+    // the cv::RNG sample table of the frame-at-a-time pose entry points, for every M they take from the table (<= VIS_POSE_TABLE_M): built
+    // HERE, where parameters change, not inside the first vis_essential_ransac whose correspondence count exceeds the last one's (round 5's
+    // single_frame_api leg: one call of 200 took 57 ms -- a table freed, rebuilt and re-uploaded when M grew from 33 to 39 -- against a
+    // p50 of 0.14 ms).  A failure here is not fatal: the entry point asks again.
+    (void)hipSetDevice(ctx->device);
+    (void)vis_build_sample_table(ctx, VIS_POSE_TABLE_M);
     if (keep) {
         Plan* np = nullptr;
         rc = plan_create(ctx, old->w, old->h, old->stride, 1, VIS_NSLOTS, 1, &np);
@@ -919,7 +925,9 @@ static int pose_host(vis_ctx* ctx, const float* p1xy, const float* p2xy, int m, 
     if (m > VIS_RANSAC_MAX_M) return VIS_E_CAPACITY;
     const int mcap = std::max(m, 1);
     const int iters = ctx->p.ransac_max_iters;
-    size_t need = (size_t)mcap * (16 + 32 + 1) + (size_t)iters * (20 + 720 + 40 + 8 * VIS_HYP_DOUBLES) + 65536;
+    // scratch sized for a power-of-two correspondence count >= 256: a stream whose match count creeps up does not re-allocate per call
+    int mroom = 256; while (mroom < mcap) mroom <<= 1;
+    size_t need = (size_t)mroom * (16 + 32 + 1) + (size_t)iters * (20 + 720 + 40 + 8 * VIS_HYP_DOUBLES) + 65536;
     int rc = ensure_scratch(ctx, need);
     if (rc) return rc;
     Carver cv{(char*)ctx->d_scratch, 0};
@@ -944,7 +952,7 @@ static int pose_host(vis_ctx* ctx, const float* p1xy, const float* p2xy, int m, 
     hs.up(d_npts, &mm, 4);
     if (E_in) hs.up(d_E, E_in, 72);
     hs.flush_ups();
-    rc = vis_build_sample_table(ctx, std::min(m, 64));
+    rc = vis_build_sample_table(ctx, VIS_POSE_TABLE_M);           // (already there since vis_set_params / the first call: never rebuilt because M grew)
     if (rc) return rc;
     if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[6], ctx->stream);
     rc = pose_run(ctx, 1, mcap, iters, d_p1, d_p2, d_npts, d_n1, d_n2, d_samples, d_models, d_counts, d_rstate,

@@ -133,6 +133,7 @@ struct Plan {
     bool pair0_valid = false;                // last run: frame 0 had a predecessor
 };
 
+#define VIS_POSE_TABLE_M 64                  // the frame-at-a-time pose entry points take their RANSAC samples from the table for M <= 64 (root^2 = 49 in the reference)
 struct vis_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
