@@ -285,7 +285,7 @@ def leg_detect_counters(label, leg, B):
         if cs is None:
             return {"counters_from": f"not measured for this workload (no legs.{label} in profiles/pmc_traffic.json)"}
         out = {"counters_from": f"profiles/pmc_traffic.json legs.{label} ({cs['batch_frames']} frames per launch, commit {cs.get('measured_at_commit')})"}
-        for k in ("k_fast", "k_resize", "k_describe", "k_select"):
+        for k in ("k_fast", "k_resize", "k_describe", "k_select", "k_select_1024"):
             if k not in cs:
                 continue
             calls = cs["raw"][k]["FETCH_SIZE"]["calls"] / max(1, cs.get("steps_counted", 1))          # launches of the family per step

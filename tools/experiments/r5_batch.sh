@@ -1,5 +1,5 @@
 #!/bin/bash
-# headline against the frames-per-launch choice and the stage mask (same box): tools/r5_batch.sh
+# headline against the frames-per-launch choice and the stage mask (same box): tools/experiments/r5_batch.sh
 cd $GRAFT_REPO_ROOT
 for S in 1 15; do
 for B in 512 640 1024 1280 2048 4096; do

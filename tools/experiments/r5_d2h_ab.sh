@@ -1,5 +1,5 @@
 #!/bin/bash
-# headline, headline + results download, S-752P for several builds, alternating: tools/r5_d2h_ab.sh LIB_A LIB_B ...
+# headline, headline + results download, S-752P for several builds, alternating: tools/experiments/r5_d2h_ab.sh LIB_A LIB_B ...
 cd $GRAFT_REPO_ROOT
 for r in 1 2 3; do for L in "$@"; do
   export VISLAM_HIP_LIB=$GRAFT_REPO_ROOT/$L

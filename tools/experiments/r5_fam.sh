@@ -1,4 +1,4 @@
-# k_fast alone (detect stage only) for several builds: tools/r5_fam.sh LIB...
+# k_fast alone (detect stage only) for several builds: tools/experiments/r5_fam.sh LIB...
 cd $GRAFT_REPO_ROOT
 for L in "$@"; do
   VISLAM_HIP_LIB=$GRAFT_REPO_ROOT/$L timeout -k 10 200 python bench.py --no-legs --no-cpu-baseline --steps 6 --stages 1 2>/dev/null | python -c "

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counter passes of one kernel for several library builds: tools/r5_pmc_ab.sh KERNEL LIB_A [LIB_B ...]   (GPU box, repo root)
+# SQ counter passes of one kernel for several library builds: tools/experiments/r5_pmc_ab.sh KERNEL LIB_A [LIB_B ...]   (GPU box, repo root)
 K=$1; shift
 for L in "$@"; do
   T=$(basename $L .so)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# headline bench with different stage sets for several builds: tools/r5_stage_ab.sh "STAGESETS" LIB_A [LIB_B ...]
+# headline bench with different stage sets for several builds: tools/experiments/r5_stage_ab.sh "STAGESETS" LIB_A [LIB_B ...]
 cd $GRAFT_REPO_ROOT
 SETS=$1; shift
 for r in 1 2; do for L in "$@"; do for S in $SETS; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel-trace timeline of the pipelined steady state for several builds: tools/r5_trace.sh LIB_A [LIB_B ...]
+# kernel-trace timeline of the pipelined steady state for several builds: tools/experiments/r5_trace.sh LIB_A [LIB_B ...]
 export TMPDIR=/tmp
 for L in "$@"; do
   T=$(basename $L .so)

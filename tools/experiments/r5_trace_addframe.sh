@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel + copy timeline of VISystemGPU::AddFrameGPU on the adapter classes (vi-slam_amd/lib/addframe_bench): tools/r5_trace_addframe.sh
+# kernel + copy timeline of VISystemGPU::AddFrameGPU on the adapter classes (vi-slam_amd/lib/addframe_bench): tools/experiments/r5_trace_addframe.sh
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 D=$GRAFT_REPO_ROOT/gpurun_out/trace_addframe

@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel-trace timeline of config 3 (1080p, 4000 keypoints, 2000 fixed RANSAC iterations, 128 frames per step): tools/r5_trace_c3.sh
+# kernel-trace timeline of config 3 (1080p, 4000 keypoints, 2000 fixed RANSAC iterations, 128 frames per step): tools/experiments/r5_trace_c3.sh
 export TMPDIR=/tmp
 D=$GRAFT_REPO_ROOT/gpurun_out/trace_c3
 rm -rf $D; mkdir -p $D

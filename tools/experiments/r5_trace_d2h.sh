@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel-trace timeline of the headline with the results download queued behind every step: tools/r5_trace_d2h.sh
+# kernel-trace timeline of the headline with the results download queued behind every step: tools/experiments/r5_trace_d2h.sh
 export TMPDIR=/tmp
 D=$GRAFT_REPO_ROOT/gpurun_out/trace_d2h
 rm -rf $D; mkdir -p $D

@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel-trace timeline of the GPU main's per-frame sequence (legs.gpu_main_sequence): tools/r5_trace_main.sh
+# kernel-trace timeline of the GPU main's per-frame sequence (legs.gpu_main_sequence): tools/experiments/r5_trace_main.sh
 export TMPDIR=/tmp
 D=$GRAFT_REPO_ROOT/gpurun_out/trace_main
 rm -rf $D; mkdir -p $D

@@ -52,7 +52,7 @@ if peak_log and os.path.exists(peak_log):
             res.update(json.loads(line))
 fb = res["calibration"]["fetch_bytes_per_unit"] or 2048.0
 wb = res["calibration"]["write_bytes_per_unit"] or 1024.0
-for k in ("k_fast", "k_resize", "k_describe", "k_knn2", "k_knn_mfma", "k_expand", "k_select", "k_filter", "k_ransac_hyp", "k_hyp_roots", "k_hyp_roots_packed", "k_hyp_models", "k_hyp_score",
+for k in ("k_fast", "k_resize", "k_describe", "k_knn2", "k_knn_mfma", "k_expand", "k_select", "k_select_1024", "k_filter", "k_ransac_hyp", "k_hyp_roots", "k_hyp_roots_packed", "k_hyp_models", "k_hyp_score",
           "k_pose_final", "k_gradient", "k_half4"):
     if k in summary and "FETCH_SIZE" in summary[k]:
         f = summary[k]["FETCH_SIZE"]["mean"]

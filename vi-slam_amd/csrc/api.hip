@@ -695,41 +695,49 @@ extern "C" int vis_orb_detect_compute(vis_ctx* ctx, const uint8_t* img, int w, i
     rc = vis_ensure_pin(ctx, (size_t)w * h + nfetch * (sizeof(vis_keypoint) + 32) + 4096);
     if (rc) return rc;
     std::memset(&ctx->tm, 0, sizeof(ctx->tm));
-    HostStage hs(ctx);
-    hs.up2d(pl->d_stage, pl->stride, img, stride, w, h);
-    hs.flush_ups();
-    if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[0], ctx->stream);
-    rc = launch_detect(ctx, pl, pl->d_stage, 1, frame_slot);
-    if (rc) return rc;
-    const int32_t* h_n = (const int32_t*)hs.down(pl->d_nkp + frame_slot, 4);
-    const int32_t* h_fl = (const int32_t*)hs.down(pl->d_flags, 4);
-    const void* h_kps = kps_out && nfetch ? hs.down(pl->d_kps + (size_t)frame_slot * pl->kcap, nfetch * sizeof(vis_keypoint)) : nullptr;
-    const void* h_desc = desc_out && nfetch ? hs.down(pl->d_desc + (size_t)frame_slot * pl->kcap * 32, nfetch * 32) : nullptr;
-    rc = hs.wait();
-    if (rc) return rc;
-    collect_detect_timings(ctx);
-    { float a = 0; if (ctx->ev_ok && ev_elapsed(&a, ctx->ev[0], ctx->ev[4])) ctx->tm.ms_total = a; }
-    const int32_t n = *h_n, fl = *h_fl;
-    if (fl) {
-        // More tied keypoints than the plan's records hold (KeyPointsFilter::retainBest keeps every tie at its cut: a checkerboard)?  The
-        // caller's `cap` says how many it is prepared to take: grow the per-frame capacity towards it -- the other slots' records move
-        // into the re-created plan -- and detect again.  Only what exceeds `cap` (or 65535) is an error.
-        if ((fl & 12) && !(fl & ~12) && cap > pl->kcap && pl->kcap < 65535) {
-            HIPCHK(ctx, hipMemset(pl->d_flags, 0, 4));
-            const int want = std::min(65535, std::max(cap, 2 * pl->kcap));
-            rc = grow_single(ctx, want);
-            if (rc) return rc;
-            return vis_orb_detect_compute(ctx, img, w, h, stride, frame_slot, kps_out, desc_out, cap, n_out);
-        }
-        rc = check_flags(ctx, pl);                                 // (reads and clears the flags: the error path may block again)
+    int grow_to = 0;                                               // > 0: more ties than the plan's records hold; grow and detect again (below, once the stage is gone)
+    {
+        HostStage hs(ctx);
+        hs.up2d(pl->d_stage, pl->stride, img, stride, w, h);
+        hs.flush_ups();
+        if (ctx->ev_ok) (void)hipEventRecord(ctx->ev[0], ctx->stream);
+        rc = launch_detect(ctx, pl, pl->d_stage, 1, frame_slot);
         if (rc) return rc;
+        const int32_t* h_n = (const int32_t*)hs.down(pl->d_nkp + frame_slot, 4);
+        const int32_t* h_fl = (const int32_t*)hs.down(pl->d_flags, 4);
+        const void* h_kps = kps_out && nfetch ? hs.down(pl->d_kps + (size_t)frame_slot * pl->kcap, nfetch * sizeof(vis_keypoint)) : nullptr;
+        const void* h_desc = desc_out && nfetch ? hs.down(pl->d_desc + (size_t)frame_slot * pl->kcap * 32, nfetch * 32) : nullptr;
+        rc = hs.wait();
+        if (rc) return rc;
+        collect_detect_timings(ctx);
+        { float a = 0; if (ctx->ev_ok && ev_elapsed(&a, ctx->ev[0], ctx->ev[4])) ctx->tm.ms_total = a; }
+        const int32_t n = *h_n, fl = *h_fl;
+        if (fl) {
+            // More tied keypoints than the plan's records hold (KeyPointsFilter::retainBest keeps every tie at its cut: a checkerboard)?  The
+            // caller's `cap` says how many it is prepared to take: grow the per-frame capacity towards it -- the other slots' records move
+            // into the re-created plan -- and detect again.  Only what exceeds `cap` (or 65535) is an error.
+            if ((fl & 12) && !(fl & ~12) && cap > pl->kcap && pl->kcap < 65535) grow_to = std::min(65535, std::max(cap, 2 * pl->kcap));
+            else {
+                rc = check_flags(ctx, pl);                         // (reads and clears the flags: the error path may block again)
+                if (rc) return rc;
+            }
+        }
+        if (!grow_to) {
+            ctx->slot_valid[frame_slot] = 1;
+            *n_out = n;
+            if (n > cap && (kps_out || desc_out)) return VIS_E_CAPACITY;
+            if (kps_out && n) std::memcpy(kps_out, h_kps, (size_t)n * sizeof(vis_keypoint));
+            if (desc_out && n) std::memcpy(desc_out, h_desc, (size_t)n * 32);
+            return VIS_OK;
+        }
     }
-    ctx->slot_valid[frame_slot] = 1;
-    *n_out = n;
-    if (n > cap && (kps_out || desc_out)) return VIS_E_CAPACITY;
-    if (kps_out && n) std::memcpy(kps_out, h_kps, (size_t)n * sizeof(vis_keypoint));
-    if (desc_out && n) std::memcpy(desc_out, h_desc, (size_t)n * 32);
-    return VIS_OK;
+    // The retry runs with NO stage alive: it sizes the staging block for the larger record count, which may replace the block (round 6: the
+    // retry used to re-enter this function under the first pass's live stage -- harmless only because that stage was never touched again;
+    // vis_ensure_pin now refuses it, tests/test_edge_cases_gpu.py::test_ties_beyond_the_default_slack_are_all_returned on a fresh context)
+    HIPCHK(ctx, hipMemset(pl->d_flags, 0, 4));
+    rc = grow_single(ctx, grow_to);
+    if (rc) return rc;
+    return vis_orb_detect_compute(ctx, img, w, h, stride, frame_slot, kps_out, desc_out, cap, n_out);
 }
 
 static int set_single_pair(vis_ctx* ctx, Plan* pl, int slot_q, int slot_t) {
