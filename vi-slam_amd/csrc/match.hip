@@ -162,17 +162,22 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, 
     uint4 pre;
 #define STAGE_LOAD(t_) do { pre = *reinterpret_cast<const uint4*>(xs + (size_t)min((t_) * 32 + st_row, ns - 1) * 128 + 16 * st_c); } while (0)
 #define STAGE_STORE(buf_) do { tile[buf_][st_row * KM_ROW + st_c] = pre; } while (0)
-    // The dot products are multiples of 8192 after the 2^20 offset, so the 13 low bits of an accumulator are free: the chain
-    // STARTS from 2^20 + ((tile << 4) | accumulator register), and the finished accumulator IS the running key
-    // 8192 * Hamming + (tile << 4 | register) -- no per-element key construction.  Inside a lane the register order is the row
-    // order, so (tile, register) breaks ties exactly like the row index; the true row index is restored before the two
-    // half-lanes of a column are merged.  Keys are compared as the bit patterns of non-negative floats; INT_MAX = none.
+    // The dot products are multiples of 8192 after the 2^20 offset, so the 13 low bits of an accumulator are free: every chain STARTS
+    // from 2^20 + 8192 + accumulator register, and the finished accumulator IS the key 8192 * (Hamming + 1) + register of a row of the
+    // CURRENT tile -- no per-element key construction.  The tile index is carried by AGE instead of by the start values (round 6: 16
+    // v_add_f32 per tile on the start values before, 2 v_sub_f32 per column group now): in front of every tile's merge the two running
+    // keys lose 16, so a key that is D tiles old reads 8192 * (Hamming + 1) + register - 16 D.  Inside a lane the register order is the
+    // row order and an older tile means lower rows, so among equal distances the smaller key is still the lower row; 16 D <= 8176 never
+    // borrows across a distance (ns <= 16384: D <= 511) and never goes negative.  At the end w = key + 16 (ntiles - 1) restores
+    // 8192 * (Hamming + 1) + (tile << 4 | register).  Keys are compared as the bit patterns of positive floats; KNN_NONE (1.7e38: a
+    // finite float that 16 cannot change) = no neighbour yet.
+#define KNN_NONE 0x7F000000
     int k0[NC], k1[NC];
 #pragma unroll
-    for (int c = 0; c < NC; c++) { k0[c] = 0x7FFFFFFF; k1[c] = 0x7FFFFFFF; }
+    for (int c = 0; c < NC; c++) { k0[c] = KNN_NONE; k1[c] = KNN_NONE; }
     v16f cstart;
 #pragma unroll
-    for (int r = 0; r < 16; r++) cstart[r] = 1048576.f + (float)r;
+    for (int r = 0; r < 16; r++) cstart[r] = 1048576.f + 8192.f + (float)r;
     if (ntiles > 0) { STAGE_LOAD(0); STAGE_STORE(0); }
     __syncthreads();
     for (int t = 0; t < ntiles; t++) {
@@ -189,7 +194,11 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, 
             for (int c = 0; c < NC; c++)      // cbsz = blgp = 4: FP4 e2m1 on both sides; scales 2^6 (e8m0 133): products +-4096
                 acc[c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bf[c][ks], acc[c], 4, 4, 0, 133, 0, 133);
         }
-        cstart += 16.f;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {                                 // age the running keys by one tile (see above); exact float subtractions
+            k0[c] = __float_as_int(__int_as_float(k0[c]) - 16.f);
+            k1[c] = __float_as_int(__int_as_float(k1[c]) - 16.f);
+        }
         if (t * 32 + 32 <= ns) {
             // two keys per step, three instructions (1.5 per key instead of 2): the second smallest of {k0, k1, x, y} is k1 or the
             // second smallest of {k0, x, y} (k1 >= k0 >= the smallest of those three); all keys are distinct (they carry their tile
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, 
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int trow = toff + (r & 3) + 8 * (r >> 2);
-                    const int key = trow < ns ? __float_as_int(acc[c][r]) : 0x7FFFFFFF;
+                    const int key = trow < ns ? __float_as_int(acc[c][r]) : KNN_NONE;
                     k1[c] = imed3(k0[c], k1[c], key);
                     k0[c] = min(k0[c], key);
                 }
@@ -221,10 +230,12 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const int8_t* __restrict__ X, 
 #undef STAGE_STORE
     // (Hamming << 16) | row: the record format of k_filter / the popcount kernel
     auto true_key = [&](int k) -> uint32_t {
-        const uint32_t u = (uint32_t)__int_as_float(k), lo = u & 8191u, r = lo & 15u;       // the float IS the integer key (exact)
+        const uint32_t w = (uint32_t)__int_as_float(k) + 16u * (uint32_t)(ntiles - 1);      // the float IS the integer key (exact); undo the ageing
+        const uint32_t lo = w & 8191u, r = lo & 15u;
         const uint32_t row = (lo >> 4) * 32u + 4u * (uint32_t)h + (r & 3u) + 8u * (r >> 2);
-        return k == 0x7FFFFFFF ? 0xFFFFFFFFu : (((u >> 13) << 16) | row);
+        return k == KNN_NONE ? 0xFFFFFFFFu : ((((w >> 13) - 1u) << 16) | row);
     };
+#undef KNN_NONE
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         const uint32_t a0 = true_key(k0[c]), a1 = true_key(k1[c]);
