@@ -726,7 +726,13 @@ def main():
         q3.nfeatures, q3.nlevels, q3.w_size, q3.h_size = 4000, 4, 1920, 1080
         q3.fy = q3.fx
         q3.ransac_adaptive, q3.ransac_max_iters, q3.pose_input = 0, 2000, 1
-        guarded("config3_s1080", lambda: dict(run_leg(dev, 1920, 1080, 128, 2, q3, 0xE0C00003, 8192, 24, 2), pose_kernels=pose_kernels("c3"),
+        def leg3():
+            r = run_leg(dev, 1920, 1080, 128, 2, q3, 0xE0C00003, 8192, 24, 2)
+            r["pose_kernels"] = pose_kernels("c3")
+            r["matcher_roofline"] = matcher_roofline(r["kernels_ms_per_step"]["ms_knn"], 4000, 127, counters="c3")
+            r["detect_counters"] = leg_detect_counters("c3", r, 128)
+            return r
+        guarded("config3_s1080", lambda: dict(leg3(),
                 what="BASELINE configs[2]: 1920x1080, 4-level pyramid, 4000 kps/frame, 4000x4000 knn both directions, essential RANSAC with a FIXED "
                      "2000 iterations on the un-gridded symmetric matches (pose_input = SYM) + recoverPose; 128 frames per step"))
         q5 = vislam.default_params()
