@@ -43,8 +43,16 @@ def check_line(s, full):
 def test_committed_records_format(path):
     txt = open(path).read()
     full = strict(txt if txt.lstrip().startswith("{") else [l for l in txt.splitlines() if l.startswith("{")][-1])
-    if "legs" not in full and "cpu_baseline" not in full and len(txt) < 2500:
-        pytest.skip("a compact line, not a full record")
+    if "full" in full and len(txt) < 2500:
+        # a committed COMPACT line (the stdout of a bench run, profiles/r06_bench.json): it must itself satisfy the contract, and the full
+        # record it names travels beside it
+        c = check_line(txt.strip(), full)
+        assert c["roofline"]["kernel"].startswith("k_") and c["cpu_baseline"]["kind"] == "port" and c["t1"]["target"] == 0.4
+        beside = os.path.join(os.path.dirname(path), os.path.basename(path).replace(".json", "_full.json"))
+        assert os.path.exists(beside), beside
+        fr = strict(open(beside).read())
+        assert abs(fr["value"] - c["value"]) <= 1e-5 * fr["value"] and benchline.compact_line(fr, c["full"]) == txt.strip()
+        return
     c = check_line(benchline.compact_line(full, "gpurun_out/bench_full.json"), full)
     if "cpu_baseline" in full:
         assert c["cpu_baseline"]["kind"] in ("port", "reference") and c["cpu_baseline"]["cores"] >= 1 and len(c["cpu_baseline"]["sample"]) <= 80
