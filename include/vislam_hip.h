@@ -283,15 +283,18 @@ int  vis_batch_align(vis_ctx* ctx, const vis_align_params* ap, const uint8_t* d_
                      const vis_se3f* d_init, vis_align_result* d_out);
 
 /* ---- frame ingest (src/ImageReader.cpp) ------------------------------------- */
-/* ImageReader::searchImages (src/ImageReader.cpp:49-74): the .pgm / .raw files of `dir` in byte order, names
+/* ImageReader::searchImages (src/ImageReader.cpp:49-74): the .pgm / .raw / .png files of `dir` in byte order, names
  * separated by '\n' in names_out (cap_bytes); *count = number of files.  names_out may be NULL to only count.
  * ("." and ".." are skipped by name; the reference erases the first two sorted entries.) */
 int  vis_image_list(const char* dir, char* names_out, int cap_bytes, int* count);
 /* ImageReader::getImageTime (:41-47): atol of the file name's stem (EuRoC names its images <timestamp ns>.ext) */
 long vis_image_time(const char* file_name);
 /* stand-in for imread(..., CV_LOAD_IMAGE_GRAYSCALE) (:80-82) on the formats this build reads: binary PGM
- * (P5, maxval <= 255, '#' comments allowed) and headerless raw (w*h bytes) */
+ * (P5, maxval <= 255, '#' comments allowed), headerless raw (w*h bytes) and greyscale PNG (what EuRoC ships: colour
+ * type 0 or 4, 8 or 16 bit -- the high byte --, non-interlaced; chunk CRCs checked; colour / interlaced PNGs are
+ * refused with VIS_E_INVALID).  vis_image_info tells PGM from PNG by the magic bytes. */
 int  vis_pgm_info(const char* path, int* w, int* h);
+int  vis_image_info(const char* path, int* w, int* h);
 int  vis_image_read(const char* path, uint8_t* out, int out_stride, int w, int h);
 /* Pinned-host double-buffered H2D feeder for vis_batch_run: fill vis_feeder_host_buffer(f, k) (batch x h x w,
  * dense; blocks while an earlier copy out of it is in flight), vis_feeder_submit(f, k, n, &d) enqueues the copy on a

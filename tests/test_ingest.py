@@ -1,5 +1,5 @@
 """frame ingest.  CPU part (no GPU needed): directory listing / timestamp stems as
-/root/reference/src/ImageReader.cpp:22-78 does them, PGM (P5) and raw decode in place of cv::imread.
+/root/reference/src/ImageReader.cpp:22-78 does them, PGM (P5), raw and greyscale PNG decode in place of cv::imread.
 GPU part: the pinned double-buffered feeder feeds the pipeline through files -> reader -> pinned buffer -> device and
 the result is identical to running on frames that were resident all along."""
 import os
@@ -64,6 +64,107 @@ def test_pgm_and_raw_decode(vislam, tmp_path):
         vislam.image_read(p, 64, 48)
     with pytest.raises(vislam.VisError):
         vislam.image_read(str(tmp_path / "nope.pgm"))
+
+
+def _png_chunk(tag, data):
+    import struct
+    import zlib
+    return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+
+def _write_png(path, samples, depth=8, color=0, filters=None, idat_split=None, interlace=0, corrupt_crc=False, level=6):
+    """a PNG writer for the tests, from the specification: `samples` = (h, w, channels) integer array of `depth`-bit samples;
+    `filters` = the filter type of every row (default: 0..4 in turn); the scanline filters are applied here, byte by byte"""
+    import struct
+    import zlib
+    h, w, ch = samples.shape
+    bps = depth // 8
+    if depth == 16:
+        rows = samples.astype(">u2").tobytes()
+    else:
+        rows = samples.astype(np.uint8).tobytes()
+    rowb, bpp = w * ch * bps, ch * bps
+    raw = bytearray()
+    prev = bytes(rowb)
+    for y in range(h):
+        cur = rows[y * rowb:(y + 1) * rowb]
+        ft = (filters[y] if filters is not None else y % 5)
+        out = bytearray(rowb)
+        for i in range(rowb):
+            a = cur[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            if ft == 0:
+                pr = 0
+            elif ft == 1:
+                pr = a
+            elif ft == 2:
+                pr = b
+            elif ft == 3:
+                pr = (a + b) >> 1
+            else:
+                pp = a + b - c
+                pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - c)
+                pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            out[i] = (cur[i] - pr) & 0xFF
+        raw += bytes([ft]) + out
+        prev = cur
+    z = zlib.compress(bytes(raw), level)
+    parts = [z] if not idat_split else [z[i:i + idat_split] for i in range(0, len(z), idat_split)]
+    blob = b"\x89PNG\r\n\x1a\n" + _png_chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color, 0, 0, interlace))
+    blob += _png_chunk(b"tEXt", b"Comment\x00EuRoC-shaped test frame")           # an ancillary chunk in front of the data
+    for part in parts:
+        blob += _png_chunk(b"IDAT", part)
+    blob += _png_chunk(b"IEND", b"")
+    if corrupt_crc:
+        i = blob.index(b"IDAT") + 8
+        blob = blob[:i] + bytes([blob[i] ^ 0x40]) + blob[i + 1:]
+    with open(path, "wb") as f:
+        f.write(blob)
+
+
+def test_png_decode_greyscale_as_imread_would(vislam, tmp_path):
+    """EuRoC ships cam0 as 8-bit greyscale PNG (the reference decodes it with imread(..., CV_LOAD_IMAGE_GRAYSCALE), src/ImageReader.cpp:80-82).
+    Every scanline filter, several IDAT chunks, 16-bit samples (high byte), grey + alpha (alpha dropped), a 752x480 frame; what imread would
+    push through libpng's colour conversion (RGB, palette) or de-interlacing is refused, as are damaged files."""
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    img[5:9, :] = 0
+    img[20, :] = 255                                                   # rows that wrap around in the filters' byte arithmetic
+    p = str(tmp_path / "1403636579763555584.png")
+    _write_png(p, img[:, :, None])
+    assert (vislam.image_read(p) == img).all()
+    for ft in range(5):                                                # one filter type for the whole image, each in turn
+        _write_png(p, img[:, :, None], filters=[ft] * img.shape[0], idat_split=97)
+        assert (vislam.image_read(p) == img).all(), ft
+    g16 = rng.integers(0, 65536, (19, 31), dtype=np.uint16)
+    _write_png(p, g16[:, :, None], depth=16)
+    assert (vislam.image_read(p) == (g16 >> 8).astype(np.uint8)).all()
+    ga = rng.integers(0, 256, (23, 29, 2), dtype=np.uint8)
+    _write_png(p, ga, color=4)
+    assert (vislam.image_read(p) == ga[:, :, 0]).all()
+    ga16 = rng.integers(0, 65536, (9, 14, 2), dtype=np.uint16)
+    _write_png(p, ga16, depth=16, color=4)
+    assert (vislam.image_read(p) == (ga16[:, :, 0] >> 8).astype(np.uint8)).all()
+    frame = vislam.synth_frame(vislam.synth_canvas(1024, 5), 3, 752, 480, 5)
+    _write_png(p, frame[:, :, None], level=1)
+    assert (vislam.image_read(p) == frame).all() and (vislam.image_read(p, 752, 480) == frame).all()
+    assert vislam.image_list(str(tmp_path)) == ["1403636579763555584.png"] and vislam.image_time(p) == 1403636579763555584
+    # refused, not guessed
+    rgb = rng.integers(0, 256, (8, 8, 3), dtype=np.uint8)
+    bad = str(tmp_path / "bad.png")
+    for kw, arr in ((dict(color=2), rgb), (dict(interlace=1), img[:, :, None]), (dict(corrupt_crc=True), img[:, :, None])):
+        _write_png(bad, arr, **kw)
+        with pytest.raises(vislam.VisError):
+            vislam.image_read(bad)
+    _write_png(bad, img[:, :, None])
+    blob = open(bad, "rb").read()
+    open(bad, "wb").write(blob[:len(blob) // 2])                       # truncated
+    with pytest.raises(vislam.VisError):
+        vislam.image_read(bad)
+    _write_png(bad, img[:, :, None])
+    with pytest.raises(vislam.VisError):
+        vislam.image_read(bad, 64, 48)                                 # wrong size requested
 
 
 @pytest.mark.gpu

@@ -1,7 +1,12 @@
 // ingest.hip -- frame ingest for the throughput path: image directory listing and timestamp
-// stems as /root/reference/src/ImageReader.cpp:22-78 does them, a PGM (P5) / raw 8-bit reader in place of
+// stems as /root/reference/src/ImageReader.cpp:22-78 does them, a PGM (P5) / raw 8-bit / greyscale PNG reader in place of
 // cv::imread(..., CV_LOAD_IMAGE_GRAYSCALE) (:80-82), and a pinned-host double-buffered H2D feeder so that batch k+1
 // is copied while batch k is processed.  No kernels here: host code + HIP runtime copies.
+// PNG (round 6): EuRoC ships cam0 as 8-bit greyscale PNG, which is what the reference's imread decodes.  The decoder here
+// handles exactly the lossless cases in which imread's answer is defined by the PNG specification alone -- colour type 0 (grey)
+// and 4 (grey + alpha: the alpha channel is dropped), bit depth 8 and 16 (the high byte, as libpng's strip_16), non-interlaced --
+// chunk CRCs checked, zlib's inflate for the stream.  Colour PNGs are refused: imread would go through libpng's rgb_to_gray,
+// whose rounding is not restated here.
 #include "vis_internal.h"
 #include <dirent.h>
 #include <sys/stat.h>
@@ -9,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <zlib.h>
 
 // ---- directory listing (ImageReader::searchImages, :49-74) -------------------------------------------------------
 // The reference sorts ALL directory entries and drops the first two, assuming they are "." and ".."; here the two
@@ -27,7 +33,7 @@ extern "C" int vis_image_list(const char* dir, char* names_out, int cap_bytes, i
         if (dot == std::string::npos) continue;
         std::string ext = n.substr(dot);
         for (auto& c : ext) c = (char)tolower((unsigned char)c);
-        if (ext != ".pgm" && ext != ".raw") continue;
+        if (ext != ".pgm" && ext != ".raw" && ext != ".png") continue;
         struct stat st;
         if (stat((base + n).c_str(), &st) != 0 || !S_ISREG(st.st_mode)) continue;
         names.push_back(n);
@@ -90,7 +96,84 @@ extern "C" int vis_pgm_info(const char* path, int* w, int* h) {
     return rc;
 }
 
-// reads a w x h image into out (row stride out_stride); a .raw file is w*h bytes without header
+// ---- PNG (greyscale, 8 / 16 bit, optional alpha, non-interlaced) ------------------------------------------------------
+struct PngHead { int w = 0, h = 0, depth = 0, color = 0, interlace = 0; };
+static uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+static bool is_png_magic(const uint8_t* p) { static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A}; return std::memcmp(p, sig, 8) == 0; }
+
+// walks the chunks of a PNG file: header fields, and (idat != nullptr) the concatenated IDAT payload.  Every chunk's CRC is checked.
+static int png_parse(const char* path, PngHead* hd, std::vector<uint8_t>* idat) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return VIS_E_STATE;
+    std::vector<uint8_t> buf;
+    {
+        uint8_t tmp[65536]; size_t n;
+        while ((n = std::fread(tmp, 1, sizeof(tmp), f)) > 0) { buf.insert(buf.end(), tmp, tmp + n); if (buf.size() > ((size_t)1 << 30)) break; }
+        std::fclose(f);
+    }
+    if (buf.size() < 8 + 25 || !is_png_magic(buf.data())) return VIS_E_INVALID;
+    size_t pos = 8; bool have_head = false, have_end = false;
+    while (pos + 12 <= buf.size()) {
+        const uint32_t len = be32(&buf[pos]);
+        if (len > buf.size() || pos + 12 + (size_t)len > buf.size()) return VIS_E_INVALID;                 // truncated
+        const uint8_t* type = &buf[pos + 4]; const uint8_t* data = &buf[pos + 8];
+        if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), type, 4 + len) != be32(data + len)) return VIS_E_INVALID;
+        if (!have_head) {
+            if (std::memcmp(type, "IHDR", 4) != 0 || len != 13) return VIS_E_INVALID;
+            hd->w = (int)be32(data); hd->h = (int)be32(data + 4); hd->depth = data[8]; hd->color = data[9]; hd->interlace = data[12];
+            if (hd->w < 1 || hd->h < 1 || hd->w > (1 << 16) || hd->h > (1 << 16) || data[10] != 0 || data[11] != 0) return VIS_E_INVALID;
+            have_head = true;
+            if (!idat) return VIS_OK;
+        } else if (std::memcmp(type, "IDAT", 4) == 0) idat->insert(idat->end(), data, data + len);
+        else if (std::memcmp(type, "IEND", 4) == 0) { have_end = true; break; }
+        pos += 12 + (size_t)len;
+    }
+    return have_head && have_end ? VIS_OK : VIS_E_INVALID;
+}
+
+static int png_read(const char* path, uint8_t* out, int out_stride, int w, int h) {
+    PngHead hd; std::vector<uint8_t> idat;
+    int rc = png_parse(path, &hd, &idat);
+    if (rc) return rc;
+    if (hd.w != w || hd.h != h) return VIS_E_INVALID;
+    if ((hd.color != 0 && hd.color != 4) || (hd.depth != 8 && hd.depth != 16) || hd.interlace != 0) return VIS_E_INVALID;   // see the file header
+    const int bpp = (hd.color == 4 ? 2 : 1) * (hd.depth / 8);            // bytes per pixel = the filters' left-neighbour distance
+    const size_t rowb = (size_t)w * bpp;
+    std::vector<uint8_t> raw((rowb + 1) * (size_t)h);
+    uLongf got = (uLongf)raw.size();
+    if (uncompress(raw.data(), &got, idat.data(), (uLong)idat.size()) != Z_OK || got != raw.size()) return VIS_E_INVALID;
+    std::vector<uint8_t> zero(rowb, 0);
+    const uint8_t* prev = zero.data();
+    for (int y = 0; y < h; y++) {
+        uint8_t* line = raw.data() + (size_t)y * (rowb + 1);
+        const int ft = line[0]; uint8_t* cur = line + 1;
+        if (ft > 4) return VIS_E_INVALID;
+        for (size_t i = 0; i < rowb; i++) {                               // PNG specification 9.2: Sub, Up, Average, Paeth on bytes
+            const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= (size_t)bpp ? prev[i - bpp] : 0;
+            int pr = 0;
+            if (ft == 1) pr = a; else if (ft == 2) pr = b; else if (ft == 3) pr = (a + b) >> 1;
+            else if (ft == 4) { const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+            cur[i] = (uint8_t)(cur[i] + pr);
+        }
+        uint8_t* o = out + (size_t)y * out_stride;
+        for (int x = 0; x < w; x++) o[x] = cur[(size_t)x * bpp];          // grey sample, its high byte at 16 bit; alpha dropped
+        prev = cur;
+    }
+    return VIS_OK;
+}
+
+// width and height of a PGM (P5) or PNG file, by its magic bytes
+extern "C" int vis_image_info(const char* path, int* w, int* h) {
+    if (!path || !w || !h) return VIS_E_INVALID;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return VIS_E_STATE;
+    uint8_t m[8] = {0}; const size_t n = std::fread(m, 1, 8, f);
+    std::fclose(f);
+    if (n == 8 && is_png_magic(m)) { PngHead hd; const int rc = png_parse(path, &hd, nullptr); *w = hd.w; *h = hd.h; return rc; }
+    return vis_pgm_info(path, w, h);
+}
+
+// reads a w x h image into out (row stride out_stride); a .raw file is w*h bytes without header, anything else is told by its magic bytes
 extern "C" int vis_image_read(const char* path, uint8_t* out, int out_stride, int w, int h) {
     if (!path || !out || w < 1 || h < 1 || out_stride < w) return VIS_E_INVALID;
     const char* dot = std::strrchr(path, '.');
@@ -98,6 +181,11 @@ extern "C" int vis_image_read(const char* path, uint8_t* out, int out_stride, in
     FILE* f = nullptr;
     if (raw) { f = std::fopen(path, "rb"); if (!f) return VIS_E_STATE; }
     else {
+        f = std::fopen(path, "rb");
+        if (!f) return VIS_E_STATE;
+        uint8_t m[8] = {0}; const size_t n = std::fread(m, 1, 8, f);
+        std::fclose(f); f = nullptr;
+        if (n == 8 && is_png_magic(m)) return png_read(path, out, out_stride, w, h);
         int fw = 0, fh = 0;
         const int rc = pgm_open(path, &f, &fw, &fh);
         if (rc) return rc;

@@ -367,7 +367,7 @@ Mat ImageReader::getImage(int index) {                                          
     const string& f = file_names[(size_t)index];
     int w = raw_w, h = raw_h;
     const bool raw = f.size() > 4 && f.compare(f.size() - 4, 4, ".raw") == 0;
-    if (!raw && vis_pgm_info(f.c_str(), &w, &h) != 0) return Mat();               // imread returns an empty Mat on failure
+    if (!raw && vis_image_info(f.c_str(), &w, &h) != 0) return Mat();             // (PGM or greyscale PNG by its magic bytes) imread returns an empty Mat on failure
     if (w < 1 || h < 1) return Mat();
     Mat m(h, w, CV_8U);
     if (vis_image_read(f.c_str(), m.data, (int)m.step, w, h) != 0) return Mat();

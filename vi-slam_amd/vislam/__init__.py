@@ -112,7 +112,7 @@ ABI_SYMBOLS = [
     "vis_batch_sync", "vis_batch_get_keypoints", "vis_batch_get_knn", "vis_batch_get_matches",
     "vis_batch_get_pose", "vis_batch_get_inlier_mask", "vis_debug_counters", "vis_device_pci_bus_id", "vis_batch_status", "vis_synth_canvas", "vis_synth_frame",
     "vis_gradient_frame_elems", "vis_half_pyramid_dims", "vis_gradient_batch", "vis_compute_gradient", "vis_patch_points",
-    "vis_image_list", "vis_image_time", "vis_pgm_info", "vis_image_read",
+    "vis_image_list", "vis_image_time", "vis_pgm_info", "vis_image_info", "vis_image_read",
     "vis_feeder_create", "vis_feeder_destroy", "vis_feeder_host_buffer", "vis_feeder_submit", "vis_feeder_release",
     "vis_default_align_params", "vis_estimate_pose_features", "vis_align_batch", "vis_batch_align",
     "vis_synth_frame_parallax", "vis_synth_frames_device", "vis_batch_results_async", "vis_batch_half_pyramid", "vis_batch_gradients", "vis_batch_fast_thresholds",
@@ -176,6 +176,7 @@ def _load():
     lib.vis_image_time.argtypes = [C.c_char_p]
     lib.vis_image_time.restype = C.c_long
     lib.vis_pgm_info.argtypes = [C.c_char_p, ip, ip]
+    lib.vis_image_info.argtypes = [C.c_char_p, ip, ip]
     lib.vis_image_read.argtypes = [C.c_char_p, vp, ci, ci, ci]
     lib.vis_feeder_create.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_void_p)]
     lib.vis_feeder_destroy.argtypes = [vp]
@@ -300,9 +301,9 @@ def image_time(name):
 def image_read(path, w=None, h=None):
     if w is None:
         cw, ch = C.c_int(0), C.c_int(0)
-        rc = lib.vis_pgm_info(path.encode(), C.byref(cw), C.byref(ch))
+        rc = lib.vis_image_info(path.encode(), C.byref(cw), C.byref(ch))
         if rc != 0:
-            raise VisError(rc, "vis_pgm_info")
+            raise VisError(rc, "vis_image_info")
         w, h = cw.value, ch.value
     out = np.empty((h, w), np.uint8)
     rc = lib.vis_image_read(path.encode(), _ptr(out), w, w, h)
