@@ -89,6 +89,11 @@ def _write_png(path, samples, depth=8, color=0, filters=None, idat_split=None, i
     for y in range(h):
         cur = rows[y * rowb:(y + 1) * rowb]
         ft = (filters[y] if filters is not None else y % 5)
+        if ft in (0, 2):                                             # vectorised (whole frames in the directory test)
+            ca, pa_ = np.frombuffer(cur, np.uint8), np.frombuffer(prev, np.uint8)
+            raw += bytes([ft]) + (ca if ft == 0 else (ca - pa_)).astype(np.uint8).tobytes()
+            prev = cur
+            continue
         out = bytearray(rowb)
         for i in range(rowb):
             a = cur[i - bpp] if i >= bpp else 0
@@ -203,3 +208,27 @@ def test_feeder_round_trip_and_pipeline_equality(vislam, ctx, canvas, tmp_path):
             k0, d0 = got[k][i]
             assert (k1 == k0).all() and (d1 == d0).all(), (k, i)
             assert str(ctx.batch_pose(i)) == str(got[k][B + i]), (k, i)
+
+
+@pytest.mark.gpu
+def test_directory_harness_on_a_euroc_shaped_png_directory(built, vislam, canvas, tmp_path):
+    """tools/run_directory.py = BASELINE configs[0] on a supplied dataset (none ships with the image): an EuRoC-shaped directory -- 752x480
+    8-bit greyscale PNGs named by nanosecond timestamps 50 ms apart, plus a file that is not an image -- through listing, PNG decode, the
+    pinned feeder and the batched pipeline with ORB::create(200); every frame checked against the CPU oracle by the tool itself."""
+    import json
+    import subprocess
+    import sys
+    d = tmp_path / "mav0" / "cam0" / "data"
+    d.mkdir(parents=True)
+    n = 12
+    for t in range(n):
+        _write_png(str(d / f"{1403636579763555584 + 50000000 * t}.png"), vislam.synth_frame(canvas, t, 752, 480)[:, :, None], filters=[0, 2] * 240, level=1)
+    (d / "data.csv").write_text("#timestamp [ns],filename\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "run_directory.py"), str(d), "--frames", "200", "--batch", "5", "--check", str(n), "--cpu-seconds", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["frames"] == n and j["width"] == 752 and j["height"] == 480 and j["first_timestamp"] == 1403636579763555584
+    assert j["median_frame_interval_ns"] == 50000000 and j["checked_frames"] == n and j["frames_differing_from_the_oracle"] == []
+    assert 180 <= j["keypoints_mean"] <= 260 and j["good_matches_mean"] > 10 and j["cpu_baseline"]["value"] > 0
