@@ -1253,7 +1253,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96), DESC_WAVES
             const uint32_t ab = (uint32_t)(int)__fmaf_rn(rx, (float)(HTS * 2), __fmaf_rn(ry, 2.f, tap0_f));
             const uint32_t* cw = (const uint32_t*)(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(ab & ~3u);
             (void)cw;
-            const uint32_t sh = ab & 2u;
+            const uint32_t sh = ab;                                  // v_alignbyte_b32 shifts by bits [1:0] of its third operand (0 or 2 here: the address is even)
 #if defined(VIS_TIMING_NOCONFLICT)       // timing experiment (results wrong): every lane gathers at its own bank
             cw = (const uint32_t*)(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(hb32) + 16u * (uint32_t)lane + (ab & 0x800u));
 #endif
