@@ -108,8 +108,9 @@ static int png_parse(const char* path, PngHead* hd, std::vector<uint8_t>* idat) 
     std::vector<uint8_t> buf;
     {
         uint8_t tmp[65536]; size_t n;
-        while ((n = std::fread(tmp, 1, sizeof(tmp), f)) > 0) { buf.insert(buf.end(), tmp, tmp + n); if (buf.size() > ((size_t)1 << 30)) break; }
+        while ((n = std::fread(tmp, 1, sizeof(tmp), f)) > 0) { buf.insert(buf.end(), tmp, tmp + n); if (buf.size() > ((size_t)1 << 28)) break; }
         std::fclose(f);
+        if (buf.size() > ((size_t)1 << 28)) return VIS_E_INVALID;          // (a 16384 x 16384 16-bit grey + alpha image is 1 GiB raw; no camera frame's file is 256 MiB)
     }
     if (buf.size() < 8 + 25 || !is_png_magic(buf.data())) return VIS_E_INVALID;
     size_t pos = 8; bool have_head = false, have_end = false;
@@ -131,7 +132,12 @@ static int png_parse(const char* path, PngHead* hd, std::vector<uint8_t>* idat) 
     return have_head && have_end ? VIS_OK : VIS_E_INVALID;
 }
 
+static int png_read_impl(const char* path, uint8_t* out, int out_stride, int w, int h);
+// (files are untrusted input: whatever they make the containers throw ends as an error code at the C boundary, never as an exception)
 static int png_read(const char* path, uint8_t* out, int out_stride, int w, int h) {
+    try { return png_read_impl(path, out, out_stride, w, h); } catch (...) { return VIS_E_NOMEM; }
+}
+static int png_read_impl(const char* path, uint8_t* out, int out_stride, int w, int h) {
     PngHead hd; std::vector<uint8_t> idat;
     int rc = png_parse(path, &hd, &idat);
     if (rc) return rc;
@@ -169,7 +175,11 @@ extern "C" int vis_image_info(const char* path, int* w, int* h) {
     if (!f) return VIS_E_STATE;
     uint8_t m[8] = {0}; const size_t n = std::fread(m, 1, 8, f);
     std::fclose(f);
-    if (n == 8 && is_png_magic(m)) { PngHead hd; const int rc = png_parse(path, &hd, nullptr); *w = hd.w; *h = hd.h; return rc; }
+    if (n == 8 && is_png_magic(m)) {
+        PngHead hd; int rc;
+        try { rc = png_parse(path, &hd, nullptr); } catch (...) { return VIS_E_NOMEM; }
+        *w = hd.w; *h = hd.h; return rc;
+    }
     return vis_pgm_info(path, w, h);
 }
 
