@@ -395,7 +395,8 @@ int vis_build_sample_table(vis_ctx* ctx, int max_m) {
     if (ctx->d_sample_table && ctx->sample_max_m >= max_m && ctx->sample_iters == iters && ctx->sample_seed == ctx->p.ransac_seed) return VIS_OK;
     if (ctx->d_sample_table) { sync_all(ctx); (void)hipFree(ctx->d_sample_table); ctx->d_sample_table = nullptr; ctx->sample_max_m = 0; }
     if (max_m < 6) return VIS_OK;                                  // no table: device replay
-    std::vector<int32_t> tab((size_t)(max_m - 5) * iters * 5);
+    std::vector<int32_t> tab;                                      // up to 256 MB of host memory: an allocation failure is an error code, not an exception across the C ABI
+    try { tab.resize((size_t)(max_m - 5) * iters * 5); } catch (...) { ctx->err = "sample table: host allocation failed"; return VIS_E_NOMEM; }
     for (int M = 6; M <= max_m; M++) {
         unsigned long long state = ctx->p.ransac_seed ? ctx->p.ransac_seed : 0xffffffffULL;
         int32_t* dst = tab.data() + (size_t)(M - 6) * iters * 5;
