@@ -804,7 +804,7 @@ def main():
                     d["limited_by"] = "lds"
                 elif (d["lds_busy_frac"] or 0) >= 0.85 and d["limited_by"] == "valu-issue":
                     # round 4: k_describe's LDS array is busy ~90 % of the launch (57 % of that bank conflicts of the sample gathers) while vector
-                    # issue sits at its half-rate ceiling: removing a fifth of its vector instructions moved it by 2 %
+                    # issue sits at its half-rate ceiling: removing a fifth of its vector instructions moved it by 2 % (DESIGN_history.md section 4, Round 4)
                     d["limited_by"] = "lds + valu-issue"
                 detect_kernels[kn] = d
             dk = detect_kernels[kname]

@@ -161,7 +161,7 @@ def test_config3_batched_path_that_the_bench_times(vislam, orc, big_canvas):
     """bench.py's config-3 leg: a BATCH of 1920x1080 frames, 4 levels, 4000 keypoints, RANSAC with 2000 fixed iterations on the
     un-gridded symmetric matches (pose_input = SYM), through vis_batch_run(STAGE_FRAME) -- the launch sequence the leg times, not the
     single-frame entry points -- against the oracle per frame / pair: keypoints, descriptors, both 2-NN tables, symmetric and good
-    matches, inlier masks, inlier counts and iteration numbers exact; E <= 1e-9, R <= 1e-7 (the batch tolerances of DESIGN section 1)."""
+    matches, inlier masks, inlier counts and iteration numbers exact; E <= 1e-9, R <= 1e-7 (the batch tolerances of DESIGN.md section 2)."""
     import torch
     p = vislam.default_params()
     p.nfeatures, p.nlevels, p.w_size, p.h_size = 4000, 4, 1920, 1080
@@ -254,7 +254,7 @@ def test_config5_batched_path_that_the_bench_times(vislam, orc, big_canvas):
     frame), not the single-frame entry points.  Keypoints + descriptors of the first, the second-to-last and the last frame exact against
     the oracle; Camera::Update's half pyramid of the last frame exact; both 2-NN tables of the last pair on >= 100 sampled rows against a
     numpy popcount over all train descriptors; symmetric / good matches exact (the oracle's filter chain on the GPU's own tables); the
-    pose record against the oracle's essential RANSAC + recoverPose on those good matches (E <= 1e-9, R <= 1e-7: DESIGN section 1).
+    pose record against the oracle's essential RANSAC + recoverPose on those good matches (E <= 1e-9, R <= 1e-7: DESIGN.md section 2).
     A second launch continues the stream: its frame 0 is matched against the carried last frame of the first launch."""
     import torch
     p = vislam.default_params()

@@ -1,6 +1,6 @@
 """Fixed-seed slices of the randomised parity tools (tools/stress_*.py: random problems through the C ABI against the oracle, bit for bit /
 to the stated tolerances) so that the driver's `pytest -m gpu` record shows them: a few seconds each, the same seeds and the same NUMBER of cases every run.  The
-tools themselves run for minutes with other seeds (DESIGN: randomised parity runs); they found two real bugs in round 4."""
+tools themselves run for minutes with other seeds (earlier rounds: DESIGN_history.md); they found two real bugs in round 4."""
 import os
 import subprocess
 import sys
@@ -28,7 +28,7 @@ def test_stress_slice(built, tool, cases, seed):
 @pytest.mark.parametrize("mode", ["parallax", "main"])
 def test_soak_slice(built, mode):
     """tools/soak_pipeline.py for a few seconds: every pass over a ring of resident frames (launches queued back to back, results into
-    pinned memory behind each launch) reproduces pass 0's records byte for byte (minutes of it: DESIGN, randomised parity runs).
+    pinned memory behind each launch) reproduces pass 0's records byte for byte (minutes of it: DESIGN.md section 4.3).
     "main" = the GPU main's sequence: gradients on the side stream into the plan's two sets in turn, vis_batch_align on the pose stream."""
     passes = 12                                                     # a pass count, not seconds: the same work on every box (150 s guard)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_pipeline.py"), "150", "64", "6", mode, str(passes)], capture_output=True, text=True, timeout=300)
