@@ -17,6 +17,6 @@ for r in rows:
     if r["Kernel_Name"].startswith(k) or k == "*":
         last.setdefault(r["Kernel_Name"][:48], []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000)
 for n, v in last.items():
-    print(os.path.basename(lib).ljust(26), n.ljust(48), "last", [round(x, 1) for x in v[-3:]])
+    print(os.path.basename(lib).ljust(26), n.ljust(48), "last", [round(x, 1) for x in v[-int(os.environ.get("KAB_LAST", "3")):]])
 PY
 done

@@ -195,7 +195,11 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
         const uint32_t sel[4] = {s4.x, s4.y, s4.z, s4.w}, coef[4] = {c4.x, c4.y, c4.z, c4.w};
         const uint32_t wb = m4.x, keep = m4.y, asel = m4.z;
         uint8_t* dbase = dst + (size_t)f * dframe + dx4;
+#ifdef VIS_TIMING_RESIZE_SRC_CACHED     // timing experiment (results wrong): every frame reads the source of frames 0 .. 7 -- the chain as if its sources were on chip
+        const uint8_t* fbase = src + (size_t)(sw < 752 ? (f & 7) : f) * sframe;
+#else
         const uint8_t* fbase = src + (size_t)f * sframe;
+#endif
         const uint4* yrow = yc + (dy0 - row_first);
         uint32_t YX[RS_ROWS], YY[RS_ROWS];
 #pragma unroll
